@@ -1,0 +1,121 @@
+"""ctypes binding of libecad_hip.so (the C ABI in include/ecad_hip.h).
+
+There is NO fallback: if the shared library is missing or does not export the ABI,
+importing a symbol raises immediately (``EcadLibraryError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_NAME = "libecad_hip.so"
+ABI_VERSION = 1
+
+ECAD_DTYPE_F16, ECAD_DTYPE_BF16, ECAD_DTYPE_F32 = 0, 1, 2
+ECAD_E_INVALID, ECAD_E_HIP, ECAD_E_NOT_READY, ECAD_E_UNSUPPORTED = -1, -2, -3, -4
+
+
+class EcadLibraryError(RuntimeError):
+    pass
+
+
+class EcadModelCfg(C.Structure):
+    _fields_ = [
+        ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("head_dim", C.c_int32),
+        ("in_channels", C.c_int32),
+        ("out_channels", C.c_int32),
+        ("patch_size", C.c_int32),
+        ("sample_size", C.c_int32),
+        ("caption_channels", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("max_tokens", C.c_int32),
+        ("max_text_tokens", C.c_int32),
+        ("dtype", C.c_int32),
+        ("norm_eps", C.c_float),
+        ("interpolation_scale", C.c_float),
+    ]
+
+
+class EcadStats(C.Structure):
+    _fields_ = [
+        ("components_executed", C.c_int64),
+        ("components_cached", C.c_int64),
+        ("linear_macs_reference", C.c_int64),
+        ("linear_macs_executed", C.c_int64),
+        ("attn_core_macs", C.c_int64),
+        ("cache_bytes_read", C.c_int64),
+        ("cache_bytes_written", C.c_int64),
+        ("cache_arena_bytes", C.c_int64),
+        ("weight_bytes", C.c_int64),
+        ("workspace_bytes", C.c_int64),
+        ("graph_nodes", C.c_int32),
+        ("launches_per_batch", C.c_int32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+_P = C.c_void_p
+_I = C.c_int
+_I64 = C.c_int64
+
+# name -> (restype, argtypes); every symbol include/ecad_hip.h declares
+SIGNATURES = {
+    "ecad_abi_version": (_I, []),
+    "ecad_create": (_I, [C.POINTER(EcadModelCfg), _I, C.POINTER(_P)]),
+    "ecad_destroy": (None, [_P]),
+    "ecad_last_error": (C.c_char_p, [_P]),
+    "ecad_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
+    "ecad_finalize_weights": (_I, [_P]),
+    "ecad_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),
+    "ecad_begin_image_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
+    "ecad_step": (_I, [_P, _I, _P, _P, _P, _P]),
+    "ecad_run_schedule": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, _I, _P]),
+    "ecad_reset_cache": (_I, [_P]),
+    "ecad_cache_stats": (_I, [_P, C.POINTER(EcadStats)]),
+    "ecad_set_profiling": (_I, [_P, _I]),
+    "ecad_get_profile": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ecad_op_gemm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I64, _I, _P]),
+    "ecad_op_ln_modulate": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _I64, _I, _P]),
+    "ecad_op_cache_accumulate": (_I, [_P, _P, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _I64, _I, _P]),
+    "ecad_op_attention": (_I, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    env = os.environ.get("ECAD_HIP_LIB")
+    return Path(env) if env else Path(__file__).resolve().parent / LIB_NAME
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every declared symbol; raise loudly otherwise."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise EcadLibraryError(
+            f"{path} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C ecad_amd/csrc`. There is no CPU fallback for the hot path."
+        )
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise EcadLibraryError(f"failed to load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EcadLibraryError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ecad_abi_version() != ABI_VERSION:
+        raise EcadLibraryError(f"ABI version mismatch: library {lib.ecad_abi_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib

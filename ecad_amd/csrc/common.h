@@ -1,0 +1,114 @@
+// common.h -- element types, vector types, MFMA / LDS-DMA wrappers for gfx950 (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ecad {
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define ECAD_DEV __device__ __forceinline__
+
+template <typename T> struct Vec8;
+template <> struct Vec8<f16_t> { typedef f16x8 type; };
+template <> struct Vec8<bf16_t> { typedef bf16x8 type; };
+
+// 8 elements (16 bytes) as a raw register quad; all global/LDS traffic moves in these.
+union Pack8 {
+  u32x4 u;
+  i16x8 s;
+  f16x8 h;
+  bf16x8 b;
+  f16_t he[8];
+  bf16_t be[8];
+};
+union Pack4 {
+  u32x2 u;
+  i16x4 s;
+  f16_t he[4];
+  bf16_t be[4];
+};
+
+template <typename T> ECAD_DEV float elem_to_float(const Pack8& p, int i);
+template <> ECAD_DEV float elem_to_float<f16_t>(const Pack8& p, int i) { return (float)p.he[i]; }
+template <> ECAD_DEV float elem_to_float<bf16_t>(const Pack8& p, int i) { return (float)p.be[i]; }
+template <typename T> ECAD_DEV void float_to_elem(Pack8& p, int i, float v);
+template <> ECAD_DEV void float_to_elem<f16_t>(Pack8& p, int i, float v) { p.he[i] = (f16_t)v; }
+template <> ECAD_DEV void float_to_elem<bf16_t>(Pack8& p, int i, float v) { p.be[i] = (bf16_t)v; }
+template <typename T> ECAD_DEV void float_to_elem4(Pack4& p, int i, float v);
+template <> ECAD_DEV void float_to_elem4<f16_t>(Pack4& p, int i, float v) { p.he[i] = (f16_t)v; }
+template <> ECAD_DEV void float_to_elem4<bf16_t>(Pack4& p, int i, float v) { p.be[i] = (bf16_t)v; }
+
+template <typename T> ECAD_DEV void unpack8(const Pack8& p, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = elem_to_float<T>(p, i);
+}
+template <typename T> ECAD_DEV Pack8 pack8(const float (&f)[8]) {
+  Pack8 p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) float_to_elem<T>(p, i, f[i]);
+  return p;
+}
+// round-trip through the storage type (what the reference's half tensors do)
+template <typename T> ECAD_DEV float round_elem(float v);
+template <> ECAD_DEV float round_elem<f16_t>(float v) { return (float)(f16_t)v; }
+template <> ECAD_DEV float round_elem<bf16_t>(float v) { return (float)(bf16_t)v; }
+
+// D(16x16) += A(16x32) * B(32x16); lane l holds A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15];
+// D[row 4(l>>4)+r][col l&15] in element r.
+template <typename T> ECAD_DEV f32x4 mfma16(const Pack8& a, const Pack8& b, f32x4 c);
+template <> ECAD_DEV f32x4 mfma16<f16_t>(const Pack8& a, const Pack8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
+}
+template <> ECAD_DEV f32x4 mfma16<bf16_t>(const Pack8& a, const Pack8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, b.b, c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// 16-byte global -> LDS DMA.  LDS destination = wave-uniform base + lane*16.
+ECAD_DEV void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+ECAD_DEV Pack8 lds_read16(const void* p) {
+  Pack8 r;
+  r.u = *reinterpret_cast<const u32x4*>(p);
+  return r;
+}
+ECAD_DEV Pack8 gload16(const void* p) {
+  Pack8 r;
+  r.u = *reinterpret_cast<const u32x4*>(p);
+  return r;
+}
+ECAD_DEV void gstore16(void* p, const Pack8& v) { *reinterpret_cast<u32x4*>(p) = v.u; }
+
+// 4 rows x 16 cols transposed LDS read (gfx950 ds_read_b64_tr_b16): lane 4q+p of a 16-lane group supplies
+// the address of row q, cols 4p..4p+3; lane i receives column i of the 4 rows.  EXEC must be all ones.
+ECAD_DEV Pack4 lds_read_tr16(const void* p) {
+  Pack4 r;
+  r.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)p);
+  return r;
+}
+
+ECAD_DEV float gelu_tanh(float x) {
+  // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)));  tanh(u) = 1 - 2/(1+exp(2u))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+  return 0.5f * x * (1.0f + t);
+}
+ECAD_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+}  // namespace ecad

@@ -1,0 +1,299 @@
+// elementwise.h -- the HBM-bound kernels of the hot path:
+//   * cache replay: hidden += sum_i gate_i * cached_i        (the "skip" side of the cache gate)
+//   * LayerNorm(no affine) + adaLN-single modulate, with pending cache replays folded in
+//   * patch-embed (conv k2 s2 + bias + sincos table), timestep sinusoid, unpatchify,
+//     CFG combine + learned-sigma drop + DPM-Solver++(2M) update
+// Reference call sites are cited per kernel.
+#pragma once
+#include "common.h"
+
+namespace ecad {
+
+// One cached sub-layer output waiting to be added to the hidden states.
+//   attn1 / ff: gate = scale_shift_table[2|5] + timestep_mod[b][2|5]   (cached_transformer_block.py:243-246,317-320)
+//   attn2:      gate = 1 (gate_table == nullptr)                        (:289)
+struct SrcDesc {
+  const void* cache;
+  const float* gate_table;  // [D] fp32 or null
+  const void* gate_mod;     // T[b * mod_stride + d] or null
+};
+
+struct FlushArgs {
+  void* h;               // [M, D] hidden states (updated in place when n_src > 0)
+  void* y;               // [M, D] LN+modulate output (ln kernel only)
+  const SrcDesc* srcs;   // device array
+  int n_src;
+  int M, D;
+  int64_t mod_stride;    // elements between batch entries of the sources' gate_mod pointers (0 = shared timestep)
+  int64_t ln_mod_stride; // same for mod_shift / mod_scale
+  int rows_per_batch;
+  // LN + modulate (ln kernel only): y = LN(h) * (1 + scale) + shift
+  const float* table_shift;
+  const float* table_scale;
+  const void* mod_shift;
+  const void* mod_scale;
+  float eps;
+};
+
+// ---- cache replay, flat: each thread owns one 16-byte chunk of the hidden states across all sources.
+// Fully cached step: n_src = 84, one streaming pass over the cache arena.
+template <typename T>
+__global__ __launch_bounds__(256) void cache_accumulate_kernel(const FlushArgs p) {
+  const int cpr = p.D >> 3;
+  const size_t total = (size_t)p.M * cpr;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int row = (int)(idx / cpr), c = (int)(idx - (size_t)row * cpr);
+    const int b = row / p.rows_per_batch;
+    const size_t off = (size_t)row * p.D + c * 8;
+    T* hp = reinterpret_cast<T*>(p.h) + off;
+    float acc[8];
+    unpack8<T>(gload16(hp), acc);
+    int s = 0;
+    for (; s + 4 <= p.n_src; s += 4) {  // 4 sources in flight
+      Pack8 cv[4];
+      SrcDesc d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d[u] = p.srcs[s + u];
+        cv[u] = gload16(reinterpret_cast<const T*>(d[u].cache) + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float cf[8];
+        unpack8<T>(cv[u], cf);
+        if (d[u].gate_table) {
+          float gm[8];
+          unpack8<T>(gload16(reinterpret_cast<const T*>(d[u].gate_mod) + (size_t)b * p.mod_stride + c * 8), gm);
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(d[u].gate_table + c * 8);
+          const f32x4 t1 = *reinterpret_cast<const f32x4*>(d[u].gate_table + c * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[e] += (t0[e] + gm[e]) * cf[e];
+            acc[4 + e] += (t1[e] + gm[4 + e]) * cf[4 + e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += cf[e];
+        }
+      }
+    }
+    for (; s < p.n_src; ++s) {
+      const SrcDesc d = p.srcs[s];
+      float cf[8];
+      unpack8<T>(gload16(reinterpret_cast<const T*>(d.cache) + off), cf);
+      if (d.gate_table) {
+        float gm[8];
+        unpack8<T>(gload16(reinterpret_cast<const T*>(d.gate_mod) + (size_t)b * p.mod_stride + c * 8), gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (d.gate_table[c * 8 + e] + gm[e]) * cf[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += cf[e];
+      }
+    }
+    gstore16(hp, pack8<T>(acc));
+  }
+}
+
+// ---- LayerNorm (eps, no affine) + modulate, one wave per row, pending cache replays folded in.
+// norm1/norm2 + `x * (1 + scale) + shift` (cached_transformer_block.py:207-215,306-310) and norm_out + modulate
+// (pixart_transformer_2d_edited.py:340-348).  MAXC = 16-byte chunks per lane (D <= 512 * MAXC).
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const FlushArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int cpr = p.D >> 3;
+  const int b = row / p.rows_per_batch;
+  T* hrow = reinterpret_cast<T*>(p.h) + (size_t)row * p.D;
+  float x[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cpr) unpack8<T>(gload16(hrow + c * 8), x[i]);
+  }
+  if (p.n_src > 0) {
+    for (int s = 0; s < p.n_src; ++s) {
+      const SrcDesc d = p.srcs[s];
+      const T* crow = reinterpret_cast<const T*>(d.cache) + (size_t)row * p.D;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cpr) {
+          float cf[8];
+          unpack8<T>(gload16(crow + c * 8), cf);
+          if (d.gate_table) {
+            float gm[8];
+            unpack8<T>(gload16(reinterpret_cast<const T*>(d.gate_mod) + (size_t)b * p.mod_stride + c * 8), gm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[i][e] += (d.gate_table[c * 8 + e] + gm[e]) * cf[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[i][e] += cf[e];
+          }
+        }
+      }
+    }
+    // hidden states are materialised in the storage type between sub-layers
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < cpr) {
+        Pack8 o = pack8<T>(x[i]);
+        gstore16(hrow + c * 8, o);
+        unpack8<T>(o, x[i]);
+      }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < cpr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += x[i][e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)p.D;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < cpr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dlt = x[i][e] - mean;
+        var += dlt * dlt;
+      }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = rsqrtf(var / (float)p.D + p.eps);
+
+  T* yrow = reinterpret_cast<T*>(p.y) + (size_t)row * p.D;
+  const T* msh = reinterpret_cast<const T*>(p.mod_shift) + (size_t)b * p.ln_mod_stride;
+  const T* msc = reinterpret_cast<const T*>(p.mod_scale) + (size_t)b * p.ln_mod_stride;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cpr) {
+      float sh[8], sc[8], o[8];
+      unpack8<T>(gload16(msh + c * 8), sh);
+      unpack8<T>(gload16(msc + c * 8), sc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float n = (x[i][e] - mean) * rstd;
+        o[e] = n * (1.0f + p.table_scale[c * 8 + e] + sc[e]) + (p.table_shift[c * 8 + e] + sh[e]);
+      }
+      gstore16(yrow + c * 8, pack8<T>(o));
+    }
+  }
+}
+
+// ---- patch embed: Conv2d(C_in, D, k = p, s = p) + bias + fixed sincos table  (pixart_transformer_2d_edited.py:306)
+// grid: (grid_h, Bt); block: 128 threads; each block produces one row of patches.  K = CIN*P*P is tiny (16):
+// bandwidth-bound on the [M, D] output, so plain FMAs with the filter taps in registers.
+template <typename T, int CIN, int P>
+__global__ __launch_bounds__(128) void patch_embed_kernel(const T* __restrict__ latents, const T* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ pos, T* __restrict__ out, int Hl, int Wl, int D) {
+  extern __shared__ float xs[];  // [CIN][P][Wl]
+  constexpr int KK = CIN * P * P;
+  const int gi = blockIdx.x, b = blockIdx.y;
+  const int gw = Wl / P, gh = gridDim.x;
+  for (int i = threadIdx.x; i < CIN * P * Wl; i += 128) {
+    const int c = i / (P * Wl), rem = i - c * (P * Wl), pr = rem / Wl, col = rem - pr * Wl;
+    xs[i] = (float)latents[(((size_t)b * CIN + c) * Hl + gi * P + pr) * Wl + col];
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 128) {
+    float wv[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) wv[k] = (float)w[(size_t)d * KK + k];
+    const float bv = bias[d];
+    for (int gj = 0; gj < gw; ++gj) {
+      float acc = bv;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int pr = 0; pr < P; ++pr)
+#pragma unroll
+          for (int pc = 0; pc < P; ++pc) acc += wv[(c * P + pr) * P + pc] * xs[(c * P + pr) * Wl + gj * P + pc];
+      const int tok = gi * gw + gj;
+      out[((size_t)b * gh * gw + tok) * D + d] = (T)(acc + pos[(size_t)tok * D + d]);
+    }
+  }
+}
+
+template <typename T> __global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (T)silu((float)x[i]);
+}
+
+// mask (1 keep / 0 discard) -> additive bias (1 - m) * -10000  (pixart_transformer_2d_edited.py:282-289)
+__global__ void mask_bias_kernel(const uint8_t* __restrict__ mask, float* __restrict__ bias, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) bias[i] = mask ? (1.0f - (float)(mask[i] != 0)) * -10000.0f : 0.f;
+}
+
+// ---- Timesteps(256, flip_sin_to_cos, shift 0): out[m] = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) i / 128)
+template <typename T> __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, T* __restrict__ out, int M) {
+  const int m = blockIdx.x, i = threadIdx.x;  // 128 threads
+  if (m >= M) return;
+  const float f = __expf(-9.210340371976184f * (float)i / 128.0f);
+  const float a = t[m] * f;
+  out[(size_t)m * 256 + i] = (T)cosf(a);
+  out[(size_t)m * 256 + 128 + i] = (T)sinf(a);
+}
+
+// ---- unpatchify: proj[M, ldp] (first P*P*Cout columns, order (p, q, c)) -> out[Bt, Cout, H, W]
+// einsum "nhwpqc->nchpwq" (pixart_transformer_2d_edited.py:352-371)
+template <typename T> __global__ void unpatchify_kernel(const T* __restrict__ proj, T* __restrict__ out, int Bt, int gh, int gw, int P, int Cout, int ldp) {
+  const int total = Bt * Cout * gh * P * gw * P;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int x = idx;
+    const int col = x % (gw * P);
+    x /= gw * P;
+    const int rowp = x % (gh * P);
+    x /= gh * P;
+    const int c = x % Cout;
+    const int b = x / Cout;
+    const int i = rowp / P, pr = rowp % P, j = col / P, pc = col % P;
+    out[idx] = proj[((size_t)b * gh * gw + i * gw + j) * ldp + (pr * P + pc) * Cout + c];
+  }
+}
+
+// ---- guidance + learned-sigma drop + DPM-Solver++(2M) update (pass_through.py:341-370; scheduler [ext]).
+// noise: [2B, Cout, H, W] (uncond half first); latents fp32 [B, C, H, W] in place; x0_prev fp32.
+// coef = {alpha_s, sigma_s, c_x, c_m0, c_m1}.  Also refreshes the CFG-doubled transformer input for the next step.
+template <typename T>
+__global__ void cfg_solver_kernel(const T* __restrict__ noise, float* __restrict__ latents, float* __restrict__ x0_prev, T* __restrict__ model_in,
+                                  const float* __restrict__ coef, float guidance, int B, int C, int Cout, int HW) {
+  const int total = B * C * HW;
+  const float alpha_s = coef[0], sigma_s = coef[1], c_x = coef[2], c0 = coef[3], c1 = coef[4];
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int hw = idx % HW, c = (idx / HW) % C, b = idx / (HW * C);
+    const float u = (float)noise[((size_t)b * Cout + c) * HW + hw];
+    const float t = (float)noise[((size_t)(B + b) * Cout + c) * HW + hw];
+    const float eps = round_elem<T>(u + guidance * (t - u));
+    const float x = latents[idx];
+    const float x0 = (x - sigma_s * eps) / alpha_s;
+    float nx = c_x * x + c0 * x0;
+    if (c1 != 0.f) nx += c1 * x0_prev[idx];
+    nx = round_elem<T>(nx);  // the reference keeps latents in half precision between steps
+    x0_prev[idx] = x0;
+    latents[idx] = nx;
+    model_in[idx] = (T)nx;
+    model_in[(size_t)total + idx] = (T)nx;
+  }
+}
+
+template <typename T> __global__ void cfg_duplicate_kernel(float* __restrict__ latents, T* __restrict__ model_in, int total) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const float x = round_elem<T>(latents[idx]);
+    latents[idx] = x;
+    model_in[idx] = (T)x;
+    model_in[(size_t)total + idx] = (T)x;
+  }
+}
+
+template <typename TS, typename TD> __global__ void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (TD)(float)src[i];
+}
+
+}  // namespace ecad

@@ -1,0 +1,898 @@
+// engine.hip -- the engine behind include/ecad_hip.h: owns weights (re-laid-out), the cache arena
+// [L][3][Bt*N][D], workspaces, the per-step op lists compiled from the schedule bits, and the captured
+// hipGraph of a whole image batch.  No torch, no other GPU library: HIP runtime + the kernels in this directory.
+//
+// Reference semantics implemented here (paths under /root/reference/ecad):
+//   transformer_2d_models/pixart_transformer_2d_edited.py:160-376  forward / _process_input / _create_output
+//   transformer_blocks/cached_transformer_block.py:167-391          block data flow + cache gate
+//   schedulers/cache_scheduler/cache_schedule.py:58-73              schedule[step][block][component]
+//   pipelines/pass_through.py:297-380                               CFG / learned-sigma drop / scheduler step
+#include "../../include/ecad_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+#include "elementwise.h"
+#include "gemm.h"
+
+namespace ecad {
+
+static std::string g_create_error;
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return fail(ECAD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+enum KClass {
+  KC_GEMM_QKV = 0, KC_GEMM_OUT1, KC_GEMM_Q2, KC_GEMM_OUT2, KC_GEMM_FF1, KC_GEMM_FF2, KC_GEMM_TEXTKV, KC_GEMM_CAPTION,
+  KC_GEMM_SMALL, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_COUNT
+};
+static const char* kclass_names[KC_COUNT] = {
+    "gemm_qkv", "gemm_attn1_out", "gemm_attn2_q", "gemm_attn2_out", "gemm_ff1_gelu", "gemm_ff2", "gemm_text_kv", "gemm_caption",
+    "gemm_small", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc"};
+
+struct EngineBase {
+  EcadModelCfg cfg;
+  int dev = 0;
+  std::string err;
+  virtual ~EngineBase() {}
+  int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  virtual int init() = 0;
+  virtual int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
+  virtual int finalize_weights() = 0;
+  virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
+  virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st) = 0;
+  virtual int step(int step_idx, const void* latents, const float* timestep, void* out, hipStream_t st) = 0;
+  virtual int run_schedule(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, float* latents, const float* ts, const float* coef,
+                           float guidance, int use_graph, hipStream_t st) = 0;
+  virtual int reset_cache() = 0;
+  virtual int stats(EcadStats* s) = 0;
+  virtual int set_profiling(int on) = 0;
+  virtual int get_profile(int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) = 0;
+  virtual int op_gemm(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, void* resid, const float* gate_table,
+                      const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t st) = 0;
+  virtual int op_ln(const void* x, void* y, int M, int D, const float* tsh, const float* tsc, const void* msh, const void* msc, int64_t mstride,
+                    int rows_per_batch, hipStream_t st) = 0;
+  virtual int op_accumulate(void* h, int M, int D, int n_src, const void* const* srcs, const float* const* gts, const void* const* gms, int64_t mstride,
+                            int rows_per_batch, hipStream_t st) = 0;
+  virtual int op_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H,
+                           int Nq, int Nk, int dh, const float* bias, hipStream_t st) = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Op {
+  enum Kind { GEMM, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP } kind;
+  int cls = KC_MISC;
+  int epi = 0;
+  GemmArgs<T> g{};
+  AttnArgs a{};
+  bool attn_masked = false;
+  FlushArgs f{};
+  int desc_off = -1;  // offset into the descriptor array (elements), patched to a device pointer at upload
+  // misc payload
+  const void* p0 = nullptr;
+  const void* p1 = nullptr;
+  void* p2 = nullptr;
+  void* p3 = nullptr;
+  size_t n = 0;
+  int i0 = 0, i1 = 0;
+  bool call_latents = false, call_timestep = false, call_out = false;  // pointers bound per ecad_step call
+  double flops = 0, bytes = 0;
+};
+
+template <typename T> class EngineT : public EngineBase {
+ public:
+  // ---- geometry
+  int L, NH, DH, D, CIN, COUT, P, CAP;
+  // ---- weights
+  char* warena = nullptr;
+  size_t warena_bytes = 0, warena_used = 0;
+  struct Dest { void* ptr; bool f32; int64_t rows, cols, ld; bool loaded; };
+  std::map<std::string, Dest> dests;
+  struct Blk {
+    T *w_qkv, *w_o1, *w_q2, *w_o2, *w_ff1, *w_ff2;
+    float *b_qkv, *b_o1, *b_q2, *b_o2, *b_ff1, *b_ff2, *sst;
+  };
+  std::vector<Blk> blk;
+  T *w_kv2_all, *w_patch, *w_t1, *w_t2, *w_ada, *w_c1, *w_c2, *w_proj;
+  float *b_kv2_all, *b_patch, *b_t1, *b_t2, *b_ada, *b_c1, *b_c2, *b_proj, *sst_out, *pos;
+  bool finalized = false;
+  int pos_grid = 0;
+  // ---- workspaces
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  T *h, *xn, *qkv, *attn_o, *qc, *ffmid, *ctx_mid, *ctx, *kv2, *cache, *proj, *model_in, *noise, *enc_buf;
+  T *tsin, *temb1, *temb, *temb_silu, *mod_all;
+  float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
+  uint8_t* mask_buf;
+  SrcDesc* desc_dev = nullptr;
+  size_t desc_cap = 0;
+  // ---- schedule / plans
+  int steps = 0;
+  std::vector<uint8_t> bits, executed;
+  int Bt = 0, Hl = 0, Wl = 0, N = 0, Tt = 0;
+  bool plan_valid = false;
+  std::vector<std::vector<Op<T>>> plan_step;  // ecad_step mode (per-sample timesteps)
+  std::vector<Op<T>> plan_begin;              // begin_image_batch ops (shared)
+  std::vector<Op<T>> plan_run;                // whole batch for run_schedule (shared timestep per step)
+  std::vector<SrcDesc> desc_host;
+  EcadStats st{};
+  // ---- graph
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  float graph_guidance = 0.f;
+  // ---- profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_cls;
+  double prof_ms[KC_COUNT], prof_flops[KC_COUNT], prof_bytes[KC_COUNT];
+  int64_t prof_launch[KC_COUNT];
+  // ---- per-call bindings for ecad_step
+  const void* call_latents = nullptr;
+  const float* call_timestep = nullptr;
+  void* call_out = nullptr;
+  bool batch_begun = false;
+
+  ~EngineT() override {
+    hipSetDevice(dev);
+    if (graph_exec) hipGraphExecDestroy(graph_exec);
+    if (graph) hipGraphDestroy(graph);
+    if (cap_stream) hipStreamDestroy(cap_stream);
+    for (auto e : ev_pool) hipEventDestroy(e);
+    if (warena) hipFree(warena);
+    if (ws) hipFree(ws);
+    if (desc_dev) hipFree(desc_dev);
+  }
+
+  // -------------------------------------------------------------------------------------------
+  template <typename U> U* walloc(size_t n) {
+    size_t bytes = (n * sizeof(U) + 255) & ~(size_t)255;
+    U* p = reinterpret_cast<U*>(warena + warena_used);
+    warena_used += bytes;
+    return p;
+  }
+  void reg(const std::string& name, void* ptr, bool f32, int64_t rows, int64_t cols, int64_t ld) { dests[name] = Dest{ptr, f32, rows, cols, ld, false}; }
+
+  int init() override {
+    L = cfg.num_layers; NH = cfg.num_heads; DH = cfg.head_dim; D = NH * DH;
+    CIN = cfg.in_channels; COUT = cfg.out_channels; P = cfg.patch_size; CAP = cfg.caption_channels;
+    if (D % 128 != 0 || D % 64 != 0) return fail(ECAD_E_UNSUPPORTED, "inner dim %d must be a multiple of 128", D);
+    if (DH % 8 != 0 || DH > 80) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported (need %%8 == 0 and <= 80)", DH);
+    if (CIN != 4 || P != 2) return fail(ECAD_E_UNSUPPORTED, "patch embed supports in_channels 4, patch 2");
+    if (P * P * COUT > 128) return fail(ECAD_E_UNSUPPORTED, "proj_out too wide");
+    if (CAP % 64 != 0) return fail(ECAD_E_UNSUPPORTED, "caption_channels must be a multiple of 64");
+    if (cfg.max_batch < 1 || cfg.max_tokens < 1 || cfg.max_text_tokens < 1) return fail(ECAD_E_INVALID, "max_batch/max_tokens/max_text_tokens must be positive");
+    HIPCHK(hipSetDevice(dev));
+    HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+
+    // ---- weight arena
+    const size_t d = D;
+    size_t per_blk_T = d * 3 * d + d * d * 3 + 4 * d * d * 2;  // qkv, o1, q2, o2, ff1, ff2
+    size_t per_blk_f = 3 * d + d * 3 + 4 * d + d + 6 * d;
+    size_t glob_T = (size_t)L * 2 * d * d + d * 16 + d * 256 + d * d + 6 * d * d + d * CAP + d * d + 128 * d;
+    size_t glob_f = (size_t)L * 2 * d + d + d + d + 6 * d + d + d + 128 + 2 * d + (size_t)cfg.max_tokens * d;
+    warena_bytes = (per_blk_T * L + glob_T) * sizeof(T) + (per_blk_f * L + glob_f) * sizeof(float) + (size_t)(L * 16 + 64) * 256;
+    HIPCHK(hipMalloc((void**)&warena, warena_bytes));
+    HIPCHK(hipMemset(warena, 0, warena_bytes));
+    blk.resize(L);
+    w_kv2_all = walloc<T>((size_t)L * 2 * d * d);
+    b_kv2_all = walloc<float>((size_t)L * 2 * d);
+    for (int i = 0; i < L; ++i) {
+      Blk& b = blk[i];
+      b.w_qkv = walloc<T>(3 * d * d); b.b_qkv = walloc<float>(3 * d);
+      b.w_o1 = walloc<T>(d * d); b.b_o1 = walloc<float>(d);
+      b.w_q2 = walloc<T>(d * d); b.b_q2 = walloc<float>(d);
+      b.w_o2 = walloc<T>(d * d); b.b_o2 = walloc<float>(d);
+      b.w_ff1 = walloc<T>(4 * d * d); b.b_ff1 = walloc<float>(4 * d);
+      b.w_ff2 = walloc<T>(4 * d * d); b.b_ff2 = walloc<float>(d);
+      b.sst = walloc<float>(6 * d);
+      const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+      const char* qkvn[3] = {"to_q", "to_k", "to_v"};
+      for (int j = 0; j < 3; ++j) {
+        reg(p + "attn1." + qkvn[j] + ".weight", b.w_qkv + (size_t)j * d * d, false, d, d, d);
+        reg(p + "attn1." + qkvn[j] + ".bias", b.b_qkv + (size_t)j * d, true, 1, d, d);
+      }
+      reg(p + "attn1.to_out.0.weight", b.w_o1, false, d, d, d);
+      reg(p + "attn1.to_out.0.bias", b.b_o1, true, 1, d, d);
+      reg(p + "attn2.to_q.weight", b.w_q2, false, d, d, d);
+      reg(p + "attn2.to_q.bias", b.b_q2, true, 1, d, d);
+      for (int j = 0; j < 2; ++j) {
+        reg(p + "attn2." + qkvn[j + 1] + ".weight", w_kv2_all + ((size_t)i * 2 + j) * d * d, false, d, d, d);
+        reg(p + "attn2." + qkvn[j + 1] + ".bias", b_kv2_all + ((size_t)i * 2 + j) * d, true, 1, d, d);
+      }
+      reg(p + "attn2.to_out.0.weight", b.w_o2, false, d, d, d);
+      reg(p + "attn2.to_out.0.bias", b.b_o2, true, 1, d, d);
+      reg(p + "ff.net.0.proj.weight", b.w_ff1, false, 4 * d, d, d);
+      reg(p + "ff.net.0.proj.bias", b.b_ff1, true, 1, 4 * d, 4 * d);
+      reg(p + "ff.net.2.weight", b.w_ff2, false, d, 4 * d, 4 * d);
+      reg(p + "ff.net.2.bias", b.b_ff2, true, 1, d, d);
+      reg(p + "scale_shift_table", b.sst, true, 6, d, d);
+    }
+    w_patch = walloc<T>(d * 16); b_patch = walloc<float>(d);
+    w_t1 = walloc<T>(d * 256); b_t1 = walloc<float>(d);
+    w_t2 = walloc<T>(d * d); b_t2 = walloc<float>(d);
+    w_ada = walloc<T>(6 * d * d); b_ada = walloc<float>(6 * d);
+    w_c1 = walloc<T>(d * CAP); b_c1 = walloc<float>(d);
+    w_c2 = walloc<T>(d * d); b_c2 = walloc<float>(d);
+    w_proj = walloc<T>(128 * d); b_proj = walloc<float>(128);
+    sst_out = walloc<float>(2 * d);
+    pos = walloc<float>((size_t)cfg.max_tokens * d);
+    reg("pos_embed.proj.weight", w_patch, false, d, CIN * P * P, CIN * P * P);
+    reg("pos_embed.proj.bias", b_patch, true, 1, d, d);
+    reg("adaln_single.emb.timestep_embedder.linear_1.weight", w_t1, false, d, 256, 256);
+    reg("adaln_single.emb.timestep_embedder.linear_1.bias", b_t1, true, 1, d, d);
+    reg("adaln_single.emb.timestep_embedder.linear_2.weight", w_t2, false, d, d, d);
+    reg("adaln_single.emb.timestep_embedder.linear_2.bias", b_t2, true, 1, d, d);
+    reg("adaln_single.linear.weight", w_ada, false, 6 * d, d, d);
+    reg("adaln_single.linear.bias", b_ada, true, 1, 6 * d, 6 * d);
+    reg("caption_projection.linear_1.weight", w_c1, false, d, CAP, CAP);
+    reg("caption_projection.linear_1.bias", b_c1, true, 1, d, d);
+    reg("caption_projection.linear_2.weight", w_c2, false, d, d, d);
+    reg("caption_projection.linear_2.bias", b_c2, true, 1, d, d);
+    reg("scale_shift_table", sst_out, true, 2, d, d);
+    reg("proj_out.weight", w_proj, false, P * P * COUT, d, d);
+    reg("proj_out.bias", b_proj, true, 1, P * P * COUT, P * P * COUT);
+    if (warena_used > warena_bytes) return fail(ECAD_E_INVALID, "internal: weight arena overflow");
+    st.weight_bytes = (int64_t)warena_used;
+
+    // ---- workspaces, sized for the largest batch
+    const size_t Bm = cfg.max_batch, Nm = cfg.max_tokens, Tm = cfg.max_text_tokens;
+    const size_t M = Bm * Nm, Mt = Bm * Tm;
+    const size_t lat = Bm * (size_t)(CIN > COUT ? CIN : COUT) * Nm * P * P;
+    const size_t max_steps = 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_h = take(M * d * sizeof(T)), o_xn = take(M * d * sizeof(T)), o_qkv = take(M * 3 * d * sizeof(T));
+    const size_t o_ao = take(M * d * sizeof(T)), o_qc = take(M * d * sizeof(T)), o_ff = take(M * 4 * d * sizeof(T));
+    const size_t o_cm = take(Mt * d * sizeof(T)), o_ctx = take(Mt * d * sizeof(T)), o_kv2 = take(Mt * (size_t)L * 2 * d * sizeof(T));
+    const size_t o_cache = take((size_t)L * 3 * M * d * sizeof(T));
+    const size_t o_proj = take(M * 128 * sizeof(T)), o_min = take(lat * sizeof(T)), o_noise = take(lat * sizeof(T));
+    const size_t o_enc = take(Mt * CAP * sizeof(T));
+    const size_t trows = max_steps * Bm;
+    const size_t o_tsin = take(trows * 256 * sizeof(T)), o_te1 = take(trows * d * sizeof(T)), o_te = take(trows * d * sizeof(T));
+    const size_t o_tes = take(trows * d * sizeof(T)), o_mod = take(trows * 6 * d * sizeof(T));
+    const size_t o_bias = take(Mt * sizeof(float)), o_x0 = take(lat * sizeof(float)), o_lat = take(lat * sizeof(float));
+    const size_t o_ts = take(trows * sizeof(float)), o_coef = take(max_steps * 8 * sizeof(float)), o_mask = take(Mt);
+    ws_bytes = off;
+    HIPCHK(hipMalloc((void**)&ws, ws_bytes));
+    HIPCHK(hipMemset(ws, 0, ws_bytes));
+    h = (T*)(ws + o_h); xn = (T*)(ws + o_xn); qkv = (T*)(ws + o_qkv); attn_o = (T*)(ws + o_ao); qc = (T*)(ws + o_qc); ffmid = (T*)(ws + o_ff);
+    ctx_mid = (T*)(ws + o_cm); ctx = (T*)(ws + o_ctx); kv2 = (T*)(ws + o_kv2); cache = (T*)(ws + o_cache); proj = (T*)(ws + o_proj);
+    model_in = (T*)(ws + o_min); noise = (T*)(ws + o_noise); enc_buf = (T*)(ws + o_enc);
+    tsin = (T*)(ws + o_tsin); temb1 = (T*)(ws + o_te1); temb = (T*)(ws + o_te); temb_silu = (T*)(ws + o_tes); mod_all = (T*)(ws + o_mod);
+    bias_buf = (float*)(ws + o_bias); x0_prev = (float*)(ws + o_x0); lat_buf = (float*)(ws + o_lat); ts_dev = (float*)(ws + o_ts);
+    coef_dev = (float*)(ws + o_coef); mask_buf = (uint8_t*)(ws + o_mask);
+    st.workspace_bytes = (int64_t)ws_bytes;
+    st.cache_arena_bytes = (int64_t)((size_t)L * 3 * M * d * sizeof(T));
+
+    // ---- kernels that need > 64 KiB dynamic LDS would be registered here
+    return set_kernel_attrs();
+  }
+
+  int set_kernel_attrs() {
+    constexpr int lds = gemm_lds_bytes<128, 128>();
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_kernel<T, 128, 128, 2, 2, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_kernel<T, 128, 128, 2, 2, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_kernel<T, 128, 128, 2, 2, EPI_BIAS_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_kernel<T, 128, 128, 2, 2, EPI_BIAS_CACHE_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) override {
+    HIPCHK(hipSetDevice(dev));
+    auto it = dests.find(name);
+    if (it == dests.end()) {
+      if (strcmp(name, "pos_embed.pos_embed") == 0) return ECAD_OK;  // fixed table, recomputed here
+      return fail(ECAD_E_INVALID, "unknown weight name '%s'", name);
+    }
+    Dest& d = it->second;
+    int64_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= shape[i];
+    if (numel != d.rows * d.cols) return fail(ECAD_E_INVALID, "weight '%s': expected %lld elements, got %lld", name, (long long)(d.rows * d.cols), (long long)numel);
+    size_t esz = dtype == ECAD_DTYPE_F32 ? 4 : 2;
+    if (dtype != ECAD_DTYPE_F16 && dtype != ECAD_DTYPE_BF16 && dtype != ECAD_DTYPE_F32) return fail(ECAD_E_INVALID, "weight '%s': bad dtype %d", name, dtype);
+    void* stage = nullptr;
+    HIPCHK(hipMalloc(&stage, numel * esz));
+    hipError_t e = hipMemcpy(stage, ptr, numel * esz, hipMemcpyDefault);
+    if (e != hipSuccess) { hipFree(stage); return fail(ECAD_E_HIP, "hipMemcpy of weight '%s' failed: %s", name, hipGetErrorString(e)); }
+    const int grid = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
+#define CONV(SRC, DST) hipLaunchKernelGGL((convert_kernel<SRC, DST>), dim3(grid), dim3(256), 0, 0, (const SRC*)stage, (DST*)d.ptr, (size_t)numel)
+    if (d.f32) {
+      if (dtype == ECAD_DTYPE_F16) CONV(f16_t, float); else if (dtype == ECAD_DTYPE_BF16) CONV(bf16_t, float); else CONV(float, float);
+    } else {
+      if (dtype == ECAD_DTYPE_F16) CONV(f16_t, T); else if (dtype == ECAD_DTYPE_BF16) CONV(bf16_t, T); else CONV(float, T);
+    }
+#undef CONV
+    e = hipDeviceSynchronize();
+    hipFree(stage);
+    if (e != hipSuccess) return fail(ECAD_E_HIP, "weight conversion failed: %s", hipGetErrorString(e));
+    d.loaded = true;
+    finalized = false;
+    return ECAD_OK;
+  }
+
+  int finalize_weights() override {
+    for (auto& kv : dests)
+      if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "weight '%s' was never loaded", kv.first.c_str());
+    finalized = true;
+    plan_valid = false;
+    return ECAD_OK;
+  }
+
+  // 2-D sincos table exactly as diffusers' PatchEmbed builds it [ext]: first half of the channels encodes the column.
+  int build_pos_table(int gh, int gw) {
+    if (gh * gw > cfg.max_tokens) return fail(ECAD_E_INVALID, "token count %d exceeds max_tokens %d", gh * gw, cfg.max_tokens);
+    const int base = cfg.sample_size / P;
+    float interp = cfg.interpolation_scale > 0 ? cfg.interpolation_scale : (float)(cfg.sample_size / 64 > 1 ? cfg.sample_size / 64 : 1);
+    std::vector<float> tab((size_t)gh * gw * D);
+    const int half = D / 2, quarter = half / 2;
+    for (int i = 0; i < gh; ++i)
+      for (int j = 0; j < gw; ++j) {
+        // diffusers: arange(grid)/ (grid/base_size) / interpolation_scale, float32
+        const float cj = (float)j / ((float)gw / (float)base) / interp;
+        const float ci = (float)i / ((float)gh / (float)base) / interp;
+        float* row = &tab[((size_t)i * gw + j) * D];
+        for (int k = 0; k < quarter; ++k) {
+          const double omega = 1.0 / pow(10000.0, (double)k / (double)quarter);
+          row[k] = (float)sin((double)cj * omega);
+          row[quarter + k] = (float)cos((double)cj * omega);
+          row[half + k] = (float)sin((double)ci * omega);
+          row[half + quarter + k] = (float)cos((double)ci * omega);
+        }
+      }
+    HIPCHK(hipMemcpy(pos, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    pos_grid = gh * 100000 + gw;
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  int set_schedule(const uint8_t* b, int nsteps, int nblocks) override {
+    if (nblocks != L) return fail(ECAD_E_INVALID, "schedule has %d blocks, model has %d", nblocks, L);
+    if (nsteps < 1 || nsteps > 64) return fail(ECAD_E_INVALID, "num_inference_steps %d out of range [1, 64]", nsteps);
+    steps = nsteps;
+    bits.assign(b, b + (size_t)nsteps * L * 3);
+    executed.assign(bits.size(), 0);
+    std::vector<uint8_t> have((size_t)L * 3, 0);
+    st.components_executed = st.components_cached = 0;
+    for (int s = 0; s < steps; ++s)
+      for (int i = 0; i < L * 3; ++i) {
+        const size_t k = (size_t)s * L * 3 + i;
+        executed[k] = (bits[k] != 0) || !have[i];  // recompute or cache empty (cached_transformer_block.py:340-347)
+        have[i] |= executed[k];
+        if (executed[k]) st.components_executed++; else st.components_cached++;
+      }
+    plan_valid = false;
+    batch_begun = false;
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // plan construction
+  Op<T> mk_gemm(int cls, int epi, const T* A, const T* W, const float* bias, T* C, int M, int Nn, int K, int lda, int ldc) {
+    Op<T> o;
+    o.kind = Op<T>::GEMM; o.cls = cls; o.epi = epi;
+    o.g.A = A; o.g.W = W; o.g.bias = bias; o.g.C = C; o.g.resid = nullptr; o.g.gate_table = nullptr; o.g.gate_mod = nullptr;
+    o.g.gate_mod_stride = 0; o.g.rows_per_batch = N > 0 ? N : 1; o.g.M = M; o.g.N = Nn; o.g.K = K; o.g.lda = lda; o.g.ldw = K; o.g.ldc = ldc; o.g.ldr = ldc;
+    o.flops = 2.0 * M * (double)Nn * K;
+    o.bytes = ((double)M * K + (double)Nn * K + (double)M * Nn) * sizeof(T);
+    return o;
+  }
+  Op<T> mk_gemm_resid(int cls, const T* A, const T* W, const float* bias, T* cache_slot, int M, int K, const float* gate_table, const T* gate_mod, int64_t mstride) {
+    Op<T> o = mk_gemm(cls, EPI_BIAS_CACHE_RESID, A, W, bias, cache_slot, M, D, K, K, D);
+    o.g.resid = h; o.g.ldr = D; o.g.gate_table = gate_table; o.g.gate_mod = gate_mod; o.g.gate_mod_stride = mstride;
+    o.bytes += 2.0 * M * (double)D * sizeof(T);
+    return o;
+  }
+
+  struct Pending { const T* cache; const float* gate_table; const T* gate_mod; };
+
+  void emit_ln(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, const float* tsh, const float* tsc, const T* msh, const T* msc, int64_t ln_stride, int64_t mstride) {
+    if (pend.size() > 6) emit_replay(ops, pend, M, mstride);
+    Op<T> o;
+    o.kind = Op<T>::LN; o.cls = KC_LN;
+    o.f.h = h; o.f.y = xn; o.f.srcs = nullptr; o.f.n_src = (int)pend.size(); o.f.M = M; o.f.D = D; o.f.mod_stride = mstride; o.f.ln_mod_stride = ln_stride;
+    o.f.rows_per_batch = N; o.f.table_shift = tsh; o.f.table_scale = tsc; o.f.mod_shift = msh; o.f.mod_scale = msc; o.f.eps = cfg.norm_eps;
+    if (!pend.empty()) {
+      o.desc_off = (int)desc_host.size();
+      for (auto& p : pend) desc_host.push_back(SrcDesc{p.cache, p.gate_table, p.gate_mod});
+    }
+    o.bytes = (2.0 + pend.size() + (pend.empty() ? 0 : 1)) * M * (double)D * sizeof(T);
+    st.cache_bytes_read += (int64_t)pend.size() * M * D * (int64_t)sizeof(T);
+    pend.clear();
+    ops.push_back(o);
+  }
+  void emit_replay(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, int64_t mstride) {
+    if (pend.empty()) return;
+    Op<T> o;
+    o.kind = Op<T>::REPLAY; o.cls = KC_CACHE_REPLAY;
+    o.f.h = h; o.f.y = nullptr; o.f.n_src = (int)pend.size(); o.f.M = M; o.f.D = D; o.f.mod_stride = mstride; o.f.ln_mod_stride = 0; o.f.rows_per_batch = N;
+    o.desc_off = (int)desc_host.size();
+    for (auto& p : pend) desc_host.push_back(SrcDesc{p.cache, p.gate_table, p.gate_mod});
+    o.bytes = (2.0 + pend.size()) * M * (double)D * sizeof(T);
+    st.cache_bytes_read += (int64_t)pend.size() * M * D * (int64_t)sizeof(T);
+    pend.clear();
+    ops.push_back(o);
+  }
+
+  // ops of one transformer forward at schedule row s.  mod_s/emb_s: adaLN tables of this step.
+  void emit_transformer(std::vector<Op<T>>& ops, int s, const T* mod_s, int64_t mstride, const T* emb_s, int64_t estride, bool bind_call) {
+    const int M = Bt * N, Mt = Bt * Tt;
+    const size_t slot = (size_t)M * D;
+    {
+      Op<T> o; o.kind = Op<T>::PATCH; o.cls = KC_PATCH; o.p0 = model_in; o.call_latents = bind_call; o.bytes = (double)M * D * sizeof(T);
+      ops.push_back(o);
+    }
+    std::vector<Pending> pend;
+    const int ldkv = L * 2 * D;
+    for (int b = 0; b < L; ++b) {
+      const Blk& B = blk[b];
+      const uint8_t* ex = &executed[((size_t)s * L + b) * 3];
+      T* c0 = cache + ((size_t)b * 3 + 0) * slot;
+      T* c1 = cache + ((size_t)b * 3 + 1) * slot;
+      T* c2 = cache + ((size_t)b * 3 + 2) * slot;
+      // --- attn1
+      if (ex[0]) {
+        emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride);
+        ops.push_back(mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D));
+        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % ATT_KT) != 0;
+        a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
+        a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+        a.flops = 4.0 * Bt * (double)NH * N * (double)N * DH; a.bytes = 4.0 * M * (double)D * sizeof(T);
+        ops.push_back(a);
+        ops.push_back(mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, c0, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
+        st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        st.linear_macs_reference += 4ll * M * D * D; st.linear_macs_executed += 4ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)N * D;
+      } else {
+        pend.push_back(Pending{c0, B.sst + 2 * D, mod_s + 2 * D});
+      }
+      // --- attn2 (no norm for ada_norm_single, cached_transformer_block.py:264-267; no gate, :289)
+      if (ex[1]) {
+        emit_replay(ops, pend, M, mstride);
+        ops.push_back(mk_gemm(KC_GEMM_Q2, EPI_BIAS, h, B.w_q2, B.b_q2, qc, M, D, D, D, D));
+        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_CROSS; a.attn_masked = true;
+        a.a.q = qc; a.a.k = kv2 + (size_t)b * 2 * D; a.a.v = kv2 + (size_t)b * 2 * D + D; a.a.out = attn_o; a.a.bias = bias_buf;
+        a.a.ldq = D; a.a.ldk = a.a.ldv = ldkv; a.a.ldo = D; a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = Tt; a.a.dh = DH;
+        a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+        a.flops = 4.0 * Bt * (double)NH * N * (double)Tt * DH; a.bytes = (2.0 * M + 2.0 * Mt) * D * sizeof(T);
+        ops.push_back(a);
+        ops.push_back(mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, c1, M, D, nullptr, nullptr, 0));
+        st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
+      } else {
+        pend.push_back(Pending{c1, nullptr, nullptr});
+      }
+      // --- ff
+      if (ex[2]) {
+        emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride);
+        ops.push_back(mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D));
+        ops.push_back(mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, c2, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
+        st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        st.linear_macs_reference += 8ll * M * D * D; st.linear_macs_executed += 8ll * M * D * D;
+      } else {
+        pend.push_back(Pending{c2, B.sst + 5 * D, mod_s + 5 * D});
+      }
+    }
+    // --- _create_output: norm_out, modulate with scale_shift_table[2, D] + embedded_timestep, proj_out, unpatchify
+    emit_ln(ops, pend, M, sst_out, sst_out + D, emb_s, emb_s, estride, mstride);
+    ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, xn, w_proj, b_proj, proj, M, 128, D, D, 128));
+    {
+      Op<T> o; o.kind = Op<T>::UNPATCH; o.cls = KC_MISC; o.p0 = proj; o.p2 = noise; o.call_out = bind_call;
+      ops.push_back(o);
+    }
+    // per-step reference overhead the calflops model counts (patch conv, t-embed, caption, proj_out)
+    const int64_t per_sample_over = (int64_t)Tt * ((int64_t)CAP * D + (int64_t)D * D) + (int64_t)N * 16 * D + (256ll * D + 7ll * D * D) + (int64_t)N * D * 32;
+    st.linear_macs_reference += per_sample_over * Bt;
+    st.linear_macs_executed += ((int64_t)N * 16 * D + (int64_t)N * D * 32) * Bt;
+  }
+
+  // timestep MLP + adaLN-single linear for `rows` timesteps at ts (device), results at row offset r0
+  void emit_temb(std::vector<Op<T>>& ops, const float* ts, int rows, size_t r0, bool bind_call) {
+    Op<T> s; s.kind = Op<T>::SINUS; s.cls = KC_MISC; s.p0 = ts; s.p2 = tsin + r0 * 256; s.i0 = rows; s.call_timestep = bind_call;
+    ops.push_back(s);
+    ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS_SILU, tsin + r0 * 256, w_t1, b_t1, temb1 + r0 * D, rows, D, 256, 256, D));
+    ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, temb1 + r0 * D, w_t2, b_t2, temb + r0 * D, rows, D, D, D, D));
+    Op<T> a; a.kind = Op<T>::SILU; a.cls = KC_MISC; a.p0 = temb + r0 * D; a.p2 = temb_silu + r0 * D; a.n = (size_t)rows * D;
+    ops.push_back(a);
+    ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, temb_silu + r0 * D, w_ada, b_ada, mod_all + r0 * 6 * D, rows, 6 * D, D, D, 6 * D));
+  }
+
+  void emit_begin(std::vector<Op<T>>& ops) {
+    const int Mt = Bt * Tt;
+    Op<T> m; m.kind = Op<T>::MASKBIAS; m.cls = KC_MISC; m.p0 = mask_buf; m.p2 = bias_buf; m.i0 = Mt;
+    ops.push_back(m);
+    // caption projection, hoisted: step-invariant (pixart_transformer_2d_edited.py:315-321)
+    ops.push_back(mk_gemm(KC_GEMM_CAPTION, EPI_BIAS_GELU, enc_buf, w_c1, b_c1, ctx_mid, Mt, D, CAP, CAP, D));
+    ops.push_back(mk_gemm(KC_GEMM_CAPTION, EPI_BIAS, ctx_mid, w_c2, b_c2, ctx, Mt, D, D, D, D));
+    // cross-attention K/V of the text for all blocks in ONE launch (weights stacked [L*2D, D])
+    ops.push_back(mk_gemm(KC_GEMM_TEXTKV, EPI_BIAS, ctx, w_kv2_all, b_kv2_all, kv2, Mt, L * 2 * D, D, D, L * 2 * D));
+    st.linear_macs_executed += (int64_t)Mt * ((int64_t)CAP * D + (int64_t)D * D) + (int64_t)Mt * L * 2 * D * D;
+  }
+
+  int build_plans() {
+    if (!finalized) return fail(ECAD_E_NOT_READY, "weights not finalized");
+    if (steps == 0) return fail(ECAD_E_NOT_READY, "no schedule set");
+    const int gh = Hl / P, gw = Wl / P;
+    if (pos_grid != gh * 100000 + gw) { int rc = build_pos_table(gh, gw); if (rc) return rc; }
+    desc_host.clear();
+    st.linear_macs_reference = st.linear_macs_executed = st.attn_core_macs = 0;
+    st.cache_bytes_read = st.cache_bytes_written = 0;
+    plan_begin.clear(); plan_run.clear(); plan_step.assign(steps, {});
+    emit_begin(plan_begin);
+    // --- run plan: shared timestep per step, tables for all steps computed up front
+    EcadStats keep = st;
+    plan_run = plan_begin;
+    emit_temb(plan_run, ts_dev, steps, 0, false);
+    { Op<T> d; d.kind = Op<T>::DUP; d.cls = KC_MISC; plan_run.push_back(d); }
+    for (int s = 0; s < steps; ++s) {
+      emit_transformer(plan_run, s, mod_all + (size_t)s * 6 * D, 0, temb + (size_t)s * D, 0, false);
+      Op<T> o; o.kind = Op<T>::SOLVER; o.cls = KC_MISC; o.i0 = s;
+      plan_run.push_back(o);
+    }
+    st.launches_per_batch = (int)plan_run.size();
+    // temb macs: steps rows
+    st.linear_macs_executed += (int64_t)steps * (256ll * D + 7ll * D * D);
+    EcadStats run_stats = st;
+    // --- step plans: per-sample timesteps, tables at rows [s*Bt, (s+1)*Bt)
+    st = keep;
+    for (int s = 0; s < steps; ++s) {
+      emit_temb(plan_step[s], nullptr, Bt, (size_t)s * Bt, true);
+      emit_transformer(plan_step[s], s, mod_all + (size_t)s * Bt * 6 * D, 6 * D, temb + (size_t)s * Bt * D, D, true);
+    }
+    st = run_stats;
+    // --- upload descriptors and patch pointers
+    if (desc_host.size() > desc_cap) {
+      if (desc_dev) hipFree(desc_dev);
+      desc_cap = desc_host.size() + 1024;
+      HIPCHK(hipMalloc((void**)&desc_dev, desc_cap * sizeof(SrcDesc)));
+    }
+    if (!desc_host.empty()) HIPCHK(hipMemcpy(desc_dev, desc_host.data(), desc_host.size() * sizeof(SrcDesc), hipMemcpyHostToDevice));
+    auto patch = [&](std::vector<Op<T>>& ops) { for (auto& o : ops) if (o.desc_off >= 0) o.f.srcs = desc_dev + o.desc_off; };
+    patch(plan_run);
+    for (auto& v : plan_step) patch(v);
+    if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    st.graph_nodes = 0;
+    plan_valid = true;
+    return ECAD_OK;
+  }
+
+  int ensure_shapes(int Bt_, int H_, int W_, int T_) {
+    if (Bt_ < 1 || Bt_ > cfg.max_batch) return fail(ECAD_E_INVALID, "batch %d outside [1, max_batch=%d]", Bt_, cfg.max_batch);
+    if (H_ % P || W_ % P || H_ < P || W_ < P) return fail(ECAD_E_INVALID, "latent size %dx%d not a multiple of patch %d", H_, W_, P);
+    const int n = (H_ / P) * (W_ / P);
+    if (n > cfg.max_tokens) return fail(ECAD_E_INVALID, "%d image tokens exceed max_tokens %d", n, cfg.max_tokens);
+    if (T_ < 1 || T_ > cfg.max_text_tokens) return fail(ECAD_E_INVALID, "text tokens %d outside [1, %d]", T_, cfg.max_text_tokens);
+    if (!plan_valid || Bt_ != Bt || H_ != Hl || W_ != Wl || T_ != Tt) {
+      Bt = Bt_; Hl = H_; Wl = W_; Tt = T_; N = n;
+      return build_plans();
+    }
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // launch
+  template <int EPI> void launch_gemm_epi(const GemmArgs<T>& g, hipStream_t s) {
+    const int tiles = ((g.M + 127) / 128) * (g.N / 128);
+    constexpr int lds = gemm_lds_bytes<128, 128>();
+    hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, EPI>), dim3(tiles), dim3(256), lds, s, g);
+  }
+  int launch_gemm(int epi, const GemmArgs<T>& g, hipStream_t s) {
+    if (g.N % 128 || g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (N%%128, K%%64)", g.M, g.N, g.K);
+    switch (epi) {
+      case EPI_BIAS: launch_gemm_epi<EPI_BIAS>(g, s); break;
+      case EPI_BIAS_GELU: launch_gemm_epi<EPI_BIAS_GELU>(g, s); break;
+      case EPI_BIAS_SILU: launch_gemm_epi<EPI_BIAS_SILU>(g, s); break;
+      case EPI_BIAS_CACHE_RESID: launch_gemm_epi<EPI_BIAS_CACHE_RESID>(g, s); break;
+      default: return fail(ECAD_E_INVALID, "bad epilogue %d", epi);
+    }
+    return ECAD_OK;
+  }
+  void launch_attn(const AttnArgs& a, bool masked, hipStream_t s) {
+    dim3 grid((a.Nq + 63) / 64, a.H, a.B);
+    if (masked) hipLaunchKernelGGL((attn_kernel<T, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<T, false>), grid, dim3(256), 0, s, a);
+  }
+  int launch_ln(const FlushArgs& f, hipStream_t s) {
+    const int cpr = f.D / 8;
+    const int grid = (f.M + 3) / 4;
+    if (f.D % 8) return fail(ECAD_E_INVALID, "D %% 8 != 0");
+    if (cpr <= 64 * 3) hipLaunchKernelGGL((ln_modulate_kernel<T, 3>), dim3(grid), dim3(256), 0, s, f);
+    else if (cpr <= 64 * 6) hipLaunchKernelGGL((ln_modulate_kernel<T, 6>), dim3(grid), dim3(256), 0, s, f);
+    else return fail(ECAD_E_UNSUPPORTED, "D=%d too wide for ln kernel", f.D);
+    return ECAD_OK;
+  }
+  void launch_replay(const FlushArgs& f, hipStream_t s) {
+    const size_t total = (size_t)f.M * (f.D / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((cache_accumulate_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, f);
+  }
+
+  int launch_op(const Op<T>& o, hipStream_t s, float guidance) {
+    const int M = Bt * N;
+    switch (o.kind) {
+      case Op<T>::GEMM: return launch_gemm(o.epi, o.g, s);
+      case Op<T>::ATTN: launch_attn(o.a, o.attn_masked, s); break;
+      case Op<T>::LN: return launch_ln(o.f, s);
+      case Op<T>::REPLAY: launch_replay(o.f, s); break;
+      case Op<T>::PATCH: {
+        const T* src = o.call_latents ? (const T*)call_latents : (const T*)o.p0;
+        hipLaunchKernelGGL((patch_embed_kernel<T, 4, 2>), dim3(Hl / P, Bt), dim3(128), CIN * P * Wl * sizeof(float), s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
+        break;
+      }
+      case Op<T>::SINUS: {
+        const float* ts = o.call_timestep ? call_timestep : (const float*)o.p0;
+        hipLaunchKernelGGL((timestep_sinusoid_kernel<T>), dim3(o.i0), dim3(128), 0, s, ts, (T*)o.p2, o.i0);
+        break;
+      }
+      case Op<T>::SILU: hipLaunchKernelGGL((silu_kernel<T>), dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0, s, (const T*)o.p0, (T*)o.p2, o.n); break;
+      case Op<T>::MASKBIAS: hipLaunchKernelGGL(mask_bias_kernel, dim3((o.i0 + 255) / 256), dim3(256), 0, s, (const uint8_t*)o.p0, (float*)o.p2, o.i0); break;
+      case Op<T>::UNPATCH: {
+        T* dst = o.call_out ? (T*)call_out : (T*)o.p2;
+        const int total = Bt * COUT * Hl * Wl;
+        hipLaunchKernelGGL((unpatchify_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, (const T*)o.p0, dst, Bt, Hl / P, Wl / P, P, COUT, 128);
+        break;
+      }
+      case Op<T>::SOLVER: {
+        const int B = Bt / 2, total = B * CIN * Hl * Wl;
+        hipLaunchKernelGGL((cfg_solver_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, noise, lat_buf, x0_prev, model_in, coef_dev + o.i0 * 8, guidance, B, CIN, COUT, Hl * Wl);
+        break;
+      }
+      case Op<T>::DUP: {
+        const int total = (Bt / 2) * CIN * Hl * Wl;
+        hipLaunchKernelGGL((cfg_duplicate_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, lat_buf, model_in, total);
+        break;
+      }
+    }
+    (void)M;
+    return ECAD_OK;
+  }
+
+  int run_ops(const std::vector<Op<T>>& ops, hipStream_t s, float guidance, bool allow_profile) {
+    const bool prof = profiling && allow_profile;
+    if (prof) {
+      while (ev_pool.size() < 2 * ops.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev_pool.push_back(e); }
+      ev_cls.clear();
+    }
+    size_t k = 0;
+    for (const auto& o : ops) {
+      if (prof) HIPCHK(hipEventRecord(ev_pool[2 * k], s));
+      int rc = launch_op(o, s, guidance);
+      if (rc) return rc;
+      if (prof) { HIPCHK(hipEventRecord(ev_pool[2 * k + 1], s)); ev_cls.push_back(o.cls); }
+      ++k;
+    }
+    HIPCHK(hipGetLastError());
+    if (prof) {
+      HIPCHK(hipStreamSynchronize(s));
+      for (size_t i = 0; i < ops.size(); ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev_pool[2 * i], ev_pool[2 * i + 1]));
+        const int c = ops[i].cls;
+        prof_ms[c] += ms; prof_launch[c]++; prof_flops[c] += ops[i].flops; prof_bytes[c] += ops[i].bytes;
+      }
+    }
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  int stage_inputs(const void* enc, const uint8_t* mask, hipStream_t s) {
+    const size_t Mt = (size_t)Bt * Tt;
+    HIPCHK(hipMemcpyAsync(enc_buf, enc, Mt * CAP * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (mask) HIPCHK(hipMemcpyAsync(mask_buf, mask, Mt, hipMemcpyDeviceToDevice, s));
+    else HIPCHK(hipMemsetAsync(mask_buf, 1, Mt, s));
+    return ECAD_OK;
+  }
+
+  int begin_batch(int Bt_, int H_, int W_, const void* enc, const uint8_t* mask, int T_, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (!enc) return fail(ECAD_E_INVALID, "enc_dev is NULL");
+    int rc = ensure_shapes(Bt_, H_, W_, T_);
+    if (rc) return rc;
+    rc = stage_inputs(enc, mask, s);
+    if (rc) return rc;
+    rc = run_ops(plan_begin, s, 0.f, true);
+    if (rc) return rc;
+    batch_begun = true;
+    return ECAD_OK;
+  }
+
+  int step(int step_idx, const void* latents, const float* timestep, void* out, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (!batch_begun || !plan_valid) return fail(ECAD_E_NOT_READY, "ecad_begin_image_batch must be called before ecad_step");
+    if (step_idx < 0 || step_idx >= steps) return fail(ECAD_E_INVALID, "step_idx %d outside [0, %d)", step_idx, steps);
+    if (!latents || !timestep || !out) return fail(ECAD_E_INVALID, "NULL pointer argument");
+    call_latents = latents; call_timestep = timestep; call_out = out;
+    return run_ops(plan_step[step_idx], s, 0.f, true);
+  }
+
+  int run_schedule(int Bt_, int H_, int W_, const void* enc, const uint8_t* mask, int T_, float* latents, const float* ts, const float* coef,
+                   float guidance, int use_graph, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (Bt_ % 2) return fail(ECAD_E_INVALID, "run_schedule needs a CFG-doubled batch (Bt even), got %d", Bt_);
+    if (!enc || !latents || !ts || !coef) return fail(ECAD_E_INVALID, "NULL pointer argument");
+    int rc = ensure_shapes(Bt_, H_, W_, T_);
+    if (rc) return rc;
+    // per-schedule constants (timesteps, solver coefficients): uploaded synchronously, outside the graph
+    std::vector<float> c8((size_t)steps * 8, 0.f);
+    for (int i = 0; i < steps; ++i) for (int j = 0; j < 5; ++j) c8[(size_t)i * 8 + j] = coef[i * 5 + j];
+    HIPCHK(hipMemcpyAsync(ts_dev, ts, steps * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(coef_dev, c8.data(), c8.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    rc = stage_inputs(enc, mask, s);
+    if (rc) return rc;
+    const size_t nlat = (size_t)(Bt / 2) * CIN * Hl * Wl;
+    HIPCHK(hipMemcpyAsync(lat_buf, latents, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (use_graph && !profiling) {
+      if (!graph_exec || graph_guidance != guidance) {
+        if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+        HIPCHK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+        rc = run_ops(plan_run, cap_stream, guidance, false);
+        hipError_t e = hipStreamEndCapture(cap_stream, &graph);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(ECAD_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+        size_t nn = 0;
+        hipGraphGetNodes(graph, nullptr, &nn);
+        st.graph_nodes = (int)nn;
+        graph_guidance = guidance;
+      }
+      HIPCHK(hipGraphLaunch(graph_exec, s));
+    } else {
+      rc = run_ops(plan_run, s, guidance, true);
+      if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(latents, lat_buf, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    batch_begun = false;  // caches are dropped after the last step (image_generator.py:197-202)
+    return ECAD_OK;
+  }
+
+  int reset_cache() override { batch_begun = false; return ECAD_OK; }
+  int stats(EcadStats* s) override { *s = st; return ECAD_OK; }
+  int set_profiling(int on) override {
+    profiling = on != 0;
+    for (int i = 0; i < KC_COUNT; ++i) { prof_ms[i] = prof_flops[i] = prof_bytes[i] = 0; prof_launch[i] = 0; }
+    return ECAD_OK;
+  }
+  int get_profile(int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) override {
+    int n = 0;
+    for (int i = 0; i < KC_COUNT && n < maxc; ++i) {
+      names[n] = kclass_names[i]; ms[n] = prof_ms[i]; launches[n] = prof_launch[i]; flops[n] = prof_flops[i]; bytes[n] = prof_bytes[i];
+      ++n;
+    }
+    return n;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // single-op entry points
+  int op_gemm(int epi, const void* A, const void* W, const float* bias, void* out, int M, int Nn, int K, void* resid, const float* gate_table,
+              const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    GemmArgs<T> g{};
+    g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
+    g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K; g.lda = K; g.ldw = K; g.ldc = Nn; g.ldr = Nn;
+    if (epi == EPI_BIAS_CACHE_RESID && !resid) return fail(ECAD_E_INVALID, "epilogue 3 needs resid");
+    int rc = launch_gemm(epi, g, s);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int op_ln(const void* x, void* y, int M, int Dd, const float* tsh, const float* tsc, const void* msh, const void* msc, int64_t mstride, int rows_per_batch,
+            hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    FlushArgs f{};
+    f.h = const_cast<void*>(x); f.y = y; f.srcs = nullptr; f.n_src = 0; f.M = M; f.D = Dd; f.mod_stride = mstride; f.ln_mod_stride = mstride;
+    f.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; f.table_shift = tsh; f.table_scale = tsc; f.mod_shift = msh; f.mod_scale = msc; f.eps = cfg.norm_eps;
+    int rc = launch_ln(f, s);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int op_accumulate(void* hh, int M, int Dd, int n_src, const void* const* srcs, const float* const* gts, const void* const* gms, int64_t mstride,
+                    int rows_per_batch, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (n_src < 0 || n_src > 4096) return fail(ECAD_E_INVALID, "n_src out of range");
+    std::vector<SrcDesc> d(n_src);
+    for (int i = 0; i < n_src; ++i) d[i] = SrcDesc{srcs[i], gts ? gts[i] : nullptr, gms ? gms[i] : nullptr};
+    SrcDesc* dd = nullptr;
+    HIPCHK(hipMalloc((void**)&dd, sizeof(SrcDesc) * (n_src + 1)));
+    hipMemcpy(dd, d.data(), sizeof(SrcDesc) * n_src, hipMemcpyHostToDevice);
+    FlushArgs f{};
+    f.h = hh; f.srcs = dd; f.n_src = n_src; f.M = M; f.D = Dd; f.mod_stride = mstride; f.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    launch_replay(f, s);
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(dd);
+    if (e != hipSuccess) return fail(ECAD_E_HIP, "cache_accumulate failed: %s", hipGetErrorString(e));
+    return ECAD_OK;
+  }
+  int op_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk,
+                   int dh, const float* bias, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (dh % 8 || dh > 80) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported", dh);
+    AttnArgs a{};
+    a.q = q; a.k = k; a.v = v; a.out = out; a.bias = bias; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh;
+    a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)dh));
+    launch_attn(a, bias != nullptr || (Nk % ATT_KT) != 0, s);
+    HIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+};
+
+}  // namespace ecad
+
+// ================================================================================================
+using namespace ecad;
+struct EcadEngine { EngineBase* impl; };
+
+extern "C" {
+
+int ecad_abi_version(void) { return ECAD_ABI_VERSION; }
+
+int ecad_create(const EcadModelCfg* cfg, int device, EcadEngine** out) {
+  if (!cfg || !out) { g_create_error = "NULL argument"; return ECAD_E_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device visible"; return ECAD_E_HIP; }
+  if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return ECAD_E_INVALID; }
+  EngineBase* impl = nullptr;
+  if (cfg->dtype == ECAD_DTYPE_F16) impl = new EngineT<f16_t>();
+  else if (cfg->dtype == ECAD_DTYPE_BF16) impl = new EngineT<bf16_t>();
+  else { g_create_error = "dtype must be ECAD_DTYPE_F16 or ECAD_DTYPE_BF16"; return ECAD_E_INVALID; }
+  impl->cfg = *cfg;
+  impl->dev = device;
+  int rc = impl->init();
+  if (rc) { g_create_error = impl->err; delete impl; return rc; }
+  *out = new EcadEngine{impl};
+  return ECAD_OK;
+}
+void ecad_destroy(EcadEngine* e) { if (e) { delete e->impl; delete e; } }
+const char* ecad_last_error(const EcadEngine* e) { return e ? e->impl->err.c_str() : g_create_error.c_str(); }
+
+#define ENG(e) if (!(e)) return ECAD_E_INVALID; EngineBase* E = (e)->impl
+
+int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { ENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
+int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights(); }
+int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks) { ENG(e); if (!bits) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bits, steps, blocks); }
+int ecad_begin_image_batch(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, void* stream) { ENG(e); return E->begin_batch(Bt, H, W, enc, mask, T, (hipStream_t)stream); }
+int ecad_step(EcadEngine* e, int step_idx, const void* lat, const float* ts, void* out, void* stream) { ENG(e); return E->step(step_idx, lat, ts, out, (hipStream_t)stream); }
+int ecad_run_schedule(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, float* latents, const float* ts, const float* coef, float guidance, int use_graph, void* stream) {
+  ENG(e); return E->run_schedule(Bt, H, W, enc, mask, T, latents, ts, coef, guidance, use_graph, (hipStream_t)stream);
+}
+int ecad_reset_cache(EcadEngine* e) { ENG(e); return E->reset_cache(); }
+int ecad_cache_stats(EcadEngine* e, EcadStats* s) { ENG(e); if (!s) return E->fail(ECAD_E_INVALID, "NULL stats"); return E->stats(s); }
+int ecad_set_profiling(EcadEngine* e, int on) { ENG(e); return E->set_profiling(on); }
+int ecad_get_profile(EcadEngine* e, int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) { ENG(e); return E->get_profile(maxc, names, ms, launches, flops, bytes); }
+int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, void* stream) {
+  ENG(e); return E->op_gemm(epi, A, W, bias, out, M, N, K, resid, gate_table, gate_mod, gate_mod_stride, rows_per_batch, (hipStream_t)stream);
+}
+int ecad_op_ln_modulate(EcadEngine* e, const void* x, void* y, int M, int D, const float* tsh, const float* tsc, const void* msh, const void* msc, int64_t mstride, int rows_per_batch, void* stream) {
+  ENG(e); return E->op_ln(x, y, M, D, tsh, tsc, msh, msc, mstride, rows_per_batch, (hipStream_t)stream);
+}
+int ecad_op_cache_accumulate(EcadEngine* e, void* h, int M, int D, int n_src, const void* const* srcs, const float* const* gts, const void* const* gms, int64_t mstride, int rows_per_batch, void* stream) {
+  ENG(e); return E->op_accumulate(h, M, D, n_src, srcs, gts, gms, mstride, rows_per_batch, (hipStream_t)stream);
+}
+int ecad_op_attention(EcadEngine* e, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream) {
+  ENG(e); return E->op_attention(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Nq, Nk, dh, bias, (hipStream_t)stream);
+}
+
+}  // extern "C"

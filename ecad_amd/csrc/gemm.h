@@ -1,0 +1,209 @@
+// gemm.h -- MFMA GEMM for the dense contractions of the PixArt block (QKV / out-proj / cross-Q /
+// text-KV / FF1 / FF2 / caption / adaLN / proj_out), with the cache gate fused into the epilogue.
+//
+//   C[M,N] = epilogue( A[M,K] (row-major, lda) @ W[N,K]^T (torch Linear layout, ldw) + bias[N] )
+//
+// Replaces the cuBLAS calls behind diffusers' Attention.to_q/to_k/to_v/to_out and FeedForward
+// (reference call sites: ecad/transformer_blocks/cached_transformer_block.py:348-353,374-382) and the
+// elementwise tail `cache <- out; hidden = gate * out + hidden` (:243-246,289,317-320,355-360,388-389).
+//
+// Structure (gfx950): BMxBN output tile per workgroup, BK=64; both operands are K-contiguous so A and W
+// tiles share one LDS image: [rows][64] elements = 128-B rows, 16-B chunks XOR-swizzled by ((row>>1)&7)
+// (conflict-free ds_read_b128 for 16 rows x one k-chunk).  Tiles arrive by LDS-DMA
+// (global_load_lds_dwordx4; the swizzle is applied to the per-lane SOURCE address, the LDS image stays
+// lane-linear), double-buffered.  MFMA 16x16x32 with the WEIGHT fragment as the A operand so every lane
+// ends up with 4 consecutive output columns -> packed 8-byte LDS writes, then the C tile is re-read row-wise
+// for 16-byte coalesced global stores (and 16-byte loads of the residual).
+#pragma once
+#include "common.h"
+
+namespace ecad {
+
+enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_BIAS_CACHE_RESID = 3 };
+
+template <typename T> struct GemmArgs {
+  const T* A;
+  const T* W;
+  const float* bias;  // [N] fp32 (may be null)
+  T* C;               // plain output, or the cache slot for EPI_BIAS_CACHE_RESID (may be null)
+  T* resid;           // EPI_BIAS_CACHE_RESID: hidden states, updated in place: resid += gate * out
+  const float* gate_table;  // [N] fp32 row of scale_shift_table (null => gate = 1, no mod)
+  const T* gate_mod;        // adaLN-single modulation rows: gate_mod[b * gate_mod_stride + n]
+  int64_t gate_mod_stride;  // 0 when one timestep is shared by the whole batch
+  int rows_per_batch;       // image tokens per sample (row -> b)
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+};
+
+constexpr int GEMM_BK = 64;
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmArgs<T> p) {
+  constexpr int NWAVES = WAVES_M * WAVES_N;
+  constexpr int NT = NWAVES * 64;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
+  constexpr int FM = WTM / 16, FN = WTN / 16;            // 16x16 fragments per wave
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM / 8 / NWAVES, B_INST = BN / 8 / NWAVES;  // 1-KiB DMA instructions per wave
+  constexpr int CS = BN + 8;                                          // C tile row stride (elements)
+  static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile/wave mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- tile coordinates, XCD-aware: blocks b and b+8 share an XCD (and its L2); give each XCD a
+  // contiguous range of the row-major tile order so concurrently resident tiles share A rows / W rows.
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-lane DMA source pointers (advance by 64 elements per K step)
+  const T* a_src[A_INST];
+  const T* b_src[B_INST];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int row = m0 + r;
+    row = row < p.M ? row : p.M - 1;
+    a_src[i] = p.A + (size_t)row * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INST; ++i) {
+    const int r = (wave * B_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = p.W + (size_t)(n0 + r) * p.ldw + c * 8;
+  }
+
+  auto stage = [&](int buf) {
+    char* abase = smem + buf * STAGE_BYTES;
+    char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      glds16(a_src[i], abase + (wave * A_INST + i) * 1024);
+      a_src[i] += GEMM_BK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+      glds16(b_src[i], bbase + (wave * B_INST + i) * 1024);
+      b_src[i] += GEMM_BK;
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = base + 16*i + l15, logical chunk = kk*4 + g, physical = logical ^ ((row>>1)&7)
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wm * WTM + l15) * 128;
+  const int b_row_off = (wn * WTN + l15) * 128;
+
+  const int nk = p.K / GEMM_BK;
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage(buf ^ 1);
+    const char* abase = smem + buf * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + g) ^ swz) * 16;
+      Pack8 af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue 1: acc[i][j][r] = C[m = wm*WTM+16i+l15][n = wn*WTN+16j+4g+r]; bias/activation, round to T,
+  // pack 4 consecutive n -> 8-byte LDS write into the row-major C tile (reuses the operand buffers).
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nl = wn * WTN + 16 * j + 4 * g;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wm * WTM + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[r];
+        if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+        if (EPI == EPI_BIAS_SILU) v = silu(v);
+        float_to_elem4<T>(o, r, v);
+      }
+      *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: row-wise 16-byte pass over the C tile
+  constexpr int CPR = BN / 8;            // 16-byte chunks per row
+  constexpr int ROWS_PER_PASS = NT / CPR;
+  const int cchunk = tid % CPR, crow0 = tid / CPR;
+  const int n = n0 + cchunk * 8;
+  float gate_t[8];
+  if (EPI == EPI_BIAS_CACHE_RESID) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gate_t[e] = p.gate_table ? p.gate_table[n + e] : 1.0f;
+  }
+#pragma unroll 4
+  for (int pass = 0; pass < BM / ROWS_PER_PASS; ++pass) {
+    const int ml = pass * ROWS_PER_PASS + crow0;
+    const int m = m0 + ml;
+    if (m >= p.M) break;
+    Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+    if (EPI == EPI_BIAS_CACHE_RESID) {
+      if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);  // cache <- un-gated sub-layer output
+      T* rp = p.resid + (size_t)m * p.ldr + n;
+      Pack8 hv = gload16(rp);
+      float o[8], h[8], gm[8];
+      unpack8<T>(v, o);
+      unpack8<T>(hv, h);
+      if (p.gate_mod) {
+        const int b = m / p.rows_per_batch;
+        Pack8 gp = gload16(p.gate_mod + (size_t)b * p.gate_mod_stride + n);
+        unpack8<T>(gp, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += (gate_t[e] + gm[e]) * o[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += gate_t[e] * o[e];
+      }
+      gstore16(rp, pack8<T>(h));
+    } else {
+      gstore16(p.C + (size_t)m * p.ldc + n, v);
+    }
+  }
+}
+
+template <int BM, int BN> constexpr int gemm_lds_bytes() {
+  return (2 * (BM + BN) * 128) > (BM * (BN + 8) * 2) ? (2 * (BM + BN) * 128) : (BM * (BN + 8) * 2);
+}
+
+}  // namespace ecad

@@ -1,0 +1,207 @@
+"""Python handle on one native engine (one per process and GPU).
+
+Thin: converts torch tensors to raw device pointers and raises the reference's exception
+types (ValueError for bad arguments, RuntimeError for device failures).  All compute is in
+libecad_hip.so; torch only owns the I/O tensors and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping
+
+import numpy as np
+import torch
+
+from ecad_amd import _lib as L
+
+_TORCH2ECAD = {torch.float16: L.ECAD_DTYPE_F16, torch.bfloat16: L.ECAD_DTYPE_BF16, torch.float32: L.ECAD_DTYPE_F32}
+
+
+def _stream_ptr(stream=None) -> int:
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return int(stream.cuda_stream)
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+class EcadEngine:
+    def __init__(
+        self,
+        num_layers=28,
+        num_heads=16,
+        head_dim=72,
+        in_channels=4,
+        out_channels=8,
+        patch_size=2,
+        sample_size=32,
+        caption_channels=4096,
+        max_batch=32,
+        max_tokens=256,
+        max_text_tokens=120,
+        dtype: torch.dtype = torch.float16,
+        norm_eps=1e-6,
+        interpolation_scale=None,
+        device: int = 0,
+    ):
+        self.lib = L.load()
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("engine dtype must be torch.float16 or torch.bfloat16")
+        self.dtype = dtype
+        self.device_index = device
+        self.device = torch.device("cuda", device)
+        self.cfg = L.EcadModelCfg(
+            num_layers, num_heads, head_dim, in_channels, out_channels, patch_size, sample_size, caption_channels,
+            max_batch, max_tokens, max_text_tokens, _TORCH2ECAD[dtype], norm_eps, float(interpolation_scale or 0.0),
+        )
+        self.dim = num_heads * head_dim
+        self._h = C.c_void_p()
+        rc = self.lib.ecad_create(C.byref(self.cfg), device, C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            self._raise(rc, handle=None)
+        self.steps = 0
+
+    # -- errors ---------------------------------------------------------------------------
+    def _raise(self, rc: int, handle="self"):
+        msg = self.lib.ecad_last_error(self._h if handle == "self" else None)
+        msg = msg.decode() if msg else f"error {rc}"
+        if rc in (L.ECAD_E_INVALID, L.ECAD_E_UNSUPPORTED):
+            raise ValueError(msg)
+        raise RuntimeError(msg)
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            self._raise(rc)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.ecad_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights --------------------------------------------------------------------------
+    def load_state_dict(self, state: Mapping[str, torch.Tensor]) -> None:
+        for name, t in state.items():
+            if name == "pos_embed.pos_embed":
+                continue
+            t = t.detach().contiguous()
+            if t.dtype not in _TORCH2ECAD:
+                t = t.float()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            self._chk(self.lib.ecad_load_weights(self._h, name.encode(), t.data_ptr(), _TORCH2ECAD[t.dtype], shape, t.dim()))
+        self._chk(self.lib.ecad_finalize_weights(self._h))
+
+    # -- schedule -------------------------------------------------------------------------
+    def set_schedule(self, bits: np.ndarray) -> None:
+        bits = np.ascontiguousarray(np.asarray(bits).astype(np.uint8))
+        if bits.ndim != 3 or bits.shape[2] != 3:
+            raise ValueError(f"schedule bits must have shape (steps, blocks, 3), got {bits.shape}")
+        self.steps = int(bits.shape[0])
+        self._chk(self.lib.ecad_set_schedule(self._h, bits.ctypes.data_as(C.POINTER(C.c_uint8)), bits.shape[0], bits.shape[1]))
+
+    # -- per batch ------------------------------------------------------------------------
+    def _prep_enc(self, enc: torch.Tensor, mask: torch.Tensor | None):
+        enc = enc.to(device=self.device, dtype=self.dtype).contiguous()
+        if mask is not None:
+            mask = (mask.to(self.device) != 0).to(torch.uint8).contiguous()
+        return enc, mask
+
+    def begin_image_batch(self, enc: torch.Tensor, mask: torch.Tensor | None, height: int, width: int, stream=None) -> None:
+        enc, mask = self._prep_enc(enc, mask)
+        Bt, T, _ = enc.shape
+        self._keep = (enc, mask)
+        self._chk(self.lib.ecad_begin_image_batch(self._h, Bt, height, width, enc.data_ptr(), _ptr(mask), T, _stream_ptr(stream)))
+
+    def step(self, step_idx: int, latents: torch.Tensor, timestep: torch.Tensor, stream=None) -> torch.Tensor:
+        latents = latents.to(device=self.device, dtype=self.dtype).contiguous()
+        Bt = latents.shape[0]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        if ts.numel() == 1:
+            ts = ts.expand(Bt)
+        ts = ts.contiguous()
+        out = torch.empty((Bt, self.cfg.out_channels, latents.shape[2], latents.shape[3]), device=self.device, dtype=self.dtype)
+        self._chk(self.lib.ecad_step(self._h, int(step_idx), latents.data_ptr(), ts.data_ptr(), out.data_ptr(), _stream_ptr(stream)))
+        return out
+
+    def run_schedule(self, enc, mask, latents: torch.Tensor, timesteps, solver_coef, guidance_scale: float = 4.5, use_graph: bool = True, stream=None) -> torch.Tensor:
+        """Whole denoising loop for one image batch; returns the final latents (fp32, new tensor)."""
+        enc, mask = self._prep_enc(enc, mask)
+        Bt, T, _ = enc.shape
+        lat = latents.to(device=self.device, dtype=torch.float32).contiguous().clone()
+        if lat.shape[0] * 2 != Bt:
+            raise ValueError(f"latents batch {lat.shape[0]} must be half of the CFG batch {Bt}")
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.float32))
+        coef = np.ascontiguousarray(np.asarray(solver_coef, dtype=np.float32))
+        if ts.shape[0] != self.steps or coef.shape != (self.steps, 5):
+            raise ValueError(f"need {self.steps} timesteps and [{self.steps}, 5] solver coefficients")
+        self._chk(
+            self.lib.ecad_run_schedule(
+                self._h, Bt, lat.shape[2], lat.shape[3], enc.data_ptr(), _ptr(mask), T, lat.data_ptr(),
+                ts.ctypes.data_as(C.POINTER(C.c_float)), coef.ctypes.data_as(C.POINTER(C.c_float)),
+                float(guidance_scale), int(use_graph), _stream_ptr(stream),
+            )
+        )
+        return lat
+
+    def reset_cache(self) -> None:
+        self._chk(self.lib.ecad_reset_cache(self._h))
+
+    def stats(self) -> dict:
+        s = L.EcadStats()
+        self._chk(self.lib.ecad_cache_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    # -- profiling ------------------------------------------------------------------------
+    def set_profiling(self, on: bool) -> None:
+        self._chk(self.lib.ecad_set_profiling(self._h, int(on)))
+
+    def get_profile(self) -> dict[str, dict]:
+        n = 32
+        names = (C.c_char_p * n)()
+        ms = (C.c_double * n)()
+        launches = (C.c_int64 * n)()
+        flops = (C.c_double * n)()
+        nbytes = (C.c_double * n)()
+        k = self.lib.ecad_get_profile(self._h, n, names, ms, launches, flops, nbytes)
+        return {names[i].decode(): {"ms": ms[i], "launches": launches[i], "flops": flops[i], "bytes": nbytes[i]} for i in range(k)}
+
+    # -- single ops (tests / micro-benchmarks) ----------------------------------------------
+    def op_gemm(self, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None):
+        M, K = a.shape
+        N = w.shape[0]
+        if out is None and epi != 3:
+            out = torch.empty((M, N), device=self.device, dtype=self.dtype)
+        self._chk(
+            self.lib.ecad_op_gemm(self._h, epi, a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(out), M, N, K, _ptr(resid), _ptr(gate_table), _ptr(gate_mod),
+                                  int(gate_mod_stride), int(rows_per_batch), _stream_ptr())
+        )
+        return out
+
+    def op_ln_modulate(self, x, table_shift, table_scale, mod_shift, mod_scale, mod_stride, rows_per_batch):
+        M, D = x.shape
+        y = torch.empty_like(x)
+        self._chk(self.lib.ecad_op_ln_modulate(self._h, x.data_ptr(), y.data_ptr(), M, D, table_shift.data_ptr(), table_scale.data_ptr(), mod_shift.data_ptr(),
+                                               mod_scale.data_ptr(), int(mod_stride), int(rows_per_batch), _stream_ptr()))
+        return y
+
+    def op_cache_accumulate(self, h, srcs, gate_tables, gate_mods, mod_stride, rows_per_batch):
+        M, D = h.shape
+        n = len(srcs)
+        arr = lambda xs: (C.c_void_p * n)(*[None if x is None else x.data_ptr() for x in xs])
+        self._chk(self.lib.ecad_op_cache_accumulate(self._h, h.data_ptr(), M, D, n, arr(srcs), arr(gate_tables), arr(gate_mods), int(mod_stride), int(rows_per_batch), _stream_ptr()))
+        return h
+
+    def op_attention(self, q, k, v, B, H, Nq, Nk, dh, bias=None):
+        """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer)."""
+        out = torch.empty((B * Nq, H * dh), device=self.device, dtype=self.dtype)
+        self._chk(self.lib.ecad_op_attention(self._h, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0),
+                                             B, H, Nq, Nk, dh, _ptr(bias), _stream_ptr()))
+        return out

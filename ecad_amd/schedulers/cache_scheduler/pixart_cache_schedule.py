@@ -1,0 +1,50 @@
+"""PixArt cache schedule: components ``attn1, attn2, ff`` per block.
+
+Mirror of ``ecad/schedulers/cache_scheduler/pixart_cache_schedule.py:9-37``; the bit
+layout of ``to_numpy`` -- ``(step, block, [attn1, attn2, ff])`` -- is the layout the C
+ABI's ``ecad_set_schedule`` takes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ecad_amd.schedulers.cache_scheduler.cache_schedule import CacheSchedule
+
+
+class PixArtCacheSchedule(CacheSchedule):
+    @property
+    def components(self) -> list[str]:
+        return ["attn1", "attn2", "ff"]
+
+    def to_numpy(self, flatten: bool = False) -> np.ndarray:
+        arr = np.zeros((self.num_inference_steps, self.num_blocks, 3), dtype=np.bool_)
+        for step, per_block in self.schedule.items():
+            for block_num, comp in per_block.items():
+                arr[step, int(block_num)] = [comp[c] for c in self.components]
+        return arr.flatten() if flatten else arr
+
+    @classmethod
+    def from_numpy(cls, bits: np.ndarray, name: str = "from_numpy", num_blocks: int = 28, num_inference_steps: int = 20, **kw) -> "PixArtCacheSchedule":
+        """Inverse of ``to_numpy`` (``binary_vector_to_schedule_dict``, pixart_population_io_manager.py:213-240)."""
+        arr = np.asarray(bits).reshape(num_inference_steps, num_blocks, 3)
+        schedule = {
+            s: {str(b): {"attn1": bool(arr[s, b, 0]), "attn2": bool(arr[s, b, 1]), "ff": bool(arr[s, b, 2])} for b in range(num_blocks)}
+            for s in range(num_inference_steps)
+        }
+        return cls(num_blocks, num_inference_steps, name, schedule, **kw)
+
+    def get_custom_compute_attn(self, block_num: str) -> dict:
+        return self.schedule[self.curr_step][str(block_num)].get("custom_compute_attn", {})
+
+    def get_custom_compute_ff(self, block_num: str) -> dict:
+        return self.schedule[self.curr_step][str(block_num)].get("custom_compute_ff", {})
+
+    def uses_only_native_compute(self) -> bool:
+        """True when every block uses the default cached attn/ff functions (the HIP path)."""
+        for per_block in self.schedule.values():
+            for comp in per_block.values():
+                for key, default in (("custom_compute_attn", "compute_attn_cached"), ("custom_compute_ff", "compute_ff_cached")):
+                    name = (comp.get(key) or {}).get("name")
+                    if name is not None and name.lower() != default:
+                        return False
+        return True

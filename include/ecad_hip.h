@@ -1,0 +1,151 @@
+/*
+ * ecad_hip.h -- C ABI of libecad_hip.so: the MI355X (gfx950) native engine for the
+ * denoising hot path of ECAD's PixArt cached-diffusion transformer.
+ *
+ * Plain pointers and sizes only; no torch / HIP C++ types.  Streams cross the boundary as
+ * `void*` (a hipStream_t; NULL = the null stream).  Every "dev" pointer is device memory
+ * owned by the caller (e.g. a torch tensor's data_ptr) that must outlive the stream work.
+ *
+ * Each entry point names the reference interface it replaces (paths under /root/reference).
+ * All functions return 0 on success or a negative ECAD_E_* code; the message is available
+ * from ecad_last_error().  One engine per (process, GPU); not thread-safe by contract.
+ */
+#ifndef ECAD_HIP_H
+#define ECAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECAD_ABI_VERSION 1
+
+enum {
+  ECAD_OK = 0,
+  ECAD_E_INVALID = -1,   /* bad argument / shape / state   (Python shim: ValueError)   */
+  ECAD_E_HIP = -2,       /* HIP runtime failure             (Python shim: RuntimeError) */
+  ECAD_E_NOT_READY = -3, /* weights / schedule / batch not set up                       */
+  ECAD_E_UNSUPPORTED = -4
+};
+
+enum { ECAD_DTYPE_F16 = 0, ECAD_DTYPE_BF16 = 1, ECAD_DTYPE_F32 = 2 };
+
+/* Model geometry: the constructor arguments of PixArtTransformer2DEdited
+ * (ecad/transformer_2d_models/pixart_transformer_2d_edited.py:23-49). */
+typedef struct EcadModelCfg {
+  int32_t num_layers;        /* 28 */
+  int32_t num_heads;         /* 16 */
+  int32_t head_dim;          /* 72 */
+  int32_t in_channels;       /* 4  */
+  int32_t out_channels;      /* 8  */
+  int32_t patch_size;        /* 2  */
+  int32_t sample_size;       /* latent side the checkpoint was trained at: 32 for 256x256 */
+  int32_t caption_channels;  /* 4096 */
+  int32_t max_batch;         /* largest transformer batch Bt (CFG-doubled) to size workspaces for */
+  int32_t max_tokens;        /* largest image-token count N = (h/p)*(w/p) */
+  int32_t max_text_tokens;   /* largest T (120 alpha, 300 sigma) */
+  int32_t dtype;             /* ECAD_DTYPE_F16 (reference: .half(), :98) or ECAD_DTYPE_BF16 */
+  float norm_eps;            /* 1e-6 */
+  float interpolation_scale; /* <= 0: max(sample_size / 64, 1) as diffusers does */
+} EcadModelCfg;
+
+typedef struct EcadStats {
+  int64_t components_executed;   /* of steps*blocks*3, after the "empty cache => recompute" rule */
+  int64_t components_cached;
+  int64_t linear_macs_reference; /* Linear/Conv MACs the reference would execute (compute_macs.py model) */
+  int64_t linear_macs_executed;  /* after hoisting step-invariant work out of the step loop */
+  int64_t attn_core_macs;        /* QK^T + PV */
+  int64_t cache_bytes_read;      /* per image batch, algorithmic */
+  int64_t cache_bytes_written;
+  int64_t cache_arena_bytes;
+  int64_t weight_bytes;
+  int64_t workspace_bytes;
+  int32_t graph_nodes;           /* kernels captured in the whole-schedule hipGraph (0 = not built) */
+  int32_t launches_per_batch;
+} EcadStats;
+
+typedef struct EcadEngine EcadEngine;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Replaces PixArtTransformer2DEdited.__init__/_post_init (pixart_transformer_2d_edited.py:23-102). */
+int ecad_create(const EcadModelCfg* cfg, int device, EcadEngine** out);
+void ecad_destroy(EcadEngine* e);
+const char* ecad_last_error(const EcadEngine* e); /* e may be NULL: last create() error */
+int ecad_abi_version(void);
+
+/* Replaces from_pretrained + init_cached_transformer_blocks weight copy (:104-153).  `name` is the
+ * diffusers state-dict key ("transformer_blocks.3.attn1.to_q.weight", "pos_embed.proj.bias", ...).
+ * `ptr` may be host or device memory; the engine converts to its dtype and re-lays-out (fused QKV,
+ * padded proj_out); the caller keeps ownership. */
+int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim);
+/* Call once after the last ecad_load_weights: checks completeness, builds fused layouts. */
+int ecad_finalize_weights(EcadEngine* e);
+
+/* ---- schedule --------------------------------------------------------------------------- */
+
+/* Replaces the per-component host lookups CacheSchedule.get_recompute
+ * (ecad/schedulers/cache_scheduler/cache_schedule.py:68-73).  bits: [steps][blocks][3] bytes
+ * (0/1), layout of PixArtCacheSchedule.to_numpy (pixart_cache_schedule.py:15-27).  The rule
+ * "flag false + empty cache => recompute" (cached_transformer_block.py:340-347) is resolved here,
+ * statically, into the per-step op lists. */
+int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks);
+
+/* ---- per image batch ---------------------------------------------------------------------- */
+
+/* Start a batch: resets caches + step state (reset_cache, :155-158; _reset_schedules_callback,
+ * ecad/image_generators/image_generator.py:193-202) and hoists the step-invariant work of
+ * _process_input/_create_attention_mask (:255-330): caption projection and, per block, the
+ * cross-attention K/V of the text.  enc_dev: [Bt, T, caption_channels] engine dtype;
+ * mask_dev: [Bt, T] uint8 (1 keep / 0 discard), NULL = all keep.  H, W: latent height/width. */
+int ecad_begin_image_batch(EcadEngine* e, int Bt, int H, int W, const void* enc_dev, const uint8_t* mask_dev, int T, void* stream);
+
+/* One noise prediction == PixArtTransformer2DEdited.forward (:160-253) at schedule row `step_idx`.
+ * latents_dev: [Bt, C, H, W] engine dtype; timestep_dev: [Bt] float32; out: [Bt, out_channels, H, W]
+ * engine dtype.  Cache reads/writes follow the schedule row; the caller advances step_idx the way the
+ * reference's callbacks advance curr_step. */
+int ecad_step(EcadEngine* e, int step_idx, const void* latents_dev, const float* timestep_dev, void* noise_pred_out_dev, void* stream);
+
+/* Whole denoising loop == the loop mirrored at ecad/pipelines/pass_through.py:297-380 for one image
+ * batch: CFG concat, `steps` transformer calls, guidance combine, learned-sigma drop and the
+ * DPM-Solver++(2M) update, captured once into a hipGraph per (schedule, shapes) and replayed.
+ * latents_dev: [B, C, H, W] float32, B = Bt/2, updated in place.  enc/mask as in
+ * ecad_begin_image_batch (uncond half first).  timesteps_host: [steps] float.
+ * solver_coef_host: [steps][5] float = {alpha_s, sigma_s, c_x, c_m0, c_m1} with
+ * x0 = (x - sigma_s*eps)/alpha_s; x <- c_x*x + c_m0*x0 + c_m1*x0_prev. */
+int ecad_run_schedule(EcadEngine* e, int Bt, int H, int W, const void* enc_dev, const uint8_t* mask_dev, int T,
+                      float* latents_dev, const float* timesteps_host, const float* solver_coef_host,
+                      float guidance_scale, int use_graph, void* stream);
+
+int ecad_reset_cache(EcadEngine* e);               /* reset_cache (:155-158) */
+int ecad_cache_stats(EcadEngine* e, EcadStats* s); /* feeds the roofline accounting */
+
+/* Per-kernel-class device time of the most recent NON-graph ecad_run_schedule/ecad_step when
+ * profiling is on (hipEvents on the launch stream around every launch).  names: out array of
+ * const char* (static storage); ms / launches / flops / bytes: per class.  Returns the class count. */
+int ecad_set_profiling(EcadEngine* e, int on);
+int ecad_get_profile(EcadEngine* e, int max_classes, const char** names, double* ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- single-op entry points (parity tests and micro-benchmarks; same kernels the engine launches) */
+
+/* out[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias[N]); epi: 0 bias, 1 bias+GELU(tanh), 2 bias+SiLU,
+ * 3 bias -> cache write -> resid += gate * out  (gate_table_f32 [N] + gate_mod [rows/rows_per_batch][..] may be NULL => gate 1). */
+int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                 void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, void* stream);
+/* y = LN(x) * (1 + scale) + shift with scale = table[1*D..] + mod[b][1], shift = table[0] + mod[b][0] (adaLN-single). */
+int ecad_op_ln_modulate(EcadEngine* e, const void* x, void* y, int M, int D, const float* table_shift, const float* table_scale,
+                        const void* mod_shift, const void* mod_scale, int64_t mod_stride, int rows_per_batch, void* stream);
+/* h += sum_i gate_i * C_i  (n_src cached tensors; gate tables may be NULL => 1). */
+int ecad_op_cache_accumulate(EcadEngine* e, void* h, int M, int D, int n_src, const void* const* srcs, const float* const* gate_tables,
+                             const void* const* gate_mods, int64_t gate_mod_stride, int rows_per_batch, void* stream);
+/* Multi-head attention core: out[b,q,h,:] = softmax(Q K^T / sqrt(dh) + bias[b,k]) V.
+ * q: rows of stride ldq, k/v likewise; bias_f32 [B, Nk] or NULL. */
+int ecad_op_attention(EcadEngine* e, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo,
+                      int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECAD_HIP_H */

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by IMPORTING the reference (runs only in
+the build container, where /root/reference exists; never on the GPU box).
+
+Outputs (data only -- inputs and expected outputs):
+  tests/golden/mac_kat.npz           packed schedule bits + per-step MACs for every
+                                     PixArt-256 non-TGATE schedule JSON that carries
+                                     metrics.by_inference_step (the reference's own
+                                     known answers, compute_macs.py:296-303)
+  tests/golden/schedule_vectors.json vectors captured from the reference's importable
+                                     schedule / population classes
+  schedules/...                      the schedule JSON data files the bench / tests use
+                                     (re-serialised through the reference's to_dict)
+"""
+import hashlib
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+REPO = OUT.parents[1]
+sys.path.insert(0, str(REF))
+# graphviz is only used for rendering (ecad/graph/builder.py:8,80)
+sys.modules.setdefault("graphviz", types.ModuleType("graphviz")).Digraph = object
+
+from ecad.genetic.pixart_population_io_manager import PixArtPopulationIOManager  # noqa: E402
+from ecad.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule  # noqa: E402
+from ecad.schedulers.cache_scheduler.generators.pixart_schedule_generators import gen_default  # noqa: E402
+
+
+def mac_kat():
+    names, bits, macs, totals = [], [], [], []
+    skipped = 0
+    for p in sorted((REF / "schedules").rglob("*.json")):
+        rel = str(p.relative_to(REF / "schedules"))
+        if rel.startswith("flux") or "/flux" in rel:
+            continue
+        with open(p) as f:
+            d = json.load(f)
+        cs = d.get("cache_schedule")
+        m = d.get("metrics", {}).get("by_inference_step")
+        if cs is None or m is None or cs.get("num_blocks") != 28:
+            continue
+        cfg = d.get("config", {}) or {}
+        if cfg.get("pipeline", {}).get("name") == "tgate":
+            skipped += 1
+            continue
+        if "1024" in str(cfg.get("transformer_weights", "")) or cfg.get("height", 256) != 256:
+            skipped += 1
+            continue
+        sched = PixArtCacheSchedule.from_json(p)
+        b = sched.to_numpy(flatten=True)
+        steps = sched.num_inference_steps
+        if steps != 20 or b.size != 1680:
+            skipped += 1
+            continue
+        names.append(rel)
+        bits.append(np.packbits(b))
+        macs.append([m[f"{s:03}"]["macs"] for s in range(steps)])
+        totals.append(d["metrics"].get("total_macs", -1))
+    np.savez_compressed(
+        OUT / "mac_kat.npz",
+        names=np.array(names),
+        bits=np.stack(bits),
+        macs=np.array(macs, dtype=np.int64),
+        totals=np.array(totals, dtype=np.int64),
+    )
+    print(f"mac_kat: {len(names)} schedules, skipped {skipped}")
+
+
+def copy_schedule(rel: str):
+    """Re-serialise a reference schedule JSON (data) through the reference's own to_dict."""
+    src = REF / "schedules" / rel
+    sched = PixArtCacheSchedule.from_json(src)
+    dst = REPO / "schedules" / rel
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    sched.to_json(dst)
+    return sched
+
+
+def schedule_vectors():
+    out = {}
+    named = {
+        "ours_fast": "schedules_in_paper/pixart_alpha_256/ours_fast.json",
+        "ours_faster": "schedules_in_paper/pixart_alpha_256/ours_faster.json",
+        "ours_fastest": "schedules_in_paper/pixart_alpha_256/ours_fastest.json",
+        "sigma_ours_fast": "schedules_in_paper/pixart_sigma_256/ours_fast.json",
+        "default": "alpha_cache_schedules/gen_default/default.json",
+        "recompute_all_every_002": "alpha_cache_schedules/gen_recompute_all_every_n/recompute_all_every_002.json",
+        "recompute_all_every_003": "alpha_cache_schedules/gen_recompute_all_every_n/recompute_all_every_003.json",
+    }
+    vec = {}
+    for key, rel in named.items():
+        sched = copy_schedule(rel)
+        b = sched.to_numpy(flatten=True)
+        vec[key] = {
+            "path": rel,
+            "packed_hex": np.packbits(b).tobytes().hex(),
+            "sum": int(b.sum()),
+            "sha256_of_bits": hashlib.sha256(b.astype(np.uint8).tobytes()).hexdigest(),
+            "name": sched.name,
+            "attributes": sched.attributes,
+        }
+    out["to_numpy"] = vec
+
+    # to_dict round trip: key padding "000", block keys as strings
+    sched = PixArtCacheSchedule.from_json(REF / "schedules" / named["ours_fast"])
+    d = sched.to_dict()
+    out["to_dict_shape"] = {
+        "top_keys": list(d.keys()),
+        "cache_schedule_keys": list(d["cache_schedule"].keys()),
+        "step_keys": list(d["cache_schedule"]["schedule"].keys()),
+        "block_keys_step0": list(d["cache_schedule"]["schedule"]["000"].keys()),
+        "entry_000_17": d["cache_schedule"]["schedule"]["000"]["17"],
+    }
+
+    # step-counter trace under callbacks 0..19 (cache_schedule.py:58-66)
+    trace = []
+    sched.reset_step()
+    for s in range(20):
+        trace.append([sched.curr_step, bool(sched.get_recompute("3", "ff")), bool(sched.get_recompute("0", "attn1"))])
+        sched.per_step_callback(s, 999 - 50 * s)
+    after = sched.curr_step
+    sched.reset_step()
+    out["step_trace"] = {"trace": trace, "curr_step_after_19": after, "curr_step_after_reset": sched.curr_step}
+    try:
+        sched.get_recompute("0", "bogus")
+        out["bad_component_raises"] = None
+    except ValueError as e:
+        out["bad_component_raises"] = "ValueError"
+    out["custom_compute_default"] = {
+        "attn": sched.get_custom_compute_attn("0"),
+        "ff": sched.get_custom_compute_ff("0"),
+    }
+
+    # population manager: bit-vector <-> schedule dict, constraints, attributes
+    import tempfile
+
+    rng = np.random.default_rng(1234)
+    x = rng.integers(0, 2, size=1680).astype(np.bool_)
+    sd = PixArtPopulationIOManager.binary_vector_to_schedule_dict(x, 20, 28, 3)
+    rt = PixArtCacheSchedule(28, 20, "rt", sd).to_numpy(flatten=True)
+    with tempfile.TemporaryDirectory() as td:
+        mgr = PixArtPopulationIOManager("kat", Path(td) / "p", Path(td) / "b", generation_num=1)
+        pop = np.stack([x, np.ones(1680, dtype=np.bool_), sched.to_numpy(flatten=True)])
+        G = mgr.get_constraint_violations(pop)
+        info = mgr.compute_additional_info(sched.schedule)
+        info_x = mgr.compute_additional_info(sd)
+    out["population"] = {
+        "seed": 1234,
+        "x_packed_hex": np.packbits(x).tobytes().hex(),
+        "roundtrip_equal": bool((rt == x).all()),
+        "entry_step5_block7": sd[5]["7"],
+        "G": G.reshape(-1).tolist(),
+        "additional_info_ours_fast": info,
+        "additional_info_x": info_x,
+    }
+    d0 = next(gen_default(28, 20))
+    out["default_schedule"] = {"name": d0.name, "all_true": bool(d0.to_numpy().all()), "attributes": d0.attributes}
+
+    with open(OUT / "schedule_vectors.json", "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("schedule_vectors.json written")
+
+    # GA seed population used by BASELINE config 4 (72 candidates): bits only
+    pop_dir = REF / "schedules/population_initialization/pixart_alpha_256x256/gen_000/candidates"
+    if pop_dir.exists():
+        cands = sorted(pop_dir.glob("cand_*.json"))
+        packed = np.stack([np.packbits(PixArtCacheSchedule.from_json(c).to_numpy(flatten=True)) for c in cands])
+        np.savez_compressed(OUT / "ga_seed_population.npz", bits=packed, names=np.array([c.name for c in cands]))
+        print(f"ga_seed_population: {len(cands)} candidates")
+
+
+if __name__ == "__main__":
+    mac_kat()
+    schedule_vectors()

@@ -1,0 +1,147 @@
+"""Minimal PixArt pipeline around the native transformer (diffusers is not a dependency).
+
+Mirrors the call the reference's image generators make
+(``ecad/image_generators/pixart_image_generator.py:358-383``) and the loop at
+``ecad/pipelines/pass_through.py:169-404`` (verbatim diffusers ``PixArtAlphaPipeline.__call__``):
+CFG concat with the negative half first, 20 DPM-Solver++ steps, ``callback(step, t, latents)``
+after every step.  Two execution paths over the same engine:
+
+* ``native_loop=True`` (default when the only callbacks are the schedule counters): the whole loop
+  runs as ONE ``ecad_run_schedule`` call (hipGraph replay); the callbacks are then fired in order so
+  the host-side counters end in the same state.
+* per-step: Python loop, one ``ecad_step`` per step, solver math in torch -- the drop-in for code
+  that needs intermediate latents.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from ecad_amd.pipelines.dpm_solver import DPMSolverMultistepScheduler
+
+# 4-channel SD latent -> RGB preview factors (only used when no VAE is attached)
+_LATENT_RGB = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0.158, 0.189, 0.264], [-0.184, -0.271, -0.473]])
+
+
+class PixArtAlphaPipeline:
+    vae_scale_factor = 8
+
+    def __init__(self, transformer=None, scheduler=None, vae=None, text_encoder=None, tokenizer=None):
+        self.transformer = transformer
+        self.scheduler = scheduler or DPMSolverMultistepScheduler()
+        self.vae = vae
+        self.text_encoder = text_encoder
+        self.tokenizer = tokenizer
+        self.native_loop = True
+        self._device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, transformer=None, text_encoder=None, vae=None, scheduler=None, **kwargs):
+        return cls(transformer=transformer, scheduler=scheduler, vae=vae, text_encoder=text_encoder)
+
+    def to(self, device):
+        self._device = torch.device(device)
+        return self
+
+    def encode_prompt(self, *a, **k):
+        raise NotImplementedError("text encoding stays in PyTorch/transformers (T5) and needs the encoder weights; out of scope for the hot path")
+
+    def prepare_latents(self, batch, channels, height, width, dtype, device, generator, latents=None):
+        shape = (batch, channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            # randn_tensor [ext]: CPU generator => sample on CPU, then move
+            gdev = generator.device if generator is not None else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        return latents.to(device) * self.scheduler.init_noise_sigma
+
+    @torch.no_grad()
+    def __call__(
+        self,
+        prompt=None,
+        negative_prompt=None,
+        prompt_embeds: torch.Tensor | None = None,
+        prompt_attention_mask: torch.Tensor | None = None,
+        negative_prompt_embeds: torch.Tensor | None = None,
+        negative_prompt_attention_mask: torch.Tensor | None = None,
+        num_images_per_prompt: int = 1,
+        num_inference_steps: int = 20,
+        generator: torch.Generator | None = None,
+        guidance_scale: float = 4.5,
+        height: Optional[int] = None,
+        width: Optional[int] = None,
+        latents: torch.Tensor | None = None,
+        output_type: str = "pil",
+        return_dict: bool = True,
+        callback: Callable[[int, int, torch.Tensor], None] | None = None,
+        callback_steps: int = 1,
+        **kwargs,
+    ):
+        if prompt is not None or prompt_embeds is None:
+            raise ValueError("pass pre-computed prompt_embeds (as the reference's image generators do)")
+        if num_images_per_prompt != 1:
+            raise ValueError("num_images_per_prompt must be 1 (the reference always passes 1)")
+        tr = self.transformer
+        sample = tr.config.sample_size
+        height = height or sample * self.vae_scale_factor
+        width = width or sample * self.vae_scale_factor
+        device = tr.device
+        B = prompt_embeds.shape[0]
+        cfg_on = guidance_scale > 1.0
+        if not cfg_on:
+            raise ValueError("guidance_scale <= 1 (no CFG) is not wired into the native loop")
+        enc = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(device)
+        mask = torch.cat([negative_prompt_attention_mask, prompt_attention_mask], dim=0).to(device)
+
+        self.scheduler.set_timesteps(num_inference_steps, device=None)
+        timesteps = self.scheduler.timesteps
+        latents = self.prepare_latents(B, tr.config.in_channels, height, width, tr.dtype, device, generator, latents)
+
+        if self.native_loop:
+            lat = tr.engine.run_schedule(enc, mask, latents.float(), timesteps.numpy().astype(np.float32), self.scheduler.coefficient_table(), guidance_scale, use_graph=True)
+            latents = lat.to(tr.dtype)
+            if callback is not None:
+                for i, t in enumerate(timesteps):
+                    if i % callback_steps == 0:
+                        callback(i, t, latents)
+            tr._begun_key = None
+        else:
+            for i, t in enumerate(timesteps):
+                x_in = torch.cat([latents] * 2)
+                tt = torch.full((x_in.shape[0],), float(t), device=device)
+                noise = tr(x_in, encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=tt, added_cond_kwargs=None, return_dict=False)[0]
+                u, c = noise.chunk(2)
+                noise = u + guidance_scale * (c - u)
+                if tr.config.out_channels // 2 == tr.config.in_channels:
+                    noise = noise.chunk(2, dim=1)[0]
+                latents = self.scheduler.step(noise, t, latents)[0]
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, latents)
+
+        if output_type == "latent":
+            image = latents
+        else:
+            image = self.decode(latents, output_type)
+        return (image,) if not return_dict else {"images": image}
+
+    def decode(self, latents: torch.Tensor, output_type: str = "pil"):
+        """VAE decode when a VAE module is attached (stays PyTorch/MIOpen); otherwise a linear latent->RGB preview."""
+        if self.vae is not None:
+            img = self.vae.decode(latents / getattr(self.vae.config, "scaling_factor", 0.13025), return_dict=False)[0]
+        else:
+            img = torch.einsum("bchw,cr->brhw", latents.float().cpu(), _LATENT_RGB)
+            img = torch.nn.functional.interpolate(img, scale_factor=self.vae_scale_factor, mode="nearest")
+        img = (img / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return img
+        arr = (img.permute(0, 2, 3, 1).float().cpu().numpy() * 255).round().astype("uint8")
+        if output_type == "np":
+            return arr
+        from PIL import Image
+
+        return [Image.fromarray(a) for a in arr]
+
+
+class PixArtSigmaPipeline(PixArtAlphaPipeline):
+    pass

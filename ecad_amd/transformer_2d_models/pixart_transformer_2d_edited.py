@@ -1,0 +1,267 @@
+"""``PixArtTransformer2DEdited``: host-side facade over the native engine.
+
+Keeps the reference class's surface
+(``ecad/transformer_2d_models/pixart_transformer_2d_edited.py:21-253``): constructor keywords,
+``from_pretrained(..., dit_scheduler=, cache_schedule=)``, ``forward(hidden_states,
+encoder_hidden_states, timestep, added_cond_kwargs, cross_attention_kwargs, attention_mask,
+encoder_attention_mask, return_dict)``, ``reset_cache()``, ``.config``, ``.dtype``, ``.device``.
+There are no torch modules inside: weights live in the engine (re-laid-out), and ``forward`` is
+one ``ecad_step`` call at schedule row ``cache_schedule.curr_step``.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Any, Dict, Optional
+
+import torch
+
+from ecad_amd.engine import EcadEngine
+from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
+from ecad_amd.schedulers.dit_scheduler.dit_scheduler import DiTScheduler
+
+# geometry of the checkpoints the reference names (image_generators/pixart_*_image_generator.py)
+KNOWN_CONFIGS: dict[str, dict[str, Any]] = {
+    "PixArt-alpha/PixArt-XL-2-256x256": dict(sample_size=32, caption_channels=4096, max_text_tokens=120),
+    "PixArt-alpha/PixArt-XL-2-512x512": dict(sample_size=64, caption_channels=4096, max_text_tokens=120),
+    "PixArt-alpha/PixArt-XL-2-1024-MS": dict(sample_size=128, caption_channels=4096, max_text_tokens=120, use_additional_conditions=True),
+    "PixArt-alpha/PixArt-Sigma-XL-2-256x256": dict(sample_size=32, caption_channels=4096, max_text_tokens=300),
+    "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS": dict(sample_size=128, caption_channels=4096, max_text_tokens=300, interpolation_scale=2),
+}
+
+
+def state_dict_shapes(cfg) -> dict[str, tuple[int, ...]]:
+    """diffusers ``PixArtTransformer2DModel`` state-dict keys and shapes [ext]."""
+    d, p = cfg.num_attention_heads * cfg.attention_head_dim, cfg.patch_size
+    s: dict[str, tuple[int, ...]] = {
+        "pos_embed.proj.weight": (d, cfg.in_channels, p, p),
+        "pos_embed.proj.bias": (d,),
+        "adaln_single.emb.timestep_embedder.linear_1.weight": (d, 256),
+        "adaln_single.emb.timestep_embedder.linear_1.bias": (d,),
+        "adaln_single.emb.timestep_embedder.linear_2.weight": (d, d),
+        "adaln_single.emb.timestep_embedder.linear_2.bias": (d,),
+        "adaln_single.linear.weight": (6 * d, d),
+        "adaln_single.linear.bias": (6 * d,),
+        "caption_projection.linear_1.weight": (d, cfg.caption_channels),
+        "caption_projection.linear_1.bias": (d,),
+        "caption_projection.linear_2.weight": (d, d),
+        "caption_projection.linear_2.bias": (d,),
+        "scale_shift_table": (2, d),
+        "proj_out.weight": (p * p * cfg.out_channels, d),
+        "proj_out.bias": (p * p * cfg.out_channels,),
+    }
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}."
+        s[b + "scale_shift_table"] = (6, d)
+        for a in ("attn1", "attn2"):
+            for proj in ("to_q", "to_k", "to_v", "to_out.0"):
+                s[b + f"{a}.{proj}.weight"] = (d, d)
+                s[b + f"{a}.{proj}.bias"] = (d,)
+        s[b + "ff.net.0.proj.weight"] = (4 * d, d)
+        s[b + "ff.net.0.proj.bias"] = (4 * d,)
+        s[b + "ff.net.2.weight"] = (d, 4 * d)
+        s[b + "ff.net.2.bias"] = (d,)
+    return s
+
+
+def synthetic_state_dict(cfg, seed: int = 0, std: float = 0.02, bias_std: float = 0.02) -> dict[str, torch.Tensor]:
+    """Seeded random-init weights with the checkpoint's shapes (no network => no real weights).
+
+    Same recipe as the oracle's ``make_weights`` so both sides see identical tensors: keys in
+    ``state_dict_shapes`` order from one CPU generator; W ~ N(0, std^2), biases ~ N(0, bias_std^2),
+    scale_shift_table ~ N(0, 1)/sqrt(D).
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    d = cfg.num_attention_heads * cfg.attention_head_dim
+    out = {}
+    for name, shape in state_dict_shapes(cfg).items():
+        if name.endswith("scale_shift_table"):
+            out[name] = torch.randn(shape, generator=g) / math.sqrt(d)
+        elif name.endswith("bias"):
+            out[name] = torch.randn(shape, generator=g) * bias_std
+        else:
+            out[name] = torch.randn(shape, generator=g) * std
+    return out
+
+
+class PixArtTransformer2DEdited:
+    def __init__(
+        self,
+        num_attention_heads: int = 16,
+        attention_head_dim: int = 72,
+        in_channels: int = 4,
+        out_channels: Optional[int] = 8,
+        num_layers: int = 28,
+        dropout: float = 0.0,
+        norm_num_groups: int = 32,
+        cross_attention_dim: Optional[int] = 1152,
+        attention_bias: bool = True,
+        sample_size: int = 128,
+        patch_size: int = 2,
+        activation_fn: str = "gelu-approximate",
+        num_embeds_ada_norm: Optional[int] = 1000,
+        upcast_attention: bool = False,
+        norm_type: str = "ada_norm_single",
+        norm_elementwise_affine: bool = False,
+        norm_eps: float = 1e-6,
+        interpolation_scale: Optional[int] = None,
+        use_additional_conditions: Optional[bool] = None,
+        caption_channels: Optional[int] = None,
+        attention_type: Optional[str] = "default",
+        dit_scheduler: DiTScheduler | None = None,
+        cache_schedule: PixArtCacheSchedule | None = None,
+        # engine sizing (not in the reference; defaults cover batch 16 with CFG at 256x256)
+        max_batch: int = 32,
+        max_tokens: int | None = None,
+        max_text_tokens: int = 120,
+        torch_dtype: torch.dtype = torch.float16,
+        device: int | None = None,
+    ):
+        if norm_type != "ada_norm_single" or activation_fn != "gelu-approximate" or not attention_bias:
+            raise ValueError("the native engine implements the PixArt configuration only (ada_norm_single, gelu-approximate, attention_bias)")
+        if use_additional_conditions is None:
+            use_additional_conditions = sample_size == 128
+        self.config = SimpleNamespace(
+            num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim, in_channels=in_channels,
+            out_channels=out_channels, num_layers=num_layers, dropout=dropout, cross_attention_dim=cross_attention_dim,
+            attention_bias=attention_bias, sample_size=sample_size, patch_size=patch_size, activation_fn=activation_fn,
+            num_embeds_ada_norm=num_embeds_ada_norm, upcast_attention=upcast_attention, norm_type=norm_type,
+            norm_elementwise_affine=norm_elementwise_affine, norm_eps=norm_eps, interpolation_scale=interpolation_scale,
+            use_additional_conditions=use_additional_conditions, caption_channels=caption_channels or 4096, attention_type=attention_type,
+        )
+        if use_additional_conditions:
+            raise ValueError("micro-conditioned (1024-MS alpha) checkpoints are not supported yet: resolution/aspect-ratio embedders missing")
+        self.inner_dim = num_attention_heads * attention_head_dim
+        self.out_channels = out_channels
+        self.norm_type = norm_type
+        self.use_additional_conditions = use_additional_conditions
+        self.dtype = torch_dtype
+        dev = torch.cuda.current_device() if device is None else device
+        self.device = torch.device("cuda", dev)
+        self.engine = EcadEngine(
+            num_layers=num_layers, num_heads=num_attention_heads, head_dim=attention_head_dim, in_channels=in_channels,
+            out_channels=out_channels, patch_size=patch_size, sample_size=sample_size, caption_channels=self.config.caption_channels,
+            max_batch=max_batch, max_tokens=max_tokens or (sample_size // patch_size) ** 2, max_text_tokens=max_text_tokens,
+            dtype=torch_dtype, norm_eps=norm_eps, interpolation_scale=interpolation_scale, device=dev,
+        )
+        self.dit_scheduler: DiTScheduler = dit_scheduler  # type: ignore
+        self.cache_schedule: PixArtCacheSchedule | None = None
+        self._begun_key = None
+        if cache_schedule is not None and dit_scheduler is not None:
+            self._post_init(dit_scheduler, cache_schedule)
+
+    # -- reference: _post_init (:81-102) ----------------------------------------------------
+    def _post_init(self, dit_scheduler: DiTScheduler | None, cache_schedule: PixArtCacheSchedule | None):
+        if dit_scheduler is None:
+            raise ValueError("A DiTScheduler object must be provided.")
+        if cache_schedule is None:
+            raise ValueError("A cache schedule is required: the native engine always runs the cached block path.")
+        if not cache_schedule.uses_only_native_compute():
+            raise ValueError("schedule names a custom_compute_attn/custom_compute_ff other than the native cached functions")
+        if cache_schedule.num_blocks != self.config.num_layers:
+            raise ValueError(f"schedule has {cache_schedule.num_blocks} blocks, model has {self.config.num_layers}")
+        self.dit_scheduler = dit_scheduler
+        self.cache_schedule = cache_schedule
+        self.engine.set_schedule(cache_schedule.to_numpy())
+        self._begun_key = None
+
+    def load_state_dict(self, state: dict[str, torch.Tensor], strict: bool = True):
+        self.engine.load_state_dict(state)
+        return self
+
+    @classmethod
+    def from_pretrained(
+        cls,
+        pretrained_model_name_or_path: Optional[str | os.PathLike],
+        dit_scheduler: DiTScheduler | None = None,
+        cache_schedule: PixArtCacheSchedule | None = None,
+        subfolder: str | None = None,
+        torch_dtype: torch.dtype = torch.float16,
+        use_safetensors: bool = True,
+        synthetic_seed: int | None = None,
+        **kwargs,
+    ) -> "PixArtTransformer2DEdited":
+        """Local checkpoint directory (config.json + *.safetensors) or a known model name.
+
+        With no network and no checkpoint on disk a known name is instantiated with seeded
+        synthetic weights (``synthetic_seed`` or env ECAD_SYNTHETIC_SEED, default 0) and says so.
+        """
+        path = Path(str(pretrained_model_name_or_path))
+        if subfolder and (path / subfolder).exists():
+            path = path / subfolder
+        state = None
+        cfg_kw: dict[str, Any] = {}
+        if (path / "config.json").exists():
+            with open(path / "config.json") as f:
+                raw = json.load(f)
+            cfg_kw = {k: v for k, v in raw.items() if not k.startswith("_")}
+            from safetensors.torch import load_file
+
+            state = {}
+            for st_file in sorted(path.glob("*.safetensors")):
+                state.update(load_file(str(st_file)))
+        elif str(pretrained_model_name_or_path) in KNOWN_CONFIGS:
+            cfg_kw = dict(KNOWN_CONFIGS[str(pretrained_model_name_or_path)])
+        else:
+            raise ValueError(f"{pretrained_model_name_or_path!r}: neither a local checkpoint directory nor a known PixArt model name")
+        max_text = cfg_kw.pop("max_text_tokens", kwargs.pop("max_text_tokens", 120))
+        known = set(cls.__init__.__code__.co_varnames)
+        cfg_kw = {k: v for k, v in cfg_kw.items() if k in known}
+        cfg_kw.update({k: v for k, v in kwargs.items() if k in known})
+        model = cls(**cfg_kw, max_text_tokens=max_text, torch_dtype=torch_dtype)
+        if state is None:
+            seed = synthetic_seed if synthetic_seed is not None else int(os.environ.get("ECAD_SYNTHETIC_SEED", "0"))
+            print(f"WARNING: no checkpoint for {pretrained_model_name_or_path!r} on disk; using seeded synthetic weights (seed {seed}).")
+            state = synthetic_state_dict(model.config, seed)
+        model.load_state_dict(state)
+        model._post_init(dit_scheduler, cache_schedule)
+        return model
+
+    # -- reference: reset_cache (:155-158) ------------------------------------------------------
+    def reset_cache(self) -> None:
+        self.engine.reset_cache()
+        self._begun_key = None
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def eval(self):
+        return self
+
+    # -- reference: forward (:160-253) ----------------------------------------------------------
+    @torch.no_grad()
+    def forward(
+        self,
+        hidden_states: torch.Tensor,
+        encoder_hidden_states: Optional[torch.Tensor] = None,
+        timestep: Optional[torch.Tensor] = None,
+        added_cond_kwargs: Dict[str, torch.Tensor] | None = None,
+        cross_attention_kwargs: Dict[str, Any] | None = None,
+        attention_mask: Optional[torch.Tensor] = None,
+        encoder_attention_mask: Optional[torch.Tensor] = None,
+        return_dict: bool = True,
+    ):
+        if self.cache_schedule is None:
+            raise ValueError("no cache schedule attached (call _post_init / from_pretrained with cache_schedule=)")
+        if attention_mask is not None:
+            raise ValueError("self-attention masks are not supported by the native engine (PixArt passes None)")
+        if encoder_hidden_states is None or timestep is None:
+            raise ValueError("encoder_hidden_states and timestep are required")
+        step = self.cache_schedule.curr_step
+        enc_mask = encoder_attention_mask
+        if enc_mask is not None and enc_mask.ndim == 3:  # already a bias [B,1,T]: 0 keep / -10000 discard
+            enc_mask = (enc_mask[:, 0, :] > -1.0).to(torch.uint8)
+        key = (encoder_hidden_states.data_ptr(), tuple(encoder_hidden_states.shape), tuple(hidden_states.shape))
+        if step == 0 or self._begun_key != key:
+            # step-invariant work (caption projection, text K/V) is hoisted to the start of the batch
+            self.engine.begin_image_batch(encoder_hidden_states, enc_mask, hidden_states.shape[-2], hidden_states.shape[-1])
+            self._begun_key = key
+        out = self.engine.step(step, hidden_states, timestep)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+    __call__ = forward

@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec at a fixed schedule -- PixArt-alpha 256x256, 20 steps,
+schedules_in_paper/pixart_alpha_256/ours_fast.json, batch 16 (transformer batch 32 with CFG), CFG 4.5.
+
+One "step" = one pass of the hot path over one image batch of 16: hoisted caption projection + text K/V,
+20 x (CFG-doubled transformer forward with the cache gate -> guidance -> learned-sigma drop ->
+DPM-Solver++(2M) update), latents out.  Inputs (prompt embeddings, masks, initial latents) are resident
+in HBM when the timed region starts; VAE decode / PIL are NOT in the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, independent replicas over disjoint image batches (weak scaling), no data-path
+collective; RCCL carries only the barrier and the max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SCHEDULE = ROOT / "schedules/schedules_in_paper/pixart_alpha_256/ours_fast.json"
+BATCH = 16
+NUM_STEPS = 20
+GUIDANCE = 4.5
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+_T0 = time.time()
+
+
+def log(*a):
+    print(f"[bench +{time.time() - _T0:6.1f}s]", *a, file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def device_weights(cfg_like, seed: int, device) -> dict[str, torch.Tensor]:
+    """Random-init weights of the PixArt-XL-2 architecture, generated on the device (fp16)."""
+    from ecad_amd.transformer_2d_models.pixart_transformer_2d_edited import state_dict_shapes
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    d = cfg_like.num_attention_heads * cfg_like.attention_head_dim
+    out = {}
+    for name, shape in state_dict_shapes(cfg_like).items():
+        scale = d**-0.5 if name.endswith("scale_shift_table") else 0.02
+        out[name] = (torch.randn(shape, generator=g, device=device) * scale).half()
+    return out
+
+
+def synthetic_batch(batch: int, seed: int, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    T, C = 120, 4096
+    prompt = (torch.randn(batch, T, C, generator=g) * 0.1).half()
+    lens = torch.randint(8, T + 1, (batch,), generator=g)
+    mask = (torch.arange(T)[None, :] < lens[:, None]).to(torch.uint8)
+    neg = (torch.randn(1, T, C, generator=g) * 0.1).half().repeat(batch, 1, 1)
+    neg_mask = torch.zeros(batch, T, dtype=torch.uint8)
+    neg_mask[:, :2] = 1
+    latents = torch.randn(batch, 4, 32, 32, generator=g)
+    enc = torch.cat([neg, prompt], 0).to(device)
+    m = torch.cat([neg_mask, mask], 0).to(device)
+    return enc, m, latents.to(device)
+
+
+def cpu_baseline(weights: dict[str, torch.Tensor], bits: np.ndarray, images: int) -> dict:
+    """The oracle (fp32 PyTorch restatement of the reference module graph) timed on the host cores."""
+    from oracle.pipeline_ref import denoise, synthetic_inputs
+    from oracle.pixart_ref import PixArtConfig, PixArtOracle
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log(f'cpu baseline on {cores} threads')
+    model = PixArtOracle(PixArtConfig(), {k: v.float().cpu() for k, v in weights.items()})
+    inp = synthetic_inputs(images)
+    t0 = time.perf_counter()
+    denoise(model, bits, inp)
+    dt = time.perf_counter() - t0
+    return {
+        "value": images / dt,
+        "unit": "images/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{images} image(s) (CFG batch {2 * images}), full 20-step ours_fast schedule, fp32 PyTorch eager oracle, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    from ecad_amd.engine import EcadEngine
+    from ecad_amd.pipelines.dpm_solver import DPMSolverMultistepScheduler
+    from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
+
+    log('imports done')
+    sched = PixArtCacheSchedule.from_json(SCHEDULE)
+    bits = sched.to_numpy()
+    eng = EcadEngine(num_layers=28, max_batch=2 * BATCH, max_tokens=256, max_text_tokens=120, dtype=torch.float16, device=local_rank)
+    weights = device_weights(type("C", (), dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2,
+                                                num_layers=28, caption_channels=4096)), seed=0, device=device)
+    log('weights generated')
+    eng.load_state_dict(weights)
+    log('weights loaded')
+    eng.set_schedule(bits)
+    solver = DPMSolverMultistepScheduler()
+    solver.set_timesteps(NUM_STEPS)
+    ts = solver.timesteps.numpy().astype(np.float32)
+    coefs = solver.coefficient_table()
+    enc, mask, latents = synthetic_batch(BATCH, seed=1000 + rank, device=device)  # disjoint work per rank
+
+    def one_batch(graph=True):
+        return eng.run_schedule(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=graph)
+
+    use_graph = not args.no_graph
+    for _ in range(max(args.warmup, 1)):
+        out = one_batch(use_graph)
+    torch.cuda.synchronize()
+    log('warmup done')
+    assert torch.isfinite(out).all(), "non-finite latents"
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_batch(use_graph)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    log(f'timed region done: {elapsed:.3f}s')
+    if rank == 0:
+        st = eng.stats()
+        images = world * BATCH * args.steps
+        value = images / elapsed
+        flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"]) / BATCH
+        res = {
+            "metric": "images/sec at fixed schedule (PixArt-alpha 256, 20-step, ours_fast)",
+            "value": value,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": "PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch=16 (CFG batch 32), 1xMI355X per rank",
+                "batch_per_gpu": BATCH,
+                "guidance_scale": GUIDANCE,
+                "timed_region": "caption-proj + text-KV hoist, 20 transformer steps with cache gate, CFG, DPM-Solver++; latents out (no VAE/PIL)",
+                "weights": "random-init PixArt-XL-2 shapes (no checkpoint available offline)",
+                "hipgraph": bool(use_graph and st["graph_nodes"] > 0),
+                "kernel_launches_per_batch": st["launches_per_batch"],
+                "ms_per_image": 1000.0 * elapsed / (args.steps * BATCH),
+                "reference_equivalent_tflop_per_image": flop_per_image / 1e12,
+                "whole_job_mfma_fraction": value / world * flop_per_image / 1e12 / PEAK_MFMA_TFLOPS,
+                "published_reference_a6000_images_per_s": 11.89,
+            },
+        }
+        if not args.no_roofline:
+            # per-kernel-class device time, HIP events on the launch stream around every launch of one eager batch
+            eng.set_profiling(True)
+            reps = 2
+            for _ in range(reps):
+                one_batch(False)
+            torch.cuda.synchronize()
+            prof = eng.get_profile()
+            log('roofline pass done')
+            eng.set_profiling(False)
+            gemms = {k: v for k, v in prof.items() if k.startswith("gemm") and v["launches"] > 0}
+            dom = max(gemms, key=lambda k: gemms[k]["ms"])
+            d = gemms[dom]
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            all_ms = sum(v["ms"] for v in gemms.values())
+            all_fl = sum(v["flops"] for v in gemms.values())
+            res["roofline"] = {
+                "bound": "mfma",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": PEAK_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_MFMA_TFLOPS,
+                "traffic": None,
+                "flops_per_launch": d["flops"] / d["launches"],
+                "avg_launch_ms": d["ms"] / d["launches"],
+                "launches_measured": d["launches"],
+                "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12,
+            }
+            rep = prof.get("cache_replay")
+            if rep and rep["launches"]:
+                gbs = rep["bytes"] / (rep["ms"] * 1e-3) / 1e9
+                res["roofline_hbm"] = {"bound": "hbm", "kernel": "cache_replay", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": gbs / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": rep["bytes"] / rep["launches"],
+                                       "avg_launch_ms": rep["ms"] / rep["launches"]}
+            tot = sum(v["ms"] for v in prof.values())
+            res["time_breakdown_ms_per_batch"] = {k: round(v["ms"] / reps, 3) for k, v in prof.items() if v["launches"]}
+            res["time_breakdown_ms_per_batch"]["_sum"] = round(tot / reps, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(weights, bits, images=2)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

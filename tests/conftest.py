@@ -10,7 +10,21 @@ if str(ROOT) not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def _usable_cores() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def pytest_configure(config):
+    import torch
+
+    torch.set_num_threads(_usable_cores())  # a 256-thread pool on a 16-CPU quota crawls
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 

@@ -1,0 +1,150 @@
+"""CPU suite: host-side mirror of the reference surface + C ABI export check (no compute without a GPU)."""
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = ROOT / "tests" / "golden"
+FAST = ROOT / "schedules/schedules_in_paper/pixart_alpha_256/ours_fast.json"
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from ecad_amd import _lib
+
+    lib = _lib.load()
+    header = (ROOT / "include" / "ecad_hip.h").read_text()
+    declared = set(re.findall(r"\b(ecad_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ecad_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ecad_amd import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    cfg = _lib.EcadModelCfg(28, 16, 72, 4, 8, 2, 32, 4096, 32, 256, 120, 0, 1e-6, 0.0)
+    assert lib.ecad_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == _lib.ECAD_E_HIP
+    assert b"no HIP device" in lib.ecad_last_error(None)
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+
+    with pytest.raises(ValueError, match="CUDA is required"):
+        get_image_generator_type("PixArtAlphaImageGenerator")()
+
+
+def test_product_never_imports_oracle():
+    for py in (ROOT / "ecad_amd").rglob("*.py"):
+        txt = py.read_text()
+        assert "import oracle" not in txt and "from oracle" not in txt, py
+
+
+def test_cache_schedule_matches_reference_vectors():
+    from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
+
+    vec = json.load(open(GOLD / "schedule_vectors.json"))
+    for key, v in vec["to_numpy"].items():
+        s = PixArtCacheSchedule.from_json(ROOT / "schedules" / v["path"])
+        bits = s.to_numpy(flatten=True)
+        assert np.packbits(bits).tobytes().hex() == v["packed_hex"], key
+        assert s.name == v["name"] and s.attributes == v["attributes"]
+    s = PixArtCacheSchedule.from_json(FAST)
+    d = s.to_dict()
+    shape = vec["to_dict_shape"]
+    assert list(d.keys()) == shape["top_keys"]
+    assert list(d["cache_schedule"].keys()) == shape["cache_schedule_keys"]
+    assert list(d["cache_schedule"]["schedule"].keys()) == shape["step_keys"]
+    assert list(d["cache_schedule"]["schedule"]["000"].keys()) == shape["block_keys_step0"]
+    assert d["cache_schedule"]["schedule"]["000"]["17"] == shape["entry_000_17"]
+    # step counter + lookups, as traced on the reference object
+    s.reset_step()
+    for step, (curr, ff3, attn0) in enumerate(vec["step_trace"]["trace"]):
+        assert s.curr_step == curr
+        assert s.get_recompute("3", "ff") == ff3 and s.get_recompute("0", "attn1") == attn0
+        s.per_step_callback(step, 0)
+    assert s.curr_step == vec["step_trace"]["curr_step_after_19"]
+    s.reset_step()
+    assert s.curr_step == 0
+    with pytest.raises(ValueError):
+        s.get_recompute("0", "bogus")
+    assert s.get_custom_compute_attn("0") == vec["custom_compute_default"]["attn"] == {}
+    assert s.uses_only_native_compute()
+
+
+def test_bit_vector_round_trip_matches_population_manager():
+    from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
+
+    pop = json.load(open(GOLD / "schedule_vectors.json"))["population"]
+    x = np.unpackbits(np.frombuffer(bytes.fromhex(pop["x_packed_hex"]), dtype=np.uint8))[:1680].astype(bool)
+    s = PixArtCacheSchedule.from_numpy(x, "rt")
+    assert (s.to_numpy(flatten=True) == x).all() and pop["roundtrip_equal"]
+    assert s.schedule[5]["7"] == pop["entry_step5_block7"]
+
+
+def test_json_round_trip(tmp_path):
+    from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
+
+    s = PixArtCacheSchedule.from_json(FAST)
+    s.to_json(tmp_path / "x.json")
+    assert json.load(open(tmp_path / "x.json")) == json.load(open(FAST))
+
+
+def test_registries_and_defaults():
+    from ecad_amd.pipelines.load_pipeline import PipelineRegistry
+    from ecad_amd.schedulers.cache_scheduler.generators.pixart_schedule_generators import gen_default
+    from ecad_amd.transformer_blocks.custom_attn_ff import ComputeAttnRegistry, ComputeFFRegistry
+
+    assert ComputeAttnRegistry.get(None).__name__ == "compute_attn_cached"
+    assert ComputeFFRegistry.get("COMPUTE_FF_CACHED").__name__ == "compute_ff_cached"
+    assert ComputeAttnRegistry.get("nope", True) is None
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ComputeAttnRegistry.get(None)()
+    assert PipelineRegistry.get("pixart_alpha").__name__ == "PixArtAlphaPipeline"
+    with pytest.raises(NotImplementedError):
+        PipelineRegistry.get("tgate")
+    d = next(gen_default(28, 20))
+    ref = json.load(open(GOLD / "schedule_vectors.json"))["default_schedule"]
+    assert d.name == ref["name"] and d.to_numpy().all() and ref["all_true"]
+
+
+def test_solver_matches_oracle_coefficients():
+    from ecad_amd.pipelines.dpm_solver import DPMSolverMultistepScheduler
+    from oracle.dpm_solver_ref import DPMSolverPP2M
+
+    a = DPMSolverMultistepScheduler()
+    a.set_timesteps(20)
+    b = DPMSolverPP2M(20)
+    assert a.timesteps.tolist() == b.timesteps.tolist()
+    tab = a.coefficient_table()
+    exp = np.array([b.coefficients(i, b.order_for_step(i)) for i in range(20)], dtype=np.float32)
+    assert np.allclose(tab, exp, rtol=1e-6, atol=0)
+    # stateful torch path == oracle path on random data
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    xa, xb = x.clone(), x.clone()
+    for i in range(20):
+        eps = torch.randn(2, 4, 8, 8, generator=g)
+        xa = a.step(eps, a.timesteps[i], xa)[0]
+        xb = b.step(eps, xb)
+    assert torch.allclose(xa, xb, rtol=1e-5, atol=1e-6)
+
+
+def test_synthetic_weights_identical_to_oracle_recipe():
+    from types import SimpleNamespace
+
+    from ecad_amd.transformer_2d_models.pixart_transformer_2d_edited import synthetic_state_dict
+    from oracle.pixart_ref import PixArtConfig, make_weights
+
+    cfg = PixArtConfig(num_layers=1)
+    ns = SimpleNamespace(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2, num_layers=1, caption_channels=4096)
+    a, b = synthetic_state_dict(ns, seed=3), make_weights(cfg, seed=3)
+    assert list(a) == list(b)
+    assert all(torch.equal(a[k], b[k]) for k in a)

@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -22,10 +23,13 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "gemm3s.h"
+#include "pgemm.h"
 
 namespace ecad {
 
 static std::string g_create_error;
+constexpr int PROJ_PAD = 144;  // proj_out rows padded to one GEMM tile column
 
 #define HIPCHK(expr)                                                                         \
   do {                                                                                       \
@@ -179,18 +183,25 @@ template <typename T> class EngineT : public EngineBase {
     if (D % 128 != 0 || D % 64 != 0) return fail(ECAD_E_UNSUPPORTED, "inner dim %d must be a multiple of 128", D);
     if (DH % 8 != 0 || DH > 80) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported (need %%8 == 0 and <= 80)", DH);
     if (CIN != 4 || P != 2) return fail(ECAD_E_UNSUPPORTED, "patch embed supports in_channels 4, patch 2");
-    if (P * P * COUT > 128) return fail(ECAD_E_UNSUPPORTED, "proj_out too wide");
+    if (P * P * COUT > PROJ_PAD) return fail(ECAD_E_UNSUPPORTED, "proj_out too wide");
     if (CAP % 64 != 0) return fail(ECAD_E_UNSUPPORTED, "caption_channels must be a multiple of 64");
     if (cfg.max_batch < 1 || cfg.max_tokens < 1 || cfg.max_text_tokens < 1) return fail(ECAD_E_INVALID, "max_batch/max_tokens/max_text_tokens must be positive");
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
+    gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = gemm_impl_cls[KC_GEMM_FF1] = 0;
+    if (const char* gi = getenv("ECAD_GEMM")) {
+      if (strcmp(gi, "classic") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0;
+      if (strcmp(gi, "persistent") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
+    }
+    { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
     // ---- weight arena
     const size_t d = D;
     size_t per_blk_T = d * 3 * d + d * d * 3 + 4 * d * d * 2;  // qkv, o1, q2, o2, ff1, ff2
     size_t per_blk_f = 3 * d + d * 3 + 4 * d + d + 6 * d;
-    size_t glob_T = (size_t)L * 2 * d * d + d * 16 + d * 256 + d * d + 6 * d * d + d * CAP + d * d + 128 * d;
-    size_t glob_f = (size_t)L * 2 * d + d + d + d + 6 * d + d + d + 128 + 2 * d + (size_t)cfg.max_tokens * d;
+    size_t glob_T = (size_t)L * 2 * d * d + d * 16 + d * 256 + d * d + 6 * d * d + d * CAP + d * d + PROJ_PAD * d;
+    size_t glob_f = (size_t)L * 2 * d + d + d + d + 6 * d + d + d + PROJ_PAD + 2 * d + (size_t)cfg.max_tokens * d;
     warena_bytes = (per_blk_T * L + glob_T) * sizeof(T) + (per_blk_f * L + glob_f) * sizeof(float) + (size_t)(L * 16 + 64) * 256;
     HIPCHK(hipMalloc((void**)&warena, warena_bytes));
     HIPCHK(hipMemset(warena, 0, warena_bytes));
@@ -234,7 +245,7 @@ template <typename T> class EngineT : public EngineBase {
     w_ada = walloc<T>(6 * d * d); b_ada = walloc<float>(6 * d);
     w_c1 = walloc<T>(d * CAP); b_c1 = walloc<float>(d);
     w_c2 = walloc<T>(d * d); b_c2 = walloc<float>(d);
-    w_proj = walloc<T>(128 * d); b_proj = walloc<float>(128);
+    w_proj = walloc<T>(PROJ_PAD * d); b_proj = walloc<float>(PROJ_PAD);
     sst_out = walloc<float>(2 * d);
     pos = walloc<float>((size_t)cfg.max_tokens * d);
     reg("pos_embed.proj.weight", w_patch, false, d, CIN * P * P, CIN * P * P);
@@ -266,7 +277,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t o_ao = take(M * d * sizeof(T)), o_qc = take(M * d * sizeof(T)), o_ff = take(M * 4 * d * sizeof(T));
     const size_t o_cm = take(Mt * d * sizeof(T)), o_ctx = take(Mt * d * sizeof(T)), o_kv2 = take(Mt * (size_t)L * 2 * d * sizeof(T));
     const size_t o_cache = take((size_t)L * 3 * M * d * sizeof(T));
-    const size_t o_proj = take(M * 128 * sizeof(T)), o_min = take(lat * sizeof(T)), o_noise = take(lat * sizeof(T));
+    const size_t o_proj = take(M * PROJ_PAD * sizeof(T)), o_min = take(lat * sizeof(T)), o_noise = take(lat * sizeof(T));
     const size_t o_enc = take(Mt * CAP * sizeof(T));
     const size_t trows = max_steps * Bm;
     const size_t o_tsin = take(trows * 256 * sizeof(T)), o_te1 = take(trows * d * sizeof(T)), o_te = take(trows * d * sizeof(T));
@@ -495,7 +506,7 @@ template <typename T> class EngineT : public EngineBase {
     }
     // --- _create_output: norm_out, modulate with scale_shift_table[2, D] + embedded_timestep, proj_out, unpatchify
     emit_ln(ops, pend, M, sst_out, sst_out + D, emb_s, emb_s, estride, mstride);
-    ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, xn, w_proj, b_proj, proj, M, 128, D, D, 128));
+    ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, xn, w_proj, b_proj, proj, M, PROJ_PAD, D, D, PROJ_PAD));
     {
       Op<T> o; o.kind = Op<T>::UNPATCH; o.cls = KC_MISC; o.p0 = proj; o.p2 = noise; o.call_out = bind_call;
       ops.push_back(o);
@@ -597,8 +608,45 @@ template <typename T> class EngineT : public EngineBase {
     constexpr int lds = gemm_lds_bytes<128, 128>();
     hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, EPI>), dim3(tiles), dim3(256), lds, s, g);
   }
-  int launch_gemm(int epi, const GemmArgs<T>& g, hipStream_t s) {
-    if (g.N % 128 || g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (N%%128, K%%64)", g.M, g.N, g.K);
+  bool pg_attr[4][KC_COUNT] = {};
+  int num_cus = 256;
+  bool g3_attr[4][KC_COUNT] = {};
+  // per call-site class: 1 = persistent producer/consumer (pgemm.h), 0 = one tile per workgroup (gemm3s.h).  Defaults from
+  // interleaved in-process A/B runs with cold caches (scripts/bench_gemm.py --cold): the persistent kernel wins where a
+  // CU owns several tiles or K is long and the epilogue is a plain store; the RMW / GELU epilogues favour 8 mixed waves.
+  // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
+  int gemm_impl_cls[KC_COUNT];
+  template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
+    if (gemm_impl_cls[TAG] == 0) {
+      if (!g3_attr[EPI][TAG]) {
+        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+        g3_attr[EPI][TAG] = true;
+      }
+      const int tiles3 = ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN);
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
+      return ECAD_OK;
+    }
+    if (!pg_attr[EPI][TAG]) {
+      HIPCHK(hipFuncSetAttribute((const void*)pgemm_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_BYTES));
+      pg_attr[EPI][TAG] = true;
+    }
+    const int tiles = ((g.M + PG_BM - 1) / PG_BM) * (g.N / PG_BN);
+    const int grid = tiles < num_cus ? tiles : num_cus;  // one persistent workgroup per CU
+    hipLaunchKernelGGL((pgemm_kernel<T, EPI, TAG>), dim3(grid), dim3(512), PG_LDS_BYTES, s, g);
+    return ECAD_OK;
+  }
+  int launch_gemm(int epi, int cls, const GemmArgs<T>& g, hipStream_t s) {
+    if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
+    if (g.N % PG_BN == 0) {
+#define G144(E, C) if (epi == E && cls == C) return launch_pg<E, C>(g, s)
+      G144(EPI_BIAS, KC_GEMM_QKV); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT1); G144(EPI_BIAS, KC_GEMM_Q2); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT2);
+      G144(EPI_BIAS_GELU, KC_GEMM_FF1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_FF2); G144(EPI_BIAS, KC_GEMM_TEXTKV);
+      G144(EPI_BIAS_GELU, KC_GEMM_CAPTION); G144(EPI_BIAS, KC_GEMM_CAPTION);
+      G144(EPI_BIAS, KC_GEMM_SMALL); G144(EPI_BIAS_GELU, KC_GEMM_SMALL); G144(EPI_BIAS_SILU, KC_GEMM_SMALL); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_SMALL);
+#undef G144
+      return fail(ECAD_E_INVALID, "no pgemm instantiation for epilogue %d class %d", epi, cls);
+    }
+    if (g.N % 128) return fail(ECAD_E_INVALID, "gemm N=%d must be a multiple of 144 or 128", g.N);
     switch (epi) {
       case EPI_BIAS: launch_gemm_epi<EPI_BIAS>(g, s); break;
       case EPI_BIAS_GELU: launch_gemm_epi<EPI_BIAS_GELU>(g, s); break;
@@ -632,7 +680,7 @@ template <typename T> class EngineT : public EngineBase {
   int launch_op(const Op<T>& o, hipStream_t s, float guidance) {
     const int M = Bt * N;
     switch (o.kind) {
-      case Op<T>::GEMM: return launch_gemm(o.epi, o.g, s);
+      case Op<T>::GEMM: return launch_gemm(o.epi, o.cls, o.g, s);
       case Op<T>::ATTN: launch_attn(o.a, o.attn_masked, s); break;
       case Op<T>::LN: return launch_ln(o.f, s);
       case Op<T>::REPLAY: launch_replay(o.f, s); break;
@@ -651,7 +699,7 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::UNPATCH: {
         T* dst = o.call_out ? (T*)call_out : (T*)o.p2;
         const int total = Bt * COUT * Hl * Wl;
-        hipLaunchKernelGGL((unpatchify_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, (const T*)o.p0, dst, Bt, Hl / P, Wl / P, P, COUT, 128);
+        hipLaunchKernelGGL((unpatchify_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, (const T*)o.p0, dst, Bt, Hl / P, Wl / P, P, COUT, PROJ_PAD);
         break;
       }
       case Op<T>::SOLVER: {
@@ -796,7 +844,7 @@ template <typename T> class EngineT : public EngineBase {
     g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
     g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K; g.lda = K; g.ldw = K; g.ldc = Nn; g.ldr = Nn;
     if (epi == EPI_BIAS_CACHE_RESID && !resid) return fail(ECAD_E_INVALID, "epilogue 3 needs resid");
-    int rc = launch_gemm(epi, g, s);
+    int rc = launch_gemm(epi, KC_GEMM_SMALL, g, s);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return ECAD_OK;

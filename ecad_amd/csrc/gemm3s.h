@@ -1,0 +1,175 @@
+// gemm3s.h -- non-persistent sibling of pgemm.h: one 256x144 tile per workgroup, 8 mixed waves (each issues its share
+// of the LDS-DMA and owns 32 rows x 144 columns), 3-stage ring, one raw barrier per K-step with counted vmcnt.
+// Kept for in-process A/B against the persistent producer/consumer kernel (ECAD_GEMM=classic selects it).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace ecad {
+
+constexpr int G3_BM = 256, G3_BN = 144, G3_STAGES = 3, G3_NW = 8;
+constexpr int G3_STAGE_BYTES = (G3_BM + G3_BN) * 128;
+constexpr int G3_LDS_BYTES = G3_STAGES * G3_STAGE_BYTES;
+
+template <typename T, int EPI, int TAG>
+__global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p) {
+  constexpr int BM = G3_BM, BN = G3_BN, NWAVES = G3_NW;
+  constexpr int WTM = BM / NWAVES;
+  constexpr int FM = WTM / 16, FN = BN / 16;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int STAGE_BYTES = G3_STAGE_BYTES;
+  constexpr int A_INST = BM / 8 / NWAVES;
+  constexpr int B_INST_TOTAL = BN / 8;
+  constexpr int B_INST_MAX = (B_INST_TOTAL + NWAVES - 1) / NWAVES;
+  constexpr int CS = BN + 8;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const T* a_src[A_INST];
+  const T* b_src[B_INST_MAX];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int row = m0 + r;
+    row = row < p.M ? row : p.M - 1;
+    a_src[i] = p.A + (size_t)row * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INST_MAX; ++i) {
+    int inst = wave + i * NWAVES;
+    inst = inst < B_INST_TOTAL ? inst : B_INST_TOTAL - 1;
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = p.W + (size_t)(n0 + r) * p.ldw + c * 8;
+  }
+  auto issue = [&](int stage) {
+    char* abase = smem + stage * STAGE_BYTES;
+    char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      glds16(a_src[i], abase + (wave * A_INST + i) * 1024);
+      a_src[i] += GEMM_BK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST_MAX; ++i) {
+      const int inst = wave + i * NWAVES;
+      if (inst < B_INST_TOTAL) glds16(b_src[i], bbase + inst * 1024);
+      b_src[i] += GEMM_BK;
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wave * WTM + l15) * 128;
+  const int b_row_off = l15 * 128;
+  const int nk = p.K / GEMM_BK;
+  issue(0);
+  if (nk > 1) issue(1);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A_INST(4) + 2: oldest stage retired for every wave
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      int ns = stage + 2;
+      ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+      issue(ns);
+    }
+    const char* abase = smem + stage * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + g) ^ swz) * 16;
+      Pack8 af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+    }
+    stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
+  }
+  __syncthreads();
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nl = 16 * j + 4 * g;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wave * WTM + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[r];
+        if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+        if (EPI == EPI_BIAS_SILU) v = silu(v);
+        float_to_elem4<T>(o, r, v);
+      }
+      *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  constexpr int CPR = BN / 8;
+  constexpr int CHUNKS = WTM * CPR;
+  for (int id = lane; id < CHUNKS; id += 64) {
+    const int rl = id / CPR, cchunk = id - rl * CPR;
+    const int ml = wave * WTM + rl;
+    const int m = m0 + ml;
+    if (m >= p.M) continue;
+    const int n = n0 + cchunk * 8;
+    Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+    if (EPI == EPI_BIAS_CACHE_RESID) {
+      if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);
+      T* rp = p.resid + (size_t)m * p.ldr + n;
+      Pack8 hv = gload16(rp);
+      float o[8], h[8];
+      unpack8<T>(v, o);
+      unpack8<T>(hv, h);
+      if (p.gate_table) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
+        float gt[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if (p.gate_mod) {
+          float gm[8];
+          const int b = m / p.rows_per_batch;
+          unpack8<T>(gload16(p.gate_mod + (size_t)b * p.gate_mod_stride + n), gm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gt[e] += gm[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += gt[e] * o[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += o[e];
+      }
+      gstore16(rp, pack8<T>(h));
+    } else {
+      gstore16(p.C + (size_t)m * p.ldc + n, v);
+    }
+  }
+}
+
+}  // namespace ecad

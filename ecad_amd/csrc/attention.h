@@ -7,13 +7,16 @@
 // ecad/transformer_blocks/cached_transformer_block.py:348-353; the additive -10000 bias comes from
 // ecad/transformer_2d_models/pixart_transformer_2d_edited.py:255-291).
 //
-// Structure (gfx950, flash-style so N = 4096 (1024^2) works as well as N = 256):
-//   workgroup = 4 waves = 64 query rows of one (batch, head); loop over 64-key tiles staged in LDS.
-//   S^T = K . Q^T on MFMA 16x16x32 with the head dim (72) zero-padded to 96 in LDS only, so each lane owns
-//   ONE query column (q = lane & 15) and 16 keys per tile: row max / sum are 15 in-lane ops + 2 cross-lane
-//   steps, and exp2'd P packs straight into the B operand of O^T = V^T . P^T (k order permuted; V^T is read
-//   with ds_read_b64_tr_b16 in the same permuted order).  O^T accumulators have q on the lane as well, so the
-//   online-softmax rescale needs no shuffles.  head dim padded to 80 for PV (5 d-fragments).
+// Structure (gfx950): persistent workgroups (8 waves) walk work items (batch, head, 256-query block).  The K and V
+// rows of one item's key chunk (KC = 256 keys for self-attention, 128 for the <= 120/300-token text) are staged
+// ONCE in LDS (head dim 72 zero-padded to 96 for K / 80 for V, in LDS only) and shared by all 8 waves; the next
+// chunk is prefetched into registers while the current one is consumed.  Each wave owns 16 query rows at a time:
+//   S^T = K . Q^T (MFMA 16x16x32) for ALL KC keys stays in registers, so the softmax is ONE max / exp2 pass per
+//   chunk -- the lane owns one query column (q = lane & 15), so row max = in-lane ops + 2 cross-lane steps;
+//   exp2'd P packs straight into the B operand of O^T = V^T . P^T (k order permuted; V^T is read with
+//   ds_read_b64_tr_b16 in the same permuted order); column 72 of the padded V tile is all ones, so the softmax
+//   denominator is accumulated by the same MFMAs (O^T row 72) -- no VALU row sums;
+//   chunks are combined with the usual running-max rescale (only matters for N > KC, i.e. 1024^2 images).
 #pragma once
 #include "common.h"
 
@@ -30,174 +33,221 @@ struct AttnArgs {
   float scale_log2e;  // (1/sqrt(dh)) * log2(e)
 };
 
-constexpr int ATT_KT = 64;        // keys per tile
 constexpr int ATT_KS = 104;       // K tile row stride (elements): 96 padded head dim + 8
-constexpr int ATT_VS = 80;        // V tile row stride (elements): head dim padded to 80
-constexpr int ATT_MAXCH = 12;     // max 16-byte chunks per row supported (dh <= 96)
+constexpr int ATT_VS = 80;        // V tile row stride (elements): head dim padded to 80 (column dh = ones)
+constexpr int ATT_QB = 256;       // query rows per work item (8 waves x 16 rows x 2 rounds)
 constexpr float ATT_NEG = -1.0e30f;
 
-template <typename T, bool MASKED>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) T Ks[ATT_KT * ATT_KS];
-  __shared__ __attribute__((aligned(16))) T Vs[ATT_KT * ATT_VS];
-  __shared__ __attribute__((aligned(16))) float bias_s[ATT_KT];
+template <int KC> constexpr int attn_lds_bytes() { return KC * (ATT_KS + ATT_VS) * 2 + KC * 4; }
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <typename T, int KC, bool MASKED>
+__global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char att_smem[];
+  T* Ks = reinterpret_cast<T*>(att_smem);
+  T* Vs = Ks + KC * ATT_KS;
+  float* bias_s = reinterpret_cast<float*>(Vs + KC * ATT_VS);
+
+  constexpr int NF = KC / 16;   // key fragments per chunk
+  constexpr int NS2 = KC / 32;  // 32-key steps for P.V
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 64 + wave * 16;
   const int dh = p.dh;
-  const int nch = dh >> 3;  // 16-byte chunks per head row (9 for dh = 72)
+  const int nch = dh >> 3;            // 16-byte chunks per head row (9 for dh = 72)
+  const int ch_per_tile = KC * nch;   // chunks in the K (or V) tile
+  constexpr int MAXL = (KC * 9 * 2 + 511) / 512;  // staging loads per thread (dh <= 72 -> 9 chunks per row)
 
   const T* Q = reinterpret_cast<const T*>(p.q);
   const T* K = reinterpret_cast<const T*>(p.k);
   const T* V = reinterpret_cast<const T*>(p.v);
   T* O = reinterpret_cast<T*>(p.out);
 
-  // zero both tiles once: pad columns are never overwritten afterwards
-  for (int i = tid; i < ATT_KT * ATT_KS / 8; i += 256) reinterpret_cast<u32x4*>(Ks)[i] = (u32x4){0, 0, 0, 0};
-  for (int i = tid; i < ATT_KT * ATT_VS / 8; i += 256) reinterpret_cast<u32x4*>(Vs)[i] = (u32x4){0, 0, 0, 0};
+  const int nqb = (p.Nq + ATT_QB - 1) / ATT_QB;
+  const int nkc = (p.Nk + KC - 1) / KC;
+  const int items = p.B * p.H * nqb;
 
-  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + l15][32*ks + 8g + j]
-  Pack8 qf[3];
-  {
-    const int qrow = q0 + l15;
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      const int d = 32 * ks + 8 * g;
-      qf[ks].u = (u32x4){0, 0, 0, 0};
-      if (qrow < p.Nq && d + 8 <= dh) qf[ks] = gload16(Q + ((size_t)b * p.Nq + qrow) * p.ldq + (size_t)h * dh + d);
-    }
-  }
+  // zero the tiles once (pad columns stay zero), then the ones column of V (softmax denominator rides the P.V MFMAs)
+  for (int i = tid; i < KC * (ATT_KS + ATT_VS) / 8; i += 512) reinterpret_cast<u32x4*>(att_smem)[i] = (u32x4){0, 0, 0, 0};
+  __syncthreads();
+  for (int i = tid; i < KC; i += 512) Vs[i * ATT_VS + dh] = (T)1.0f;
 
-  // ---- register staging of the K/V tiles: chunk ids tid, tid+256, tid+512 over 64 keys x nch chunks
-  const int total_ch = ATT_KT * nch;
-  Pack8 kreg[3], vreg[3];
-  auto load_tile = [&](int key0) {
+  // ---- register staging of one (item, chunk): ids over [K chunks | V chunks]
+  Pack8 stg[MAXL];
+  auto load_stage = [&](int item, int kc) {
+    const int qb = item % nqb, bh = item / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    (void)qb;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int id = tid + i * 256;
-      kreg[i].u = (u32x4){0, 0, 0, 0};
-      vreg[i].u = (u32x4){0, 0, 0, 0};
-      if (id < total_ch) {
+    for (int i = 0; i < MAXL; ++i) {
+      int id = tid + i * 512;
+      stg[i].u = (u32x4){0, 0, 0, 0};
+      if (id < 2 * ch_per_tile) {
+        const bool isv = id >= ch_per_tile;
+        id = isv ? id - ch_per_tile : id;
         const int key = id / nch, c = id - key * nch;
-        if (key0 + key < p.Nk) {
-          const size_t row = (size_t)b * p.Nk + key0 + key;
-          kreg[i] = gload16(K + row * p.ldk + (size_t)h * dh + c * 8);
-          vreg[i] = gload16(V + row * p.ldv + (size_t)h * dh + c * 8);
+        const int gk = kc * KC + key;
+        if (gk < p.Nk) {
+          const T* base = isv ? V + ((size_t)b * p.Nk + gk) * p.ldv : K + ((size_t)b * p.Nk + gk) * p.ldk;
+          stg[i] = gload16(base + (size_t)h * dh + c * 8);
         }
       }
     }
   };
-  auto store_tile = [&](int key0) {
+  auto store_stage = [&](int item, int kc) {
+    const int bh = item / nqb;
+    const int b = bh / p.H;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int id = tid + i * 256;
-      if (id < total_ch) {
+    for (int i = 0; i < MAXL; ++i) {
+      int id = tid + i * 512;
+      if (id < 2 * ch_per_tile) {
+        const bool isv = id >= ch_per_tile;
+        id = isv ? id - ch_per_tile : id;
         const int key = id / nch, c = id - key * nch;
-        *reinterpret_cast<u32x4*>(Ks + key * ATT_KS + c * 8) = kreg[i].u;
-        *reinterpret_cast<u32x4*>(Vs + key * ATT_VS + c * 8) = vreg[i].u;
+        T* dst = isv ? Vs + key * ATT_VS + c * 8 : Ks + key * ATT_KS + c * 8;
+        *reinterpret_cast<u32x4*>(dst) = stg[i].u;
       }
     }
-    if (MASKED && tid < ATT_KT) {
-      const int key = key0 + tid;
-      float bv = ATT_NEG;
-      if (key < p.Nk) bv = p.bias ? p.bias[(size_t)b * p.Nk + key] * 1.4426950408889634f : 0.f;
-      bias_s[tid] = bv;
+    if (MASKED) {
+      for (int i = tid; i < KC; i += 512) {
+        const int gk = kc * KC + i;
+        float bv = ATT_NEG;
+        if (gk < p.Nk) bv = p.bias ? p.bias[(size_t)b * p.Nk + gk] * 1.4426950408889634f : 0.f;
+        bias_s[i] = bv;
+      }
     }
   };
 
-  f32x4 oacc[5];
-#pragma unroll
-  for (int nd = 0; nd < 5; ++nd) oacc[nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = ATT_NEG, l_run = 0.f;  // running max (log2 units) and this lane's partial row sum
+  int item = blockIdx.x;
+  if (item < items) load_stage(item, 0);
 
-  const int ntiles = (p.Nk + ATT_KT - 1) / ATT_KT;
-  load_tile(0);
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();  // everyone finished reading tile t-1 (and the zero fill on t = 0)
-    store_tile(t * ATT_KT);
-    __syncthreads();
-    if (t + 1 < ntiles) load_tile((t + 1) * ATT_KT);
+  for (; item < items; item += gridDim.x) {
+    const int qb = item % nqb, bh = item / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    f32x4 oacc[2][5];
+    float m_run[2] = {ATT_NEG, ATT_NEG};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int nd = 0; nd < 5; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- S^T tile: 4 key fragments x 16 queries
-    f32x4 s[4];
+    for (int kc = 0; kc < nkc; ++kc) {
+      __syncthreads();  // every wave finished reading the previous chunk
+      store_stage(item, kc);
+      __syncthreads();
+      // prefetch the next chunk (or the next item's first chunk) while this one is consumed
+      if (kc + 1 < nkc) load_stage(item, kc + 1);
+      else if (item + (int)gridDim.x < items) load_stage(item + gridDim.x, 0);
+
+      // two rounds of 16 query rows per wave, kept strictly sequential (sched_barrier) so only one S strip is live
+      auto round = [&](const int r, f32x4 (&oa)[5], float& m_r) {
+        const int qrow = qb * ATT_QB + r * 128 + wave * 16 + l15;
+        // Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][32*ks + 8g + j]
+        Pack8 qf[3];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 3; ++ks) {
+          const int d = 32 * ks + 8 * g;
+          qf[ks].u = (u32x4){0, 0, 0, 0};
+          if (qrow < p.Nq && d + 8 <= dh) qf[ks] = gload16(Q + ((size_t)b * p.Nq + qrow) * p.ldq + (size_t)h * dh + d);
+        }
+        // ---- S^T strip: NF key fragments x 16 queries, all in registers
+        f32x4 s[NF];
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        Pack8 kf = lds_read16(Ks + (16 * f + l15) * ATT_KS + 32 * ks + 8 * g);
-        s[f] = mfma16<T>(kf, qf[ks], s[f]);
-      }
+        for (int f = 0; f < NF; ++f) {
+          s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) {
+            Pack8 kf = lds_read16(Ks + (16 * f + l15) * ATT_KS + 32 * ks + 8 * g);
+            s[f] = mfma16<T>(kf, qf[ks], s[f]);
+          }
+        }
+        float mt = ATT_NEG;
+        if (MASKED) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + 16 * f + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s[f][e] = s[f][e] * p.scale_log2e + bv[e];
+              mt = fmaxf(mt, s[f][e]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[f][e]);
+          mt *= p.scale_log2e;  // scale > 0: max commutes with it
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_r, mt);
+        const float alpha = exp2f(m_r - m_new);
+        m_r = m_new;
+#pragma unroll
+        for (int nd = 0; nd < 5; ++nd)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) oa[nd][e] *= alpha;
+
+        // ---- O^T += V^T P^T.  k slot (g, j) of 32-key step s2 <-> key 32*s2 + (j < 4 ? 4g + j : 16 + 4g + j - 4)
+#pragma unroll
+        for (int s2 = 0; s2 < NS2; ++s2) {
+          Pack8 pf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float p0, p1;
+            if (MASKED) {
+              p0 = exp2f(s[2 * s2][e] - m_new);
+              p1 = exp2f(s[2 * s2 + 1][e] - m_new);
+            } else {
+              p0 = exp2f(s[2 * s2][e] * p.scale_log2e - m_new);
+              p1 = exp2f(s[2 * s2 + 1][e] * p.scale_log2e - m_new);
+            }
+            float_to_elem<T>(pf, e, p0);
+            float_to_elem<T>(pf, 4 + e, p1);
+          }
+          const int krow = 32 * s2 + 4 * g + (l15 >> 2);
+          const int dcol = 4 * (l15 & 3);
+#pragma unroll
+          for (int nd = 0; nd < 5; ++nd) {
+            Pack4 lo = lds_read_tr16(Vs + krow * ATT_VS + 16 * nd + dcol);
+            Pack4 hi = lds_read_tr16(Vs + (krow + 16) * ATT_VS + 16 * nd + dcol);
+            Pack8 vf;
+            vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
+            oa[nd] = mfma16<T>(vf, pf, oa[nd]);
+          }
+        }
+      };
+      round(0, oacc[0], m_run[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      round(1, oacc[1], m_run[1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    float mt = ATT_NEG;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (MASKED) bv = *reinterpret_cast<const f32x4*>(bias_s + 16 * f + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[f][r] = s[f][r] * p.scale_log2e + bv[r];
-        mt = fmaxf(mt, s[f][r]);
-      }
-    }
-    mt = fmaxf(mt, __shfl_xor(mt, 16));
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[f][r] = exp2f(s[f][r] - m_new);
-        psum += s[f][r];
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int nd = 0; nd < 5; ++nd)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[nd][r] *= alpha;
 
-    // ---- O^T += V^T P^T.  k slot (g, j) of 32-key step s2 <-> key 32*s2 + (j < 4 ? 4g + j : 16 + 4g + j - 4)
+    // ---- finish the item: denominator = O^T row dh (ones column), normalise, store 4 consecutive d per lane
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      Pack8 pf;
+    for (int r = 0; r < 2; ++r) {
+      const int dl = dh & 15;  // column dh sits in d-fragment dh/16 at (g = dl/4, e = dl%4)
+      float den = 1.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float_to_elem<T>(pf, r, s[2 * s2][r]);
-        float_to_elem<T>(pf, 4 + r, s[2 * s2 + 1][r]);
-      }
-      const int krow = 32 * s2 + 4 * g + (l15 >> 2);
-      const int dcol = 4 * (l15 & 3);
+      for (int nd = 0; nd < 5; ++nd)
 #pragma unroll
-      for (int nd = 0; nd < 5; ++nd) {
-        Pack4 lo = lds_read_tr16(Vs + krow * ATT_VS + 16 * nd + dcol);
-        Pack4 hi = lds_read_tr16(Vs + (krow + 16) * ATT_VS + 16 * nd + dcol);
-        Pack8 vf;
-        vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
-        oacc[nd] = mfma16<T>(vf, pf, oacc[nd]);
-      }
-    }
-  }
-
-  // ---- finish: total row sum across the 4 lane groups, normalise, store 4 consecutive d per lane
-  l_run += __shfl_xor(l_run, 16);
-  l_run += __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_run;
-  const int qrow = q0 + l15;
-  if (qrow < p.Nq) {
-    T* orow = O + ((size_t)b * p.Nq + qrow) * p.ldo + (size_t)h * dh;
+        for (int e = 0; e < 4; ++e)
+          if (nd == (dh >> 4) && e == (dl & 3)) den = oacc[r][nd][e];  // static indices only: no scratch
+      den = __shfl(den, l15 + 16 * (dl >> 2));  // valid on the lanes with g == dl / 4
+      const float inv = 1.0f / den;
+      const int qrow = qb * ATT_QB + r * 128 + wave * 16 + l15;
+      if (qrow < p.Nq) {
+        T* orow = O + ((size_t)b * p.Nq + qrow) * p.ldo + (size_t)h * dh;
 #pragma unroll
-    for (int nd = 0; nd < 5; ++nd) {
-      const int d = 16 * nd + 4 * g;
-      if (d + 4 <= dh) {
-        Pack4 o;
+        for (int nd = 0; nd < 5; ++nd) {
+          const int d = 16 * nd + 4 * g;
+          if (d + 4 <= dh) {
+            Pack4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) float_to_elem4<T>(o, r, oacc[nd][r] * inv);
-        *reinterpret_cast<u32x2*>(orow + d) = o.u;
+            for (int e = 0; e < 4; ++e) float_to_elem4<T>(o, e, oacc[r][nd][e] * inv);
+            *reinterpret_cast<u32x2*>(orow + d) = o.u;
+          }
+        }
       }
     }
   }

@@ -181,7 +181,7 @@ template <typename T> class EngineT : public EngineBase {
     L = cfg.num_layers; NH = cfg.num_heads; DH = cfg.head_dim; D = NH * DH;
     CIN = cfg.in_channels; COUT = cfg.out_channels; P = cfg.patch_size; CAP = cfg.caption_channels;
     if (D % 128 != 0 || D % 64 != 0) return fail(ECAD_E_UNSUPPORTED, "inner dim %d must be a multiple of 128", D);
-    if (DH % 8 != 0 || DH > 80) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported (need %%8 == 0 and <= 80)", DH);
+    if (DH % 8 != 0 || DH > 72) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported (need %%8 == 0 and <= 72)", DH);
     if (CIN != 4 || P != 2) return fail(ECAD_E_UNSUPPORTED, "patch embed supports in_channels 4, patch 2");
     if (P * P * COUT > PROJ_PAD) return fail(ECAD_E_UNSUPPORTED, "proj_out too wide");
     if (CAP % 64 != 0) return fail(ECAD_E_UNSUPPORTED, "caption_channels must be a multiple of 64");
@@ -466,7 +466,7 @@ template <typename T> class EngineT : public EngineBase {
       if (ex[0]) {
         emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride);
         ops.push_back(mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D));
-        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % ATT_KT) != 0;
+        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0;
         a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = 4.0 * Bt * (double)NH * N * (double)N * DH; a.bytes = 4.0 * M * (double)D * sizeof(T);
@@ -656,10 +656,22 @@ template <typename T> class EngineT : public EngineBase {
     }
     return ECAD_OK;
   }
-  void launch_attn(const AttnArgs& a, bool masked, hipStream_t s) {
-    dim3 grid((a.Nq + 63) / 64, a.H, a.B);
-    if (masked) hipLaunchKernelGGL((attn_kernel<T, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<T, false>), grid, dim3(256), 0, s, a);
+  bool attn_attr[3] = {};
+  template <int KC, bool MASKED> int launch_attn_t(const AttnArgs& a, int slot, int wg_per_cu, hipStream_t s) {
+    constexpr int lds = attn_lds_bytes<KC>();
+    if (!attn_attr[slot]) {
+      HIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, KC, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attn_attr[slot] = true;
+    }
+    const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
+    const int cap = num_cus * wg_per_cu;
+    hipLaunchKernelGGL((attn_kernel<T, KC, MASKED>), dim3(items < cap ? items : cap), dim3(512), lds, s, a);
+    return ECAD_OK;
+  }
+  int launch_attn(const AttnArgs& a, bool masked, hipStream_t s) {
+    // KC = 128 keys per LDS chunk for both kinds (a 256-key strip in registers spills: 64 score + 36 staging VGPRs)
+    if (masked || a.Nk % 128) return launch_attn_t<128, true>(a, 0, 1, s);
+    return launch_attn_t<128, false>(a, 1, 1, s);
   }
   int launch_ln(const FlushArgs& f, hipStream_t s) {
     const int cpr = f.D / 8;
@@ -681,7 +693,7 @@ template <typename T> class EngineT : public EngineBase {
     const int M = Bt * N;
     switch (o.kind) {
       case Op<T>::GEMM: return launch_gemm(o.epi, o.cls, o.g, s);
-      case Op<T>::ATTN: launch_attn(o.a, o.attn_masked, s); break;
+      case Op<T>::ATTN: return launch_attn(o.a, o.attn_masked, s);
       case Op<T>::LN: return launch_ln(o.f, s);
       case Op<T>::REPLAY: launch_replay(o.f, s); break;
       case Op<T>::PATCH: {
@@ -880,11 +892,12 @@ template <typename T> class EngineT : public EngineBase {
   int op_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk,
                    int dh, const float* bias, hipStream_t s) override {
     HIPCHK(hipSetDevice(dev));
-    if (dh % 8 || dh > 80) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported", dh);
+    if (dh % 8 || dh > 72) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported", dh);
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.out = out; a.bias = bias; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh;
     a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)dh));
-    launch_attn(a, bias != nullptr || (Nk % ATT_KT) != 0, s);
+    int rc = launch_attn(a, bias != nullptr, s);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     return ECAD_OK;
   }

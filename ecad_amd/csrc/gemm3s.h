@@ -35,7 +35,8 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const T* a_src[A_INST];

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GemmArgs<T> p) {
     const T* b_src[5];
     int it_tile = sched.first, it_kt = 0;
     auto set_tile = [&](int tile) {
-      const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+      int tm, tn;
+      tile_coords(tile, tiles_m, tiles_n, tm, tn);
       const int m0 = tm * PG_BM, n0 = tn * PG_BN;
 #pragma unroll
       for (int i = 0; i < A_INST; ++i) {
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GemmArgs<T> p) {
   constexpr int FM = 4, FN = 9;
   int stage = 0;
   for (int tile = sched.first; tile < sched.end; tile += sched.stride) {
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_coords(tile, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * PG_BM, n0 = tn * PG_BN;
     f32x4 acc[FM][FN];
 #pragma unroll

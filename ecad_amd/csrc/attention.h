@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
         mt = fmaxf(mt, __shfl_xor(mt, 16));
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_r, mt);
-        const float alpha = exp2f(m_r - m_new);
+        const float alpha = fast_exp2(m_r - m_new);
         m_r = m_new;
 #pragma unroll
         for (int nd = 0; nd < 5; ++nd)
@@ -196,11 +196,11 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
           for (int e = 0; e < 4; ++e) {
             float p0, p1;
             if (MASKED) {
-              p0 = exp2f(s[2 * s2][e] - m_new);
-              p1 = exp2f(s[2 * s2 + 1][e] - m_new);
+              p0 = fast_exp2(s[2 * s2][e] - m_new);
+              p1 = fast_exp2(s[2 * s2 + 1][e] - m_new);
             } else {
-              p0 = exp2f(s[2 * s2][e] * p.scale_log2e - m_new);
-              p1 = exp2f(s[2 * s2 + 1][e] * p.scale_log2e - m_new);
+              p0 = fast_exp2(s[2 * s2][e] * p.scale_log2e - m_new);
+              p1 = fast_exp2(s[2 * s2 + 1][e] * p.scale_log2e - m_new);
             }
             float_to_elem<T>(pf, e, p0);
             float_to_elem<T>(pf, 4 + e, p1);

@@ -417,6 +417,9 @@ template <typename T> class EngineT : public EngineBase {
   }
 
   struct Pending { const T* cache; const float* gate_table; const T* gate_mod; };
+  // A cache slot written at step s is dead when the same component executes again at step s+1 (or s is the last
+  // step): nothing reads it before it is overwritten / dropped.  30 % of ours_fast's writes are dead.
+  bool cache_write_live(int s, int b, int c) const { return s + 1 < steps && !executed[((size_t)(s + 1) * L + b) * 3 + c]; }
 
   void emit_ln(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, const float* tsh, const float* tsc, const T* msh, const T* msc, int64_t ln_stride, int64_t mstride) {
     if (pend.size() > 6) emit_replay(ops, pend, M, mstride);
@@ -471,8 +474,8 @@ template <typename T> class EngineT : public EngineBase {
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = 4.0 * Bt * (double)NH * N * (double)N * DH; a.bytes = 4.0 * M * (double)D * sizeof(T);
         ops.push_back(a);
-        ops.push_back(mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, c0, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
-        st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        ops.push_back(mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, cache_write_live(s, b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
+        if (cache_write_live(s, b, 0)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 4ll * M * D * D; st.linear_macs_executed += 4ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)N * D;
       } else {
         pend.push_back(Pending{c0, B.sst + 2 * D, mod_s + 2 * D});
@@ -487,8 +490,8 @@ template <typename T> class EngineT : public EngineBase {
         a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = 4.0 * Bt * (double)NH * N * (double)Tt * DH; a.bytes = (2.0 * M + 2.0 * Mt) * D * sizeof(T);
         ops.push_back(a);
-        ops.push_back(mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, c1, M, D, nullptr, nullptr, 0));
-        st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        ops.push_back(mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, cache_write_live(s, b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
+        if (cache_write_live(s, b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
       } else {
         pend.push_back(Pending{c1, nullptr, nullptr});
@@ -497,8 +500,8 @@ template <typename T> class EngineT : public EngineBase {
       if (ex[2]) {
         emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride);
         ops.push_back(mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D));
-        ops.push_back(mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, c2, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
-        st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        ops.push_back(mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, cache_write_live(s, b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
+        if (cache_write_live(s, b, 2)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 8ll * M * D * D; st.linear_macs_executed += 8ll * M * D * D;
       } else {
         pend.push_back(Pending{c2, B.sst + 5 * D, mod_s + 5 * D});

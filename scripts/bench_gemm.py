@@ -17,6 +17,7 @@ SHAPES = [  # (name, M, N, K, epi)
     ("out1", 8192, 1152, 1152, 3),
     ("q2", 8192, 1152, 1152, 0),
     ("ff1", 8192, 4608, 1152, 1),
+    ("ff1nogelu", 8192, 4608, 1152, 0),
     ("ff2", 8192, 1152, 4608, 3),
     ("textkv", 3840, 64512, 1152, 0),
 ]

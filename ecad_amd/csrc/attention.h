@@ -130,6 +130,19 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int nd = 0; nd < 5; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Q fragments of both rounds (B operand of S^T = K Q^T): lane holds Q[qrow][32*ks + 8g + j]; issued before the
+    // staging barriers so their latency hides behind the LDS fill
+    Pack8 qfr[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int qrow = qb * ATT_QB + r * 128 + wave * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int d = 32 * ks + 8 * g;
+        qfr[r][ks].u = (u32x4){0, 0, 0, 0};
+        if (qrow < p.Nq && d + 8 <= dh) qfr[r][ks] = gload16(Q + ((size_t)b * p.Nq + qrow) * p.ldq + (size_t)h * dh + d);
+      }
+    }
     for (int kc = 0; kc < nkc; ++kc) {
       __syncthreads();  // every wave finished reading the previous chunk
       store_stage(item, kc);
@@ -138,17 +151,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
       if (kc + 1 < nkc) load_stage(item, kc + 1);
       else if (item + (int)gridDim.x < items) load_stage(item + gridDim.x, 0);
 
-      // two rounds of 16 query rows per wave, kept strictly sequential (sched_barrier) so only one S strip is live
-      auto round = [&](const int r, f32x4 (&oa)[5], float& m_r) {
-        const int qrow = qb * ATT_QB + r * 128 + wave * 16 + l15;
-        // Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][32*ks + 8g + j]
-        Pack8 qf[3];
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-          const int d = 32 * ks + 8 * g;
-          qf[ks].u = (u32x4){0, 0, 0, 0};
-          if (qrow < p.Nq && d + 8 <= dh) qf[ks] = gload16(Q + ((size_t)b * p.Nq + qrow) * p.ldq + (size_t)h * dh + d);
-        }
+      auto round = [&](const Pack8 (&qf)[3], f32x4 (&oa)[5], float& m_r) {
         // ---- S^T strip: NF key fragments x 16 queries, all in registers
         f32x4 s[NF];
 #pragma unroll
@@ -217,9 +220,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
           }
         }
       };
-      round(0, oacc[0], m_run[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      round(1, oacc[1], m_run[1]);
+      round(qfr[0], oacc[0], m_run[0]);
+      __builtin_amdgcn_sched_barrier(0);  // rounds strictly sequential: interleaving them spills (2 S strips + staging)
+      round(qfr[1], oacc[1], m_run[1]);
       __builtin_amdgcn_sched_barrier(0);
     }
 

@@ -1,0 +1,49 @@
+"""Sharded evaluation of one NSGA-II generation: candidates split in contiguous blocks across ranks (72 over 8 GPUs = 9
+per GPU), each rank generates its candidates' images with its own engine, scores them locally and contributes two
+float64 per candidate to one all-gather.  Replaces the three serial subprocesses of
+``ecad/genetic/train_nsga2_single_gpu.py:198-224`` (generate_images / score_images / compute_macs).
+
+ImageReward (``ecad/benchmark/score_images.py``) is a third-party model that is absent here, so the quality
+objective is a labelled STAND-IN: negative relative L2 distance of the final latents to the uncached (all-true
+schedule) run with identical seeds.  The MAC objective is exact (closed form).
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+
+from ecad_amd import distributed as D
+from ecad_amd.benchmark.compute_macs import total_macs_T
+
+
+def latent_fidelity_score(latents, reference_latents) -> float:
+    """Stand-in quality score in (-inf, 0]: 0 == identical to the uncached run."""
+    import torch
+
+    return -float((latents.float() - reference_latents.float()).norm() / reference_latents.float().norm().clamp_min(1e-12))
+
+
+def evaluate_population(X: np.ndarray, score_fn: Callable[[int, np.ndarray], float], steps: int = 20, blocks: int = 28) -> np.ndarray:
+    """F[pop, 2] = [1 - score, TMACs] for the whole population, computed cooperatively by all ranks."""
+    rank, world = D._world()
+    n = len(X)
+    mine = D.shard_range(n, world, rank)
+    local = np.zeros((len(mine), 2), dtype=np.float64)
+    for k, c in enumerate(mine):
+        bits = np.asarray(X[c], dtype=np.bool_).reshape(steps, blocks, 3)
+        local[k] = [1.0 - score_fn(c, bits), total_macs_T(bits)]
+    return D.gather_fitness(local, n)
+
+
+def engine_score_fn(engine, enc, mask, latents, timesteps, coefs, guidance: float = 4.5):
+    """score_fn over a fixed prompt/latent batch on this rank's engine (reference latents from the all-true schedule)."""
+    steps = len(timesteps)
+    engine.set_schedule(np.ones((steps, engine.cfg.num_layers, 3), dtype=np.uint8))
+    ref = engine.run_schedule(enc, mask, latents, timesteps, coefs, guidance)
+
+    def score(_idx: int, bits: np.ndarray) -> float:
+        engine.set_schedule(bits)
+        return latent_fidelity_score(engine.run_schedule(enc, mask, latents, timesteps, coefs, guidance), ref)
+
+    return score

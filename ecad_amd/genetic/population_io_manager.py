@@ -1,0 +1,166 @@
+"""On-disk population bookkeeping for the NSGA-II search (file contracts of the reference:
+``ecad/genetic/population_io_manager.py:24-400`` and ``pixart_population_io_manager.py:28-240``).
+
+    <populations>/<name>/gen_XXX/candidates/cand_YYY.json      schedule JSON (+ metrics.total_macs_T)
+    <benchmarks>/<name>/gen_XXX/candidates/cand_YYY/scores.json {"total_score": float}
+    <populations>/<name>/gen_XXX/manager_config.json
+
+F = [1 - score, TMACs] (``load_evaluation_scores`` :246-273), G = min_diff - hamming(x, default) (:216-225).
+"""
+from __future__ import annotations
+
+import json
+import re
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+
+from ecad_amd.benchmark.compute_macs import total_macs_T
+from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
+
+
+class PixArtPopulationIOManager:
+    CONFIG_FILENAME = "manager_config.json"
+    SCORE_KEY = "total_score"
+    METRIC_KEY = "total_macs_T"
+
+    def __init__(self, name: str, all_populations_dir: Path, all_benchmarks_dir: Path, generation_num: int | None = None,
+                 num_inference_steps: int = 20, min_diff_from_default: int = 1, population_size: int = 72, num_blocks: int = 28,
+                 num_component_types: int = 3, maximize_macs: bool = False, candidate_config: dict | None = None):
+        self.name = name
+        self.population_dir = Path(all_populations_dir) / name
+        self.benchmark_dir = Path(all_benchmarks_dir) / name
+        self.population_dir.mkdir(parents=True, exist_ok=True)
+        self.benchmark_dir.mkdir(parents=True, exist_ok=True)
+        if generation_num is None:
+            gens = [int(p.name.split("_")[1]) for p in self.population_dir.iterdir() if p.is_dir() and re.fullmatch(r"gen_\d+", p.name)]
+            generation_num = max(gens) if gens else 1
+        self.generation_num = generation_num
+        self.num_inference_steps = num_inference_steps
+        self.min_diff_from_default = min_diff_from_default
+        self.population_size = population_size
+        self.num_blocks = num_blocks
+        self.num_component_types = num_component_types
+        self.maximize_macs = maximize_macs
+        self.candidate_config: dict[str, Any] = candidate_config or {}
+        self.default_bits = np.ones(num_inference_steps * num_blocks * num_component_types, dtype=np.bool_)
+
+    # -- paths ------------------------------------------------------------------------------
+    def _gen_dir(self, generation: int | None = None) -> Path:
+        g = self.generation_num if generation is None else generation
+        d = self.population_dir / f"gen_{g:03d}"
+        d.mkdir(parents=True, exist_ok=True)
+        return d
+
+    def get_pop_candidates_dir(self, generation: int | None = None) -> Path:
+        d = self._gen_dir(generation) / "candidates"
+        d.mkdir(parents=True, exist_ok=True)
+        return d
+
+    def get_benchmark_gen_dir(self, generation: int | None = None) -> Path:
+        g = self.generation_num if generation is None else generation
+        return self.benchmark_dir / f"gen_{g:03d}/candidates"
+
+    # -- config -----------------------------------------------------------------------------
+    def to_dict(self) -> dict[str, Any]:
+        return {
+            "name": self.name, "population_dir": str(self.population_dir), "benchmark_dir": str(self.benchmark_dir),
+            "generation_num": self.generation_num, "num_inference_steps": self.num_inference_steps,
+            "min_diff_from_default": self.min_diff_from_default, "population_size": self.population_size,
+            "num_blocks": self.num_blocks, "num_component_types": self.num_component_types,
+        }
+
+    def to_json(self, file_path: Path | None = None) -> None:
+        file_path = file_path or self._gen_dir() / self.CONFIG_FILENAME
+        with open(file_path, "w") as f:
+            json.dump(self.to_dict(), f, indent=4)
+
+    @classmethod
+    def from_json(cls, file_path: Path) -> "PixArtPopulationIOManager":
+        with open(file_path) as f:
+            c = json.load(f)
+        kw = {k: c[k] for k in ("generation_num", "num_inference_steps", "num_blocks", "num_component_types", "min_diff_from_default", "population_size") if k in c}
+        return cls(c["name"], Path(c["population_dir"]).parent, Path(c["benchmark_dir"]).parent, **kw)
+
+    # -- population <-> files -----------------------------------------------------------------
+    @staticmethod
+    def binary_vector_to_schedule_dict(x: np.ndarray, num_inference_steps: int, num_blocks: int, num_component_types: int) -> dict:
+        return PixArtCacheSchedule.from_numpy(x, num_blocks=num_blocks, num_inference_steps=num_inference_steps).schedule
+
+    def compute_additional_info(self, schedule: dict) -> dict[str, Any]:
+        bits = PixArtCacheSchedule(self.num_blocks, self.num_inference_steps, "tmp", schedule).to_numpy()
+        changed = ~bits.all(axis=2)  # [steps, blocks]: any component differs from the all-true default
+        return {"num_affected_steps": int(changed.any(axis=1).sum()), "num_affected_blocks": int(changed.any(axis=0).sum()),
+                "total_num_affected_blocks": int(changed.sum())}
+
+    def save_population(self, population: np.ndarray, generation: int | None = None) -> None:
+        g = self.generation_num if generation is None else generation
+        for i, x in enumerate(np.asarray(population, dtype=np.bool_)):
+            sd = self.binary_vector_to_schedule_dict(x, self.num_inference_steps, self.num_blocks, self.num_component_types)
+            sched = PixArtCacheSchedule(self.num_blocks, self.num_inference_steps, f"{self.name}_gen_{g:03d}_cand_{i:03d}", sd,
+                                        attributes=self.compute_additional_info(sd), top_level_config=self.candidate_config)
+            sched.to_json(self.get_pop_candidates_dir(g) / f"cand_{i:03d}.json")
+
+    def load_population_schedules(self, generation: int | None = None) -> list[tuple[int, PixArtCacheSchedule]]:
+        out = []
+        for fp in self.get_pop_candidates_dir(generation).glob("cand_*.json"):
+            out.append((int(fp.stem.split("_")[-1]), PixArtCacheSchedule.from_json(fp)))
+        return sorted(out, key=lambda t: t[0])
+
+    def load_population_vectors(self, generation: int | None = None) -> np.ndarray:
+        return np.array([s.to_numpy(flatten=True) for _, s in self.load_population_schedules(generation)])
+
+    def get_constraint_violations(self, population: np.ndarray) -> np.ndarray:
+        diff = np.sum(np.asarray(population, dtype=np.bool_) != self.default_bits[None], axis=1)
+        return (self.min_diff_from_default - diff).reshape(-1, 1)
+
+    # -- evaluation results -------------------------------------------------------------------
+    def write_evaluation(self, index: int, score: float, bits: np.ndarray, generation: int | None = None) -> None:
+        """In-process evaluation writes what score_images.py / compute_macs.py would have written."""
+        d = self.get_benchmark_gen_dir(generation) / f"cand_{index:03d}"
+        d.mkdir(parents=True, exist_ok=True)
+        with open(d / "scores.json", "w") as f:
+            json.dump({self.SCORE_KEY: float(score)}, f)
+        fp = self.get_pop_candidates_dir(generation) / f"cand_{index:03d}.json"
+        with open(fp) as f:
+            data = json.load(f)
+        data.setdefault("metrics", {})[self.METRIC_KEY] = total_macs_T(np.asarray(bits).reshape(self.num_inference_steps, self.num_blocks, 3))
+        with open(fp, "w") as f:
+            json.dump(data, f, indent=4)
+
+    def check_offline_eval(self) -> bool:
+        cand_dirs = [d for d in self.get_benchmark_gen_dir().glob("cand_*/") if d.is_dir()]
+        if any(not list(d.glob("scores*.json")) for d in cand_dirs):
+            return False
+        jsons = list(self.get_pop_candidates_dir().glob("cand_*.json"))
+        if not jsons or len(cand_dirs) != len(jsons):
+            return False
+        for fp in jsons:
+            with open(fp) as f:
+                m = json.load(f).get("metrics", {})
+            if self.METRIC_KEY not in m and "total_macs" not in m:
+                return False
+        return True
+
+    def load_evaluation_scores(self, generation: int | None = None) -> np.ndarray:
+        scores, metrics = {}, {}
+        for d in self.get_benchmark_gen_dir(generation).glob("cand_*"):
+            js = sorted(d.glob("scores*.json"))
+            if d.is_dir() and js:
+                with open(js[0]) as f:
+                    scores[int(d.name.split("_")[1])] = 1.0 - json.load(f)[self.SCORE_KEY]
+        for fp in self.get_pop_candidates_dir(generation).glob("cand_*.json"):
+            with open(fp) as f:
+                m = json.load(f)["metrics"]
+            metrics[int(fp.stem.split("_")[1])] = m[self.METRIC_KEY] if self.METRIC_KEY in m else m["total_macs"] / 1000**4
+        if scores.keys() != metrics.keys():
+            raise ValueError(f"candidate indices in scores and metrics do not match: {sorted(scores)} vs {sorted(metrics)}")
+        F = np.zeros((len(scores), 2))
+        for i in scores:
+            F[i] = [scores[i], -metrics[i] if self.maximize_macs else metrics[i]]
+        return F
+
+    def ask(self):
+        X = self.load_population_vectors()
+        return X, self.load_evaluation_scores(), self.get_constraint_violations(X)

@@ -1,0 +1,86 @@
+"""-m gpu: the reference-shaped host surface end to end (image generator -> pipeline -> engine), on synthetic
+embedding files in the reference's ``.pt`` format."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+FAST = ROOT / "schedules/schedules_in_paper/pixart_alpha_256/ours_fast.json"
+
+
+@pytest.fixture(scope="module")
+def embedding_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("emb")
+    g = torch.Generator().manual_seed(0)
+    neg = torch.randn(1, 120, 4096, generator=g) * 0.1
+    for i in range(4):
+        n = int(torch.randint(8, 121, (1,), generator=g))
+        mask = torch.zeros(1, 120, dtype=torch.int64)
+        mask[:, :n] = 1
+        neg_mask = torch.zeros(1, 120, dtype=torch.int64)
+        neg_mask[:, :2] = 1
+        torch.save({"prompt_embeds": torch.randn(1, 120, 4096, generator=g) * 0.1, "prompt_attention_mask": mask,
+                    "negative_prompt_embeds": neg.clone(), "negative_prompt_attention_mask": neg_mask}, d / f"{i:03}__prompt_id:{i}.pt")
+    return d
+
+
+def test_generator_surface_and_both_loops_agree(embedding_dir, tmp_path, capsys):
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+
+    gen = get_image_generator_type("PixArtAlphaImageGenerator")(start_seed=7, seed_step=3, schedule_path=FAST, max_batch=8)
+    assert gen.num_inference_steps == 20 and gen.cache_schedule.name.startswith("handcrafted")
+    assert gen.callbacks[-1] == gen._reset_schedules_callback  # reset MUST be last (image_generator.py:153-159)
+    gen.create_diffusion_pipeline()
+    batch = next(iter(gen.load_and_batch_embeddings(embedding_dir, 4)))
+    a = gen.generate_images(batch, images_per_prompt=1, output_type="latent")  # whole loop in one graph replay
+    assert gen.cache_schedule.curr_step == 0 and gen.dit_scheduler.curr_step == 0  # counters reset after step 19
+    gen.diffusion_pipeline.native_loop = False  # per-step path: 20 x ecad_step, solver in torch
+    b = gen.generate_images(batch, images_per_prompt=1, output_type="latent")
+    assert gen.cache_schedule.curr_step == 0
+    la, lb = torch.stack([x[0] for x in a]).float(), torch.stack([x[0] for x in b]).float()
+    rel = float((la - lb).norm() / lb.norm())
+    print(f"native loop vs per-step loop rel-L2: {rel:.2e}")
+    assert torch.isfinite(la).all() and rel < 5e-3  # same arithmetic up to where fp16 rounding is applied in the solver
+    # PNG path + reference file naming
+    gen.diffusion_pipeline.native_loop = True
+    gen.generate_from_saved_prompts(embedding_dir, tmp_path / "out", batch_size=2, images_per_prompt=2)
+    names = sorted(p.name for p in (tmp_path / "out").glob("*.png"))
+    assert len(names) == 8 and names[0] == "000__prompt_id:0__image_seed:007.png" and names[1] == "000__prompt_id:0__image_seed:010.png"
+
+
+def test_compute_latency_writes_metrics(embedding_dir, tmp_path):
+    from ecad_amd.benchmark.compute_latency import time_for_schedule
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+
+    sched = tmp_path / "ours_fast.json"
+    data = json.load(open(FAST))
+    data["metrics"].pop("latency", None)
+    json.dump(data, open(sched, "w"))
+    out = time_for_schedule(get_image_generator_type("PixArtAlphaImageGenerator"), sched, embedding_dir, batch_size=4, warmup_steps=1, num_samples=2,
+                            seed=0, recompute_existing=False)
+    lat = json.load(open(sched))["metrics"]["latency"]
+    assert lat["batch_size"] == 4 and len(lat["latencies"]) == 2 and len(lat["warmups"]) == 1 and lat["avg"] == out["avg"] > 0
+    assert time_for_schedule(get_image_generator_type("PixArtAlphaImageGenerator"), sched, embedding_dir, 4, 1, 2, 0, False) is None  # skip existing
+
+
+def test_bad_schedules_raise(tmp_path):
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+    from ecad_amd.engine import EcadEngine
+
+    data = json.load(open(FAST))
+    data["cache_schedule"]["schedule"]["003"]["5"]["custom_compute_attn"] = {"name": "compute_attn_tgate", "kwargs": {"gate_step": 8}}
+    p = tmp_path / "tgate.json"
+    json.dump(data, open(p, "w"))
+    gen = get_image_generator_type("PixArtAlphaImageGenerator")(schedule_path=p, max_batch=2)
+    with pytest.raises(ValueError, match="custom_compute"):
+        gen.create_diffusion_pipeline()
+    eng = EcadEngine(num_layers=2, max_batch=2)
+    with pytest.raises(ValueError, match="blocks"):
+        eng.set_schedule(np.ones((20, 28, 3), dtype=bool))
+    with pytest.raises(RuntimeError, match="never loaded"):
+        eng.load_state_dict({})

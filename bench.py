@@ -222,6 +222,10 @@ def main():
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             all_ms = sum(v["ms"] for v in gemms.values())
             all_fl = sum(v["flops"] for v in gemms.values())
+            traffic = None
+            pmc = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
+            if pmc:  # HBM bytes per launch from the latest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                traffic = json.load(open(pmc[-1])).get(dom, {}).get("hbm_bytes_per_launch")
             res["roofline"] = {
                 "bound": "mfma",
                 "kernel": dom,
@@ -229,7 +233,8 @@ def main():
                 "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                 "flops_per_launch": d["flops"] / d["launches"],
                 "avg_launch_ms": d["ms"] / d["launches"],
                 "launches_measured": d["launches"],

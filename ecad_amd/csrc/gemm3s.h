@@ -84,6 +84,24 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   const int nk = p.K / GEMM_BK;
   issue(0);
   if (nk > 1) issue(1);
+  // EPI_BIAS_CACHE_RESID: the hidden-state chunks this lane updates in the epilogue are fetched NOW, so their HBM
+  // latency hides behind the whole K loop instead of sitting at the tail of a 1-tile-per-CU kernel
+  constexpr int CPR = BN / 8;
+  constexpr int CHUNKS = WTM * CPR;
+  constexpr int NCH = (CHUNKS + 63) / 64;
+  Pack8 hpre[EPI == EPI_BIAS_CACHE_RESID ? NCH : 1];
+#ifndef G3_NO_RESID_PREFETCH
+  if (EPI == EPI_BIAS_CACHE_RESID) {
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int id = lane + it * 64;
+      const int rl = id / CPR, cchunk = id - rl * CPR;
+      const int m = m0 + wave * WTM + rl;
+      hpre[it].u = (u32x4){0, 0, 0, 0};
+      if (id < CHUNKS && m < p.M) hpre[it] = gload16(p.resid + (size_t)m * p.ldr + n0 + cchunk * 8);
+    }
+  }
+#endif
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A_INST(4) + 2: oldest stage retired for every wave
@@ -133,19 +151,23 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  constexpr int CPR = BN / 8;
-  constexpr int CHUNKS = WTM * CPR;
-  for (int id = lane; id < CHUNKS; id += 64) {
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int id = lane + it * 64;
     const int rl = id / CPR, cchunk = id - rl * CPR;
     const int ml = wave * WTM + rl;
     const int m = m0 + ml;
-    if (m >= p.M) continue;
+    if (id >= CHUNKS || m >= p.M) continue;
     const int n = n0 + cchunk * 8;
     Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
     if (EPI == EPI_BIAS_CACHE_RESID) {
       if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);
       T* rp = p.resid + (size_t)m * p.ldr + n;
+#ifdef G3_NO_RESID_PREFETCH
       Pack8 hv = gload16(rp);
+#else
+      Pack8 hv = hpre[it];
+#endif
       float o[8], h[8];
       unpack8<T>(v, o);
       unpack8<T>(hv, h);

@@ -68,16 +68,16 @@ def device_weights(cfg_like, seed: int, device) -> dict[str, torch.Tensor]:
     return out
 
 
-def synthetic_batch(batch: int, seed: int, device):
+def synthetic_batch(batch: int, seed: int, device, T: int = 120, side: int = 32):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    T, C = 120, 4096
+    C = 4096
     prompt = (torch.randn(batch, T, C, generator=g) * 0.1).half()
     lens = torch.randint(8, T + 1, (batch,), generator=g)
     mask = (torch.arange(T)[None, :] < lens[:, None]).to(torch.uint8)
     neg = (torch.randn(1, T, C, generator=g) * 0.1).half().repeat(batch, 1, 1)
     neg_mask = torch.zeros(batch, T, dtype=torch.uint8)
     neg_mask[:, :2] = 1
-    latents = torch.randn(batch, 4, 32, 32, generator=g)
+    latents = torch.randn(batch, 4, side, side, generator=g)
     enc = torch.cat([neg, prompt], 0).to(device)
     m = torch.cat([neg_mask, mask], 0).to(device)
     return enc, m, latents.to(device)
@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024"],
+                    help="alpha256 = BASELINE metric config (default); sigma1024 = BASELINE config 3 (secondary, not the headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,9 +135,15 @@ def main():
     from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
 
     log('imports done')
+    global BATCH, SCHEDULE
+    side, text_tokens, sample_size, interp = 32, 120, 32, None
+    if args.workload == "sigma1024":  # PixArt-Sigma 1024x1024, batch 4, T = 300; schedule transferred from sigma_256/ours_fast
+        BATCH, side, text_tokens, sample_size, interp = 4, 128, 300, 128, 2
+        SCHEDULE = ROOT / "schedules/schedules_in_paper/pixart_sigma_256/ours_fast.json"
     sched = PixArtCacheSchedule.from_json(SCHEDULE)
     bits = sched.to_numpy()
-    eng = EcadEngine(num_layers=28, max_batch=2 * BATCH, max_tokens=256, max_text_tokens=120, dtype=torch.float16, device=local_rank)
+    eng = EcadEngine(num_layers=28, max_batch=2 * BATCH, max_tokens=(side // 2) ** 2, max_text_tokens=text_tokens, sample_size=sample_size,
+                     interpolation_scale=interp, dtype=torch.float16, device=local_rank)
     weights = device_weights(type("C", (), dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2,
                                                 num_layers=28, caption_channels=4096)), seed=0, device=device)
     log('weights generated')
@@ -146,7 +154,7 @@ def main():
     solver.set_timesteps(NUM_STEPS)
     ts = solver.timesteps.numpy().astype(np.float32)
     coefs = solver.coefficient_table()
-    enc, mask, latents = synthetic_batch(BATCH, seed=1000 + rank, device=device)  # disjoint work per rank
+    enc, mask, latents = synthetic_batch(BATCH, seed=1000 + rank, device=device, T=text_tokens, side=side)  # disjoint work per rank
 
     def one_batch(graph=True):
         return eng.run_schedule(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=graph)
@@ -180,7 +188,8 @@ def main():
         value = images / elapsed
         flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"]) / BATCH
         res = {
-            "metric": "images/sec at fixed schedule (PixArt-alpha 256, 20-step, ours_fast)",
+            "metric": "images/sec at fixed schedule (PixArt-alpha 256, 20-step, ours_fast)" if args.workload == "alpha256"
+            else "images/sec at fixed schedule (PixArt-Sigma 1024, 20-step, sigma ours_fast transfer) [secondary]",
             "value": value,
             "unit": "images/s",
             "n_gpus": world,
@@ -193,7 +202,9 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {
-                "workload": "PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch=16 (CFG batch 32), 1xMI355X per rank",
+                "workload": ("PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch=16 (CFG batch 32), 1xMI355X per rank"
+                             if args.workload == "alpha256" else
+                             "PixArt-Sigma 1024x1024 geometry (N=4096, T=300), 20 steps, pixart_sigma_256/ours_fast.json transferred, batch=4 (CFG batch 8), 1xMI355X per rank"),
                 "batch_per_gpu": BATCH,
                 "guidance_scale": GUIDANCE,
                 "timed_region": "caption-proj + text-KV hoist, 20 transformer steps with cache gate, CFG, DPM-Solver++; latents out (no VAE/PIL)",
@@ -249,7 +260,7 @@ def main():
             tot = sum(v["ms"] for v in prof.values())
             res["time_breakdown_ms_per_batch"] = {k: round(v["ms"] / reps, 3) for k, v in prof.items() if v["launches"]}
             res["time_breakdown_ms_per_batch"]["_sum"] = round(tot / reps, 3)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "alpha256":
             res["cpu_baseline"] = cpu_baseline(weights, bits, images=2)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -29,7 +29,7 @@ KNOWN_CONFIGS: dict[str, dict[str, Any]] = {
     "PixArt-alpha/PixArt-XL-2-512x512": dict(sample_size=64, caption_channels=4096, max_text_tokens=120),
     "PixArt-alpha/PixArt-XL-2-1024-MS": dict(sample_size=128, caption_channels=4096, max_text_tokens=120, use_additional_conditions=True),
     "PixArt-alpha/PixArt-Sigma-XL-2-256x256": dict(sample_size=32, caption_channels=4096, max_text_tokens=300),
-    "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS": dict(sample_size=128, caption_channels=4096, max_text_tokens=300, interpolation_scale=2),
+    "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS": dict(sample_size=128, caption_channels=4096, max_text_tokens=300, interpolation_scale=2, use_additional_conditions=False),
 }
 
 

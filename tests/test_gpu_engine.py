@@ -176,3 +176,33 @@ def test_baseline_batch16_properties():
     sel = torch.tensor([idx, 16 + idx])
     one = eng.run_schedule(enc[sel].cuda(), mask[sel].cuda(), inp["latents"][idx : idx + 1].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
     assert rel_l2(one, a[idx : idx + 1]) < 1e-6 or torch.equal(one, a[idx : idx + 1])
+
+
+def test_sigma_1024_geometry_step_parity():
+    """BASELINE config 3 geometry (PixArt-Sigma 1024x1024: N = 4096 image tokens, T = 300 text tokens, sincos table with
+    interpolation_scale 2): multi-chunk attention (32 key chunks self, 3 cross) and the M = 8192-row GEMMs vs the oracle."""
+    from ecad_amd.engine import EcadEngine
+
+    layers, steps = 2, 3
+    bits = np.array([[[1, 1, 1]] * layers, [[0, 1, 0]] * layers, [[1, 0, 1]] * layers], dtype=bool)
+    cfg = PixArtConfig(num_layers=layers, sample_size=128, interpolation_scale=2)
+    w = make_weights(cfg, seed=4)
+    eng = EcadEngine(num_layers=layers, sample_size=128, interpolation_scale=2, max_batch=2, max_tokens=4096, max_text_tokens=300, dtype=torch.float16)
+    eng.load_state_dict(w)
+    eng.set_schedule(bits)
+    ref = PixArtOracle(cfg, w)
+    g = torch.Generator().manual_seed(11)
+    enc = torch.randn(2, 300, 4096, generator=g) * 0.1
+    mask = torch.zeros(2, 300, dtype=torch.int64)
+    mask[0, :2] = 1
+    mask[1, :211] = 1
+    eng.begin_image_batch(enc.cuda(), mask.cuda(), 128, 128)
+    worst = 0.0
+    for s in range(steps):
+        x = torch.randn(2, 4, 128, 128, generator=g)
+        t = torch.full((2,), 900.0 - 300 * s)
+        out = eng.step(s, x.cuda(), t.cuda())
+        exp = ref.forward(x.half().float(), enc.half().float(), mask, t, s, bits[s])
+        worst = max(worst, rel_l2(out, exp))
+    print(f"sigma-1024 geometry worst per-step rel-L2: {worst:.3e}")
+    assert out.shape == (2, 8, 128, 128) and worst < 4e-3

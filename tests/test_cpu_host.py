@@ -148,3 +148,14 @@ def test_synthetic_weights_identical_to_oracle_recipe():
     a, b = synthetic_state_dict(ns, seed=3), make_weights(cfg, seed=3)
     assert list(a) == list(b)
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_ecad_import_alias_resolves_to_native_host_side():
+    import ecad.schedulers.cache_scheduler.pixart_cache_schedule as a
+    import ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule as b
+    from ecad.image_generators.load_image_generator import get_image_generator_type
+    from ecad.transformer_blocks.custom_attn_ff import ComputeAttnRegistry
+
+    assert a.PixArtCacheSchedule is b.PixArtCacheSchedule
+    assert get_image_generator_type("PixArtAlphaImageGenerator").__module__.startswith("ecad_amd.")
+    assert ComputeAttnRegistry.DEFAULT == "compute_attn_cached"

@@ -159,3 +159,19 @@ def test_ecad_import_alias_resolves_to_native_host_side():
     assert a.PixArtCacheSchedule is b.PixArtCacheSchedule
     assert get_image_generator_type("PixArtAlphaImageGenerator").__module__.startswith("ecad_amd.")
     assert ComputeAttnRegistry.DEFAULT == "compute_attn_cached"
+
+
+def test_vae_decoder_shapes_and_diffusers_key_names():
+    from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly
+
+    vae = AutoencoderKLDecoderOnly().eval()
+    keys = set(vae.state_dict())
+    for k in ("post_quant_conv.weight", "decoder.conv_in.weight", "decoder.mid_block.attentions.0.to_q.weight", "decoder.mid_block.resnets.1.conv2.bias",
+              "decoder.up_blocks.0.upsamplers.0.conv.weight", "decoder.up_blocks.2.resnets.0.conv_shortcut.weight", "decoder.up_blocks.3.resnets.2.norm2.weight",
+              "decoder.conv_norm_out.weight", "decoder.conv_out.bias"):
+        assert k in keys, k
+    assert vae.state_dict()["decoder.up_blocks.2.resnets.0.conv1.weight"].shape == (256, 512, 3, 3)
+    n = sum(p.numel() for p in vae.parameters())
+    assert 49e6 < n < 50e6  # SD VAE decoder + post_quant_conv ~49.5 M parameters
+    img = vae.decode(torch.randn(1, 4, 8, 8))[0]
+    assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "gemm2w.h"
 #include "gemm3s.h"
 #include "pgemm.h"
 
@@ -189,10 +190,12 @@ template <typename T> class EngineT : public EngineBase {
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
-    gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = gemm_impl_cls[KC_GEMM_FF1] = 0;
+    gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = 0;
+    gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = 2;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0;
       if (strcmp(gi, "persistent") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
+      if (strcmp(gi, "wide") == 0) gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_SMALL] = 2;
     }
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
@@ -615,11 +618,24 @@ template <typename T> class EngineT : public EngineBase {
   int num_cus = 256;
   bool g3_attr[4][KC_COUNT] = {};
   // per call-site class: 1 = persistent producer/consumer (pgemm.h), 0 = one tile per workgroup (gemm3s.h).  Defaults from
-  // interleaved in-process A/B runs with cold caches (scripts/bench_gemm.py --cold): the persistent kernel wins where a
-  // CU owns several tiles or K is long and the epilogue is a plain store; the RMW / GELU epilogues favour 8 mixed waves.
+  // 2 = wide 256x288 tiles (gemm2w.h, N % 288 == 0).  Defaults from interleaved in-process A/B runs with cold caches
+  // (scripts/bench_gemm.py --cold): wide tiles wherever the tile count still fills the chip (FF1, text K/V); the persistent
+  // kernel for long K with a plain tile count (FF2); 8 mixed waves for the N = 1152 RMW epilogues and QKV.
   // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
   int gemm_impl_cls[KC_COUNT];
+  bool g2_attr[4][KC_COUNT] = {};
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
+    if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL) {
+      if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0) {  // wide 256x288 tiles
+        if (!g2_attr[EPI][TAG]) {
+          HIPCHK(hipFuncSetAttribute((const void*)gemm2w_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+          g2_attr[EPI][TAG] = true;
+        }
+        const int tiles2 = ((g.M + G2_BM - 1) / G2_BM) * (g.N / G2_BN);
+        hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);
+        return ECAD_OK;
+      }
+    }
     if (gemm_impl_cls[TAG] == 0) {
       if (!g3_attr[EPI][TAG]) {
         HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));

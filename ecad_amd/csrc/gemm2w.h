@@ -1,0 +1,173 @@
+// gemm2w.h -- wide-tile sibling of gemm3s.h for the large-N GEMMs (FF1: N = 4608 = 16 * 288; text K/V).
+//
+// The K loop of the 256x144 kernels is power/DVFS-limited and the clock tracks the bytes moved per flop (1.28-1.66 GHz
+// with the LDS-DMA stream, 1.87-2.0 GHz with it ablated).  A 256x288 tile moves (256+288)/(256*288) = 0.0074 B/flop
+// through L2->LDS instead of 0.0109 (-32 %), and 8 waves laid out 4 (M) x 2 (N) own 64x144 each, so the LDS fragment
+// reads drop from 0.61 to 0.36 per MFMA.  Price: only a 2-deep stage ring fits (2 x 69.6 KiB), i.e. one K-step of
+// prefetch (a step is 144 MFMAs per SIMD, ~1.2 us, enough for L2-resident operands), and N % 288 == 0.
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace ecad {
+
+constexpr int G2_BM = 256, G2_BN = 288, G2_NW = 8;
+constexpr int G2_A_BYTES = G2_BM * 128;
+constexpr int G2_STAGE_BYTES = (G2_BM + G2_BN) * 128;  // 69632
+constexpr int G2_CS = G2_BN + 8;
+constexpr int G2_LDS_BYTES = (2 * G2_STAGE_BYTES) > (G2_BM * G2_CS * 2) ? (2 * G2_STAGE_BYTES) : (G2_BM * G2_CS * 2);  // 151552
+
+template <typename T, int EPI, int TAG>
+__global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p) {
+  constexpr int FM = 4, FN = 9;
+  constexpr int A_INST = G2_BM / 8 / G2_NW;  // 4
+  constexpr int B_TOTAL = G2_BN / 8;         // 36 -> waves 0-3 issue 5, waves 4-7 issue 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;  // waves w and w+4 share a SIMD: one of each column half per SIMD
+  const int l15 = lane & 15, g = lane >> 4;
+  const int tiles_n = p.N / G2_BN;
+  const int tiles_m = (p.M + G2_BM - 1) / G2_BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+
+  const T* a_src[A_INST];
+  const T* b_src[5];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int row = m0 + r;
+    row = row < p.M ? row : p.M - 1;
+    a_src[i] = p.A + (size_t)row * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int inst = wave + i * G2_NW;
+    inst = inst < B_TOTAL ? inst : B_TOTAL - 1;
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = p.W + (size_t)(n0 + r) * p.ldw + c * 8;
+  }
+  auto issue = [&](int stage) {
+    char* abase = smem + stage * G2_STAGE_BYTES;
+    char* bbase = abase + G2_A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      glds16(a_src[i], abase + (wave * A_INST + i) * 1024);
+      a_src[i] += GEMM_BK;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int inst = wave + i * G2_NW;
+      if (inst < B_TOTAL) glds16(b_src[i], bbase + inst * 1024);
+      b_src[i] += GEMM_BK;
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wm * 64 + l15) * 128;
+  const int b_row_off = (wn * 144 + l15) * 128;
+  const int nk = p.K / GEMM_BK;
+
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed (nothing else is in flight)
+    __builtin_amdgcn_s_barrier();                      // tile kt complete; everyone is done reading the other stage
+    if (kt + 1 < nk) issue(stage ^ 1);
+    const char* abase = smem + stage * G2_STAGE_BYTES;
+    const char* bbase = abase + G2_A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + g) ^ swz) * 16;
+      Pack8 af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue 1: this wave's 64 x 144 block into the row-major C tile
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nl = wn * 144 + 16 * j + 4 * g;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wm * 64 + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[r];
+        if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+        if (EPI == EPI_BIAS_SILU) v = silu(v);
+        float_to_elem4<T>(o, r, v);
+      }
+      *reinterpret_cast<u32x2*>(ctile + ml * G2_CS + nl) = o.u;
+    }
+  }
+  __syncthreads();  // rows are shared by the two column-half waves
+
+  // ---- epilogue 2: wave w streams rows 32w .. 32w+31, 36 chunks of 16 bytes per row
+  constexpr int CPR = G2_BN / 8;
+  constexpr int CHUNKS = 32 * CPR;  // 1152 = 18 per lane
+  for (int id = lane; id < CHUNKS; id += 64) {
+    const int rl = id / CPR, cchunk = id - rl * CPR;
+    const int ml = wave * 32 + rl;
+    const int m = m0 + ml;
+    if (m >= p.M) continue;
+    const int n = n0 + cchunk * 8;
+    Pack8 v = lds_read16(ctile + ml * G2_CS + cchunk * 8);
+    if (EPI == EPI_BIAS_CACHE_RESID) {
+      if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);
+      T* rp = p.resid + (size_t)m * p.ldr + n;
+      float o[8], h[8];
+      unpack8<T>(v, o);
+      unpack8<T>(gload16(rp), h);
+      if (p.gate_table) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
+        float gt[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if (p.gate_mod) {
+          float gm[8];
+          const int b = m / p.rows_per_batch;
+          unpack8<T>(gload16(p.gate_mod + (size_t)b * p.gate_mod_stride + n), gm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gt[e] += gm[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += gt[e] * o[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += o[e];
+      }
+      gstore16(rp, pack8<T>(h));
+    } else {
+      gstore16(p.C + (size_t)m * p.ldc + n, v);
+    }
+  }
+}
+
+}  // namespace ecad

@@ -40,11 +40,11 @@ constexpr int PROJ_PAD = 144;  // proj_out rows padded to one GEMM tile column
 
 enum KClass {
   KC_GEMM_QKV = 0, KC_GEMM_OUT1, KC_GEMM_Q2, KC_GEMM_OUT2, KC_GEMM_FF1, KC_GEMM_FF2, KC_GEMM_TEXTKV, KC_GEMM_CAPTION,
-  KC_GEMM_SMALL, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_COUNT
+  KC_GEMM_SMALL, KC_GEMM_KV1, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_COUNT
 };
 static const char* kclass_names[KC_COUNT] = {
     "gemm_qkv", "gemm_attn1_out", "gemm_attn2_q", "gemm_attn2_out", "gemm_ff1_gelu", "gemm_ff2", "gemm_text_kv", "gemm_caption",
-    "gemm_small", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc"};
+    "gemm_small", "gemm_attn1_kv_wide", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc"};
 
 struct EngineBase {
   EcadModelCfg cfg;
@@ -191,9 +191,10 @@ template <typename T> class EngineT : public EngineBase {
     HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
     gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = 0;
-    gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = 2;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
+    gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
+    if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* gi = getenv("ECAD_GEMM")) {
-      if (strcmp(gi, "classic") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0;
+      if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
       if (strcmp(gi, "persistent") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
       if (strcmp(gi, "wide") == 0) gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_SMALL] = 2;
     }
@@ -471,7 +472,14 @@ template <typename T> class EngineT : public EngineBase {
       // --- attn1
       if (ex[0]) {
         emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride);
-        ops.push_back(mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D));
+        if (split_qkv && (2 * D) % G2_BN == 0) {
+          // Q columns on 256x144 tiles (256 tiles) + K,V columns on 256x288 tiles (256 tiles): the wide tiles move 32 % fewer
+          // L2->LDS bytes per flop, and both launches fill the chip exactly once
+          ops.push_back(mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, D, D, D, 3 * D));
+          ops.push_back(mk_gemm(KC_GEMM_KV1, EPI_BIAS, xn, B.w_qkv + (size_t)D * D, B.b_qkv + D, qkv + D, M, 2 * D, D, D, 3 * D));
+        } else {
+          ops.push_back(mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D));
+        }
         Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0;
         a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
@@ -624,8 +632,9 @@ template <typename T> class EngineT : public EngineBase {
   // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
   int gemm_impl_cls[KC_COUNT];
   bool g2_attr[4][KC_COUNT] = {};
+  bool split_qkv = true;  // env ECAD_SPLIT_QKV=0 keeps the single 3D-wide launch
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
-    if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL) {
+    if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
       if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0) {  // wide 256x288 tiles
         if (!g2_attr[EPI][TAG]) {
           HIPCHK(hipFuncSetAttribute((const void*)gemm2w_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
@@ -658,7 +667,7 @@ template <typename T> class EngineT : public EngineBase {
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
     if (g.N % PG_BN == 0) {
 #define G144(E, C) if (epi == E && cls == C) return launch_pg<E, C>(g, s)
-      G144(EPI_BIAS, KC_GEMM_QKV); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT1); G144(EPI_BIAS, KC_GEMM_Q2); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT2);
+      G144(EPI_BIAS, KC_GEMM_QKV); G144(EPI_BIAS, KC_GEMM_KV1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT1); G144(EPI_BIAS, KC_GEMM_Q2); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT2);
       G144(EPI_BIAS_GELU, KC_GEMM_FF1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_FF2); G144(EPI_BIAS, KC_GEMM_TEXTKV);
       G144(EPI_BIAS_GELU, KC_GEMM_CAPTION); G144(EPI_BIAS, KC_GEMM_CAPTION);
       G144(EPI_BIAS, KC_GEMM_SMALL); G144(EPI_BIAS_GELU, KC_GEMM_SMALL); G144(EPI_BIAS_SILU, KC_GEMM_SMALL); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_SMALL);

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace ecad {
 
 typedef _Float16 f16_t;
@@ -18,6 +21,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define ECAD_DEV __device__ __forceinline__
+
+// compile-time unrolled loop with a constexpr index (needed by __builtin_amdgcn_sched_group_barrier and register rings)
+template <int... Q, typename F> ECAD_DEV void static_for_impl(std::integer_sequence<int, Q...>, F&& f) { (f(std::integral_constant<int, Q>{}), ...); }
+template <int N, typename F> ECAD_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <typename T> struct Vec8;
 template <> struct Vec8<f16_t> { typedef f16x8 type; };

@@ -28,8 +28,6 @@ constexpr int PG_A_BYTES = PG_BM * 128, PG_STAGE_BYTES = (PG_BM + PG_BN) * 128; 
 constexpr int PG_LDS_BYTES = PG_STAGES * PG_STAGE_BYTES;                         // 153600
 constexpr int PG_CS = PG_BN + 8;                                                 // C slab row stride (elements)
 
-template <int... Q, typename F> ECAD_DEV void static_for_impl(std::integer_sequence<int, Q...>, F&& f) { (f(std::integral_constant<int, Q>{}), ...); }
-template <int N, typename F> ECAD_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // tile id -> workgroup: XCD x (blocks b with b % 8 == x share an L2) owns a contiguous chunk of the row-major tile
 // order; inside the chunk its workgroups take consecutive tiles round by round, so the tiles resident on one XCD at

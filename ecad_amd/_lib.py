@@ -83,6 +83,12 @@ SIGNATURES = {
     "ecad_op_ln_modulate": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _I64, _I, _P]),
     "ecad_op_cache_accumulate": (_I, [_P, _P, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _I64, _I, _P]),
     "ecad_op_attention": (_I, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
+    "ecad_vae_create": (_I, [_I, _I, C.POINTER(_P)]),
+    "ecad_vae_destroy": (None, [_P]),
+    "ecad_vae_last_error": (C.c_char_p, [_P]),
+    "ecad_vae_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
+    "ecad_vae_finalize_weights": (_I, [_P]),
+    "ecad_vae_decode": (_I, [_P, _P, _I, _I, _I, C.c_float, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,324 @@
+// vae.hip -- AutoencoderKL decoder (SD / sd-vae-ft-ema geometry: block_out_channels 128,256,512,512, 3 resnets per up
+// block, one mid attention, 32 groups) behind the C ABI: latents -> uint8 NHWC RGB, entirely in hand-written HIP.
+// Replaces `self.vae.decode(latents / scaling_factor)` + `image_processor.postprocess` of the reference's timed region
+// (ecad/pipelines/pass_through.py:382-396).  Weight names are diffusers' AutoencoderKL state-dict keys [ext].
+#include "../../include/ecad_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "vae_kernels.h"
+
+namespace ecad {
+
+static std::string g_vae_create_error;
+
+#define VHIPCHK(expr)                                                                                                  \
+  do {                                                                                                                 \
+    hipError_t _e = (expr);                                                                                            \
+    if (_e != hipSuccess) return fail(ECAD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename TS, typename TD> __global__ void vae_convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (TD)(float)src[i];
+}
+// [Cout][Cin][taps] -> [Cout][taps][Cin]
+template <typename TS, typename TD> __global__ void vae_relayout_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int Cout, int Cin, int taps) {
+  const size_t n = (size_t)Cout * Cin * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % taps);
+    const int co = (int)(i / ((size_t)Cin * taps));
+    dst[i] = (TD)(float)src[((size_t)co * Cin + ci) * taps + tap];
+  }
+}
+
+struct VaeBase {
+  int dev = 0;
+  std::string err;
+  virtual ~VaeBase() {}
+  int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  virtual int init() = 0;
+  virtual int load(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
+  virtual int finalize() = 0;
+  virtual int decode(const float* lat, int B, int h, int w, float scaling, uint8_t* out, hipStream_t s) = 0;
+};
+
+template <typename T> struct VaeT : VaeBase {
+  enum Kind { F32, CONV3, LIN, CONVOUT };
+  struct W { void* ptr; Kind kind; int cout, cin; size_t numel; bool loaded; };
+  std::map<std::string, W> wt;
+  std::vector<void*> allocs;
+  void* zero_page = nullptr;
+  // activation buffers
+  T *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr;
+  float *gn_sums = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
+  size_t act_elems = 0;
+  int cap_B = 0, cap_h = 0, cap_w = 0;
+  bool finalized = false;
+
+  ~VaeT() override {
+    hipSetDevice(dev);
+    for (void* p : allocs) hipFree(p);
+    free_acts();
+  }
+  void free_acts() {
+    for (void* p : {(void*)bufA, (void*)bufB, (void*)bufC, (void*)bufD, (void*)gn_sums, (void*)gn_scale, (void*)gn_shift})
+      if (p) hipFree(p);
+    bufA = bufB = bufC = bufD = nullptr;
+    gn_sums = gn_scale = gn_shift = nullptr;
+  }
+  int reg(const std::string& name, Kind kind, int cout, int cin) {
+    size_t n = kind == CONV3 ? (size_t)cout * cin * 9 : kind == LIN ? (size_t)cout * cin : kind == CONVOUT ? (size_t)cout * cin * 9 : (size_t)cout * (cin > 0 ? cin : 1);
+    void* p = nullptr;
+    size_t bytes = n * ((kind == CONV3 || kind == LIN) ? sizeof(T) : sizeof(float));
+    if (kind == CONVOUT) bytes = (size_t)16 * 9 * cin * sizeof(T);  // 3 real output rows + 13 zero rows: one MFMA N-fragment
+    VHIPCHK(hipMalloc(&p, bytes));
+    if (kind == CONVOUT) VHIPCHK(hipMemset(p, 0, bytes));
+    allocs.push_back(p);
+    wt[name] = W{p, kind, cout, cin, n, false};
+    return ECAD_OK;
+  }
+#define REG(...) { int rc_ = reg(__VA_ARGS__); if (rc_) return rc_; }
+  int reg_resnet(const std::string& p, int cin, int cout) {
+    REG(p + "norm1.weight", F32, cin, 0) REG(p + "norm1.bias", F32, cin, 0)
+    REG(p + "conv1.weight", CONV3, cout, cin) REG(p + "conv1.bias", F32, cout, 0)
+    REG(p + "norm2.weight", F32, cout, 0) REG(p + "norm2.bias", F32, cout, 0)
+    REG(p + "conv2.weight", CONV3, cout, cout) REG(p + "conv2.bias", F32, cout, 0)
+    if (cin != cout) { REG(p + "conv_shortcut.weight", LIN, cout, cin) REG(p + "conv_shortcut.bias", F32, cout, 0) }
+    return ECAD_OK;
+  }
+  int init() override {
+    VHIPCHK(hipSetDevice(dev));
+    VHIPCHK(hipMalloc(&zero_page, 256));
+    VHIPCHK(hipMemset(zero_page, 0, 256));
+    allocs.push_back(zero_page);
+    REG("post_quant_conv.weight", F32, 4, 4) REG("post_quant_conv.bias", F32, 4, 0)
+    REG("decoder.conv_in.weight", F32, 512, 36) REG("decoder.conv_in.bias", F32, 512, 0)
+    int rc;
+    if ((rc = reg_resnet("decoder.mid_block.resnets.0.", 512, 512))) return rc;
+    if ((rc = reg_resnet("decoder.mid_block.resnets.1.", 512, 512))) return rc;
+    const std::string a = "decoder.mid_block.attentions.0.";
+    REG(a + "group_norm.weight", F32, 512, 0) REG(a + "group_norm.bias", F32, 512, 0)
+    for (const char* n : {"to_q", "to_k", "to_v", "to_out.0"}) { REG(a + n + ".weight", LIN, 512, 512) REG(a + n + ".bias", F32, 512, 0) }
+    const int chans[4] = {512, 512, 256, 128};
+    int prev = 512;
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 3; ++j)
+        if ((rc = reg_resnet("decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", j == 0 ? prev : chans[i], chans[i]))) return rc;
+      if (i < 3) { REG("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.weight", CONV3, chans[i], chans[i]) REG("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.bias", F32, chans[i], 0) }
+      prev = chans[i];
+    }
+    REG("decoder.conv_norm_out.weight", F32, 128, 0) REG("decoder.conv_norm_out.bias", F32, 128, 0)
+    REG("decoder.conv_out.weight", CONVOUT, 3, 128) REG("decoder.conv_out.bias", F32, 3, 0)
+    VHIPCHK(hipFuncSetAttribute((const void*)conv_gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    return ECAD_OK;
+  }
+
+  int load(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) override {
+    VHIPCHK(hipSetDevice(dev));
+    auto it = wt.find(name);
+    if (it == wt.end()) {
+      if (strncmp(name, "encoder.", 8) == 0 || strncmp(name, "quant_conv.", 11) == 0) return ECAD_OK;  // encoder half is unused
+      return fail(ECAD_E_INVALID, "unknown VAE weight '%s'", name);
+    }
+    W& w = it->second;
+    int64_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= shape[i];
+    if ((size_t)numel != w.numel) return fail(ECAD_E_INVALID, "VAE weight '%s': expected %zu elements, got %lld", name, w.numel, (long long)numel);
+    const size_t esz = dtype == ECAD_DTYPE_F32 ? 4 : 2;
+    void* stage = nullptr;
+    VHIPCHK(hipMalloc(&stage, numel * esz));
+    hipError_t e = hipMemcpy(stage, ptr, numel * esz, hipMemcpyDefault);
+    if (e != hipSuccess) { hipFree(stage); return fail(ECAD_E_HIP, "copy of '%s' failed: %s", name, hipGetErrorString(e)); }
+    const int grid = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
+#define DISPATCH(KERNEL, DST, ...)                                                                                   \
+  if (dtype == ECAD_DTYPE_F16) hipLaunchKernelGGL((KERNEL<f16_t, DST>), dim3(grid), dim3(256), 0, 0, (const f16_t*)stage, (DST*)w.ptr, __VA_ARGS__);   \
+  else if (dtype == ECAD_DTYPE_BF16) hipLaunchKernelGGL((KERNEL<bf16_t, DST>), dim3(grid), dim3(256), 0, 0, (const bf16_t*)stage, (DST*)w.ptr, __VA_ARGS__); \
+  else hipLaunchKernelGGL((KERNEL<float, DST>), dim3(grid), dim3(256), 0, 0, (const float*)stage, (DST*)w.ptr, __VA_ARGS__);
+    if (w.kind == CONV3) { DISPATCH(vae_relayout_kernel, T, w.cout, w.cin, 9) }
+    else if (w.kind == CONVOUT) { DISPATCH(vae_relayout_kernel, T, w.cout, w.cin, 9) }
+    else if (w.kind == LIN) { DISPATCH(vae_convert_kernel, T, (size_t)numel) }
+    else { DISPATCH(vae_convert_kernel, float, (size_t)numel) }
+#undef DISPATCH
+    e = hipDeviceSynchronize();
+    hipFree(stage);
+    if (e != hipSuccess) return fail(ECAD_E_HIP, "conversion of '%s' failed: %s", name, hipGetErrorString(e));
+    w.loaded = true;
+    return ECAD_OK;
+  }
+  int finalize() override {
+    for (auto& kv : wt)
+      if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "VAE weight '%s' was never loaded", kv.first.c_str());
+    finalized = true;
+    return ECAD_OK;
+  }
+
+  template <typename U> U* W_(const std::string& n) { return reinterpret_cast<U*>(wt.at(n).ptr); }
+
+  int ensure_acts(int B, int h, int w) {
+    if (B <= cap_B && h <= cap_h && w <= cap_w && bufA) return ECAD_OK;
+    free_acts();
+    // largest activation: output of the third upsampler: (8h x 8w) pixels x 256 channels
+    act_elems = (size_t)B * (8 * h) * (8 * w) * 256;
+    const size_t tokens = (size_t)h * w;
+    const size_t attn_elems = (size_t)tokens * tokens;  // per-image score matrix lives in bufD
+    VHIPCHK(hipMalloc((void**)&bufA, act_elems * sizeof(T)));
+    VHIPCHK(hipMalloc((void**)&bufB, act_elems * sizeof(T)));
+    VHIPCHK(hipMalloc((void**)&bufC, act_elems * sizeof(T)));
+    VHIPCHK(hipMalloc((void**)&bufD, (attn_elems > act_elems ? attn_elems : act_elems) * sizeof(T)));
+    VHIPCHK(hipMalloc((void**)&gn_sums, (size_t)B * 512 * 2 * sizeof(float)));
+    VHIPCHK(hipMalloc((void**)&gn_scale, (size_t)B * 512 * sizeof(float)));
+    VHIPCHK(hipMalloc((void**)&gn_shift, (size_t)B * 512 * sizeof(float)));
+    cap_B = B; cap_h = h; cap_w = w;
+    return ECAD_OK;
+  }
+
+  // ---- layer launchers
+  int conv(const T* in, const std::string& name, T* out, const T* resid, int B, int H, int W, int cin, int cout, int taps, int up, hipStream_t s,
+           const T* w_override = nullptr, const float* b_override = nullptr, bool no_bias = false) {
+    if (cin % 64 || cout % 128) return fail(ECAD_E_UNSUPPORTED, "conv %s: Cin %% 64 / Cout %% 128 required (%d, %d)", name.c_str(), cin, cout);
+    ConvArgs a{};
+    a.in = in; a.w = w_override ? w_override : W_<T>(name + ".weight"); a.bias = no_bias ? nullptr : (b_override ? b_override : W_<float>(name + ".bias"));
+    a.resid = resid; a.out = out; a.zero_page = zero_page; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = taps; a.up = up;
+    const int M = B * H * W;
+    const int tiles = ((M + 127) / 128) * (cout / 128);
+    hipLaunchKernelGGL((conv_gemm_kernel<T>), dim3(tiles), dim3(256), 65536, s, a);
+    return ECAD_OK;
+  }
+  // statistics -> per-(image, channel) scale/shift in gn_scale / gn_shift
+  void group_norm_stats(const T* x, const std::string& name, int B, int HW, int C, hipStream_t s) {
+    hipMemsetAsync(gn_sums, 0, (size_t)B * 32 * 2 * sizeof(float), s);
+    const int ppb = HW >= 16384 ? 512 : HW >= 4096 ? 256 : 64;
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, x, gn_sums, HW, C, 32, ppb);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, gn_sums, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
+  }
+  void group_norm(const T* x, T* y, const std::string& name, int B, int HW, int C, bool act, hipStream_t s) {
+    group_norm_stats(x, name, B, HW, C, s);
+    const size_t chunks = (size_t)B * HW * (C / 8);
+    const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+    if (act) hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(grid), dim3(256), 0, s, x, y, gn_scale, gn_shift, chunks, HW, C);
+    else hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(grid), dim3(256), 0, s, x, y, gn_scale, gn_shift, chunks, HW, C);
+  }
+  // x (in `x`) -> resnet -> result in `out`; t1, t2 scratch
+  int resnet(const std::string& p, const T* x, T* out, T* t1, T* t2, int B, int H, int W, int cin, int cout, hipStream_t s) {
+    int rc;
+    group_norm(x, t1, p + "norm1", B, H * W, cin, true, s);
+    if ((rc = conv(t1, p + "conv1", t2, nullptr, B, H, W, cin, cout, 9, 0, s))) return rc;
+    group_norm(t2, t2, p + "norm2", B, H * W, cout, true, s);
+    const T* res = x;
+    if (cin != cout) {
+      if ((rc = conv(x, p + "conv_shortcut", t1, nullptr, B, H, W, cin, cout, 1, 0, s))) return rc;
+      res = t1;
+    }
+    return conv(t2, p + "conv2", out, res, B, H, W, cout, cout, 9, 0, s);
+  }
+
+  int decode(const float* lat, int B, int h, int w, float scaling, uint8_t* out, hipStream_t s) override {
+    VHIPCHK(hipSetDevice(dev));
+    if (!finalized) return fail(ECAD_E_NOT_READY, "VAE weights not finalized");
+    if (B < 1 || h < 4 || w < 4 || (h * w) % 128 || (w & 1)) return fail(ECAD_E_INVALID, "latent %dx%dx%d unsupported (h*w must be a multiple of 128, w even)", B, h, w);
+    int rc = ensure_acts(B, h, w);
+    if (rc) return rc;
+    T *x = bufA, *y = bufB, *t = bufC;
+    int H = h, Wd = w;
+    hipLaunchKernelGGL((vae_conv_in_kernel<T>), dim3((H * Wd + CIN_PIX - 1) / CIN_PIX, B), dim3(256), 0, s, lat, W_<float>("post_quant_conv.weight"), W_<float>("post_quant_conv.bias"),
+                       W_<float>("decoder.conv_in.weight"), W_<float>("decoder.conv_in.bias"), x, B, H, Wd, 512, 1.0f / scaling);
+    // ---- mid block
+    if ((rc = resnet("decoder.mid_block.resnets.0.", x, y, t, bufD, B, H, Wd, 512, 512, s))) return rc;
+    {  // attention: one head of 512 channels over H*W tokens; result back into x
+      const std::string a = "decoder.mid_block.attentions.0.";
+      const int HW = H * Wd, C = 512;
+      group_norm(y, t, a + "group_norm", B, HW, C, false, s);
+      T* q = x;                          // [B*HW, C]
+      T* k = bufC + (size_t)B * HW * C;  // second region of bufC (t occupies the first B*HW*C elements)
+      T* v = k + (size_t)B * HW * C;
+      T* vt = v + (size_t)B * HW * C;
+      if ((rc = conv(t, a + "to_q", q, nullptr, B, HW, 1, C, C, 1, 0, s))) return rc;
+      if ((rc = conv(t, a + "to_k", k, nullptr, B, HW, 1, C, C, 1, 0, s))) return rc;
+      if ((rc = conv(t, a + "to_v", v, nullptr, B, HW, 1, C, C, 1, 0, s))) return rc;
+      hipLaunchKernelGGL((transpose_kernel<T>), dim3((C + 31) / 32, (HW + 31) / 32, B), dim3(32, 8), 0, s, v, vt, HW, C);
+      T* o = t;  // attention output [B*HW, C] (group-normed input no longer needed once q,k,v exist)
+      for (int b = 0; b < B; ++b) {
+        T* S = bufD;  // [HW, HW]
+        if ((rc = conv(q + (size_t)b * HW * C, "", S, nullptr, 1, HW, 1, C, HW, 1, 0, s, k + (size_t)b * HW * C, nullptr, true))) return rc;
+        hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3(HW), dim3(256), 0, s, S, HW, 1.0f / sqrtf((float)C));
+        if ((rc = conv(S, "", o + (size_t)b * HW * C, nullptr, 1, HW, 1, HW, C, 1, 0, s, vt + (size_t)b * HW * C, nullptr, true))) return rc;
+      }
+      if ((rc = conv(o, a + "to_out.0", x, y, B, HW, 1, C, C, 1, 0, s))) return rc;  // + residual (input of the attention)
+    }
+    if ((rc = resnet("decoder.mid_block.resnets.1.", x, y, t, bufD, B, H, Wd, 512, 512, s))) return rc;
+    // ---- up blocks (ping-pong x <-> y)
+    const int chans[4] = {512, 512, 256, 128};
+    int prev = 512;
+    T* cur = y;
+    T* oth = x;
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        const std::string p = "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".";
+        if ((rc = resnet(p, cur, oth, t, bufD, B, H, Wd, j == 0 ? prev : chans[i], chans[i], s))) return rc;
+        std::swap(cur, oth);
+      }
+      if (i < 3) {
+        H *= 2; Wd *= 2;
+        if ((rc = conv(cur, "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", oth, nullptr, B, H, Wd, chans[i], chans[i], 9, 1, s))) return rc;
+        std::swap(cur, oth);
+      }
+      prev = chans[i];
+    }
+    // conv_norm_out's apply + SiLU is fused into the conv_out kernel's halo staging
+    group_norm_stats(cur, "decoder.conv_norm_out", B, H * Wd, 128, s);
+    hipLaunchKernelGGL((vae_conv_out_kernel<T>), dim3((H / CO_TH) * (Wd / CO_TW), B), dim3(256), 0, s, cur, gn_scale, gn_shift, W_<T>("decoder.conv_out.weight"),
+                       W_<float>("decoder.conv_out.bias"), out, B, H, Wd);
+    VHIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+};
+
+}  // namespace ecad
+
+using namespace ecad;
+struct EcadVae { VaeBase* impl; };
+
+extern "C" {
+int ecad_vae_create(int device, int dtype, EcadVae** out) {
+  if (!out) return ECAD_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_vae_create_error = "no HIP device visible"; return ECAD_E_HIP; }
+  VaeBase* impl = nullptr;
+  if (dtype == ECAD_DTYPE_F16) impl = new VaeT<f16_t>();
+  else if (dtype == ECAD_DTYPE_BF16) impl = new VaeT<bf16_t>();
+  else { g_vae_create_error = "dtype must be f16 or bf16"; return ECAD_E_INVALID; }
+  impl->dev = device;
+  int rc = impl->init();
+  if (rc) { g_vae_create_error = impl->err; delete impl; return rc; }
+  *out = new EcadVae{impl};
+  return ECAD_OK;
+}
+void ecad_vae_destroy(EcadVae* v) { if (v) { delete v->impl; delete v; } }
+const char* ecad_vae_last_error(const EcadVae* v) { return v ? v->impl->err.c_str() : g_vae_create_error.c_str(); }
+int ecad_vae_load_weights(EcadVae* v, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) {
+  if (!v || !name || !ptr || !shape) return ECAD_E_INVALID;
+  return v->impl->load(name, ptr, dtype, shape, ndim);
+}
+int ecad_vae_finalize_weights(EcadVae* v) { return v ? v->impl->finalize() : ECAD_E_INVALID; }
+int ecad_vae_decode(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, uint8_t* out_u8_dev, void* stream) {
+  if (!v || !latents_dev || !out_u8_dev) return ECAD_E_INVALID;
+  return v->impl->decode(latents_dev, B, h, w, scaling_factor, out_u8_dev, (hipStream_t)stream);
+}
+}

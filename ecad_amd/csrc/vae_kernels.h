@@ -1,0 +1,407 @@
+// vae_kernels.h -- kernels of the AutoencoderKL decoder tail (VAE decode + postprocess, inside the
+// reference's timed region at ecad/pipelines/pass_through.py:382-396 / pixart_image_generator.py:405-438).
+// Activations are NHWC fp16/bf16 so a 3x3 convolution is an implicit GEMM with K-contiguous operands:
+//   out[(b,y,x)][co] = sum_{tap, ci} in[(b, y+dy, x+dx)][ci] * w[co][tap][ci]
+// and the A tile of one K-step (64 channels of one tap) is gathered by LDS-DMA with a per-lane source address; rows
+// that fall into the zero padding point at a zero page.  Nearest-2x upsampling in front of a conv is folded into the
+// address generator ((y+dy)>>1, (x+dx)>>1).
+#pragma once
+#include "common.h"
+
+namespace ecad {
+
+struct ConvArgs {
+  const void* in;     // [B, Hin, Win, Cin]
+  const void* w;      // [Cout][taps][Cin]
+  const float* bias;  // [Cout]
+  const void* resid;  // [B, H, W, Cout] or null: out = conv + bias + resid
+  void* out;          // [B, H, W, Cout]
+  const void* zero_page;  // >= 128 bytes of zeros
+  int B, H, W;        // OUTPUT spatial size
+  int Cin, Cout, taps;  // taps = 9 (3x3, pad 1) or 1 (1x1 / linear)
+  int up;             // 1: input is [B, H/2, W/2, Cin], nearest-upsampled on the fly
+};
+
+// 128 x 128 x 64 tile, 4 waves (2 x 2, 64 x 64 each), 2-stage LDS ring; same LDS image / swizzle / epilogue as gemm.h.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
+  constexpr int BM = 128, BN = 128, BK = 64, FM = 4, FN = 4;
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+  constexpr int A_INST = 4, B_INST = 4, CS = BN + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int M = p.B * p.H * p.W;
+  const int tiles_n = p.Cout / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int K = p.taps * p.Cin;
+  const int Hin = p.up ? p.H >> 1 : p.H, Win = p.up ? p.W >> 1 : p.W;
+  const T* in = reinterpret_cast<const T*>(p.in);
+  const T* wgt = reinterpret_cast<const T*>(p.w);
+
+  // this lane's A rows (output pixels) and its 16-byte chunk inside the 64-channel K-step
+  int pb[A_INST], py[A_INST], px[A_INST], pc[A_INST];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    int m = m0 + r;
+    m = m < M ? m : M - 1;
+    pb[i] = m / (p.H * p.W);
+    const int rem = m - pb[i] * p.H * p.W;
+    py[i] = rem / p.W;
+    px[i] = rem - py[i] * p.W;
+    pc[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  }
+  const T* b_src[B_INST];
+#pragma unroll
+  for (int i = 0; i < B_INST; ++i) {
+    const int r = (wave * B_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = wgt + (size_t)(n0 + r) * K + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* abase = smem + buf * STAGE_BYTES;
+    char* bbase = abase + A_BYTES;
+    const int k0 = kt * BK;
+    const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap % 3 - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      const int sy = p.up ? yy >> 1 : yy, sx = p.up ? xx >> 1 : xx;
+      const T* src = ok ? in + ((size_t)(pb[i] * Hin + sy) * Win + sx) * p.Cin + c0 + pc[i] : reinterpret_cast<const T*>(p.zero_page) + (pc[i] & 56);
+      glds16(src, abase + (wave * A_INST + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+      glds16(b_src[i], bbase + (wave * B_INST + i) * 1024);
+      b_src[i] += BK;
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wm * 64 + l15) * 128, b_row_off = (wn * 64 + l15) * 128;
+  const int nk = K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+    const char* abase = smem + buf * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + g) ^ swz) * 16;
+      Pack8 af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // epilogue: bias in fp32, round, C tile through LDS, 16-byte row stores (+ residual)
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nl = wn * 64 + 16 * j + 4 * g;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wm * 64 + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) float_to_elem4<T>(o, r, acc[i][j][r] + bv[r]);
+      *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
+    }
+  }
+  __syncthreads();
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* res = reinterpret_cast<const T*>(p.resid);
+  const int cchunk = tid & 15, crow0 = tid >> 4;
+#pragma unroll 4
+  for (int pass = 0; pass < 8; ++pass) {
+    const int ml = pass * 16 + crow0;
+    const int m = m0 + ml;
+    if (m >= M) break;
+    Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+    const size_t off = (size_t)m * p.Cout + n0 + cchunk * 8;
+    if (res) {
+      float a[8], b[8];
+      unpack8<T>(v, a);
+      unpack8<T>(gload16(res + off), b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+      v = pack8<T>(a);
+    }
+    gstore16(out + off, v);
+  }
+}
+
+// ---- GroupNorm statistics over NHWC: sums[b][group][2] += (sum x, sum x^2).  Per-thread partials are folded per group through
+// LDS atomics (ds_add_f32), so a block issues only 2 * groups global atomics (the first version issued 16 per thread onto
+// C * 2 addresses and ran at 1 ms per call on contention alone).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, int HW, int C, int groups, int pix_per_block) {
+  __shared__ float red[64];
+  const int b = blockIdx.y;
+  const int cpr = C >> 3;  // 16-byte chunks per pixel
+  const int cg = C / groups;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  // thread t owns channel chunk t % cpr and walks pixels with stride 256 / cpr
+  const int c = threadIdx.x % cpr, pstep = 256 / cpr, pofs = threadIdx.x / cpr;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  if (pofs < pstep) {
+    const T* xp = x + ((size_t)b * HW + p0 + pofs) * C + c * 8;
+    const size_t stride = (size_t)pstep * C;
+    int pix = p0 + pofs;
+    for (; pix + 3 * pstep < p1; pix += 4 * pstep, xp += 4 * stride) {  // 4 loads in flight per lane
+      const Pack8 r0 = gload16(xp), r1 = gload16(xp + stride), r2 = gload16(xp + 2 * stride), r3 = gload16(xp + 3 * stride);
+      float v[8];
+#define ECAD_GN_ACC(r)                        \
+  unpack8<T>(r, v);                           \
+  _Pragma("unroll") for (int e = 0; e < 8; ++e) { \
+    s[e] += v[e];                             \
+    q[e] = __builtin_fmaf(v[e], v[e], q[e]);  \
+  }
+      ECAD_GN_ACC(r0) ECAD_GN_ACC(r1) ECAD_GN_ACC(r2) ECAD_GN_ACC(r3)
+    }
+    for (; pix < p1; pix += pstep, xp += stride) {
+      float v[8];
+      const Pack8 r0 = gload16(xp);
+      ECAD_GN_ACC(r0)
+    }
+#undef ECAD_GN_ACC
+  }
+  if (cg >= 8) {
+    float ts = 0.f, tq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ts += s[e], tq += q[e];
+    const int gidx = (c * 8) / cg;
+    atomicAdd(&red[2 * gidx], ts);
+    atomicAdd(&red[2 * gidx + 1], tq);
+  } else {  // cg == 4: the chunk spans two groups
+    const int gidx = (c * 8) / cg;
+    atomicAdd(&red[2 * gidx], s[0] + s[1] + s[2] + s[3]);
+    atomicAdd(&red[2 * gidx + 1], q[0] + q[1] + q[2] + q[3]);
+    atomicAdd(&red[2 * gidx + 2], s[4] + s[5] + s[6] + s[7]);
+    atomicAdd(&red[2 * gidx + 3], q[4] + q[5] + q[6] + q[7]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * groups) atomicAdd(&sums[(size_t)b * groups * 2 + threadIdx.x], red[threadIdx.x]);
+}
+
+// scale[b][c] = rstd * gamma[c], shift[b][c] = beta[c] - mean * rstd * gamma[c]   (eps 1e-6)
+__global__ void gn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ scale, float* __restrict__ shift, int C, int HW, int groups, float eps) {
+  const int b = blockIdx.x, c = threadIdx.x + blockIdx.y * blockDim.x;
+  if (c >= C) return;
+  const int cg = C / groups, gi = c / cg;
+  const float s = sums[((size_t)b * groups + gi) * 2], q = sums[((size_t)b * groups + gi) * 2 + 1];
+  const float n = (float)HW * (float)cg;
+  const float mean = s / n;
+  const float var = fmaxf(q / n - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  scale[(size_t)b * C + c] = rstd * gamma[c];
+  shift[(size_t)b * C + c] = beta[c] - mean * rstd * gamma[c];
+}
+
+// y = act(x * scale[b][c] + shift[b][c]); act = SiLU (resnets, output norm) or identity (attention group_norm)
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, size_t total_chunks, int HW, int C) {
+  const int cpr = C >> 3;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_chunks; idx += (size_t)gridDim.x * 256) {
+    const size_t pix = idx / cpr;
+    const int c = (int)(idx - pix * cpr) * 8;
+    const int b = (int)(pix / HW);
+    float v[8];
+    unpack8<T>(gload16(x + idx * 8), v);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c), s1 = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + (size_t)b * C + c), h1 = *reinterpret_cast<const f32x4*>(shift + (size_t)b * C + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = v[e] * s0[e] + h0[e];
+      v[4 + e] = v[4 + e] * s1[e] + h1[e];
+    }
+    if (SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+    }
+    gstore16(y + idx * 8, pack8<T>(v));
+  }
+}
+
+// ---- first layer: latents fp32 NCHW [B,4,h,w] / scaling -> post_quant_conv (1x1, 4->4) -> conv_in (3x3, 4->C) -> NHWC
+// A block owns CIN_PIX consecutive pixels of one image; each thread keeps the 36 weights of its channel(s) in registers.
+constexpr int CIN_PIX = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restrict__ lat, const float* __restrict__ pq_w, const float* __restrict__ pq_b,
+                                                          const float* __restrict__ w /*[C][4][3][3]*/, const float* __restrict__ bias, T* __restrict__ out,
+                                                          int B, int H, int W, int C, float inv_scale) {
+  const int pix0 = blockIdx.x * CIN_PIX, b = blockIdx.y;
+  __shared__ float z[CIN_PIX][36];  // [pixel][ci * 9 + tap]: post_quant_conv output at the 9 neighbours (0 outside the image)
+  for (int id = threadIdx.x; id < CIN_PIX * 36; id += 256) {
+    const int pl = id / 36, k = id % 36, co = k / 9, tap = k % 9;
+    const int pix = pix0 + pl;
+    const int y = pix / W, x = pix % W;
+    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+    float v = 0.f;
+    if (pix < H * W && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      v = pq_b[co];
+      for (int ci = 0; ci < 4; ++ci) v += pq_w[co * 4 + ci] * lat[(((size_t)b * 4 + ci) * H + yy) * W + xx] * inv_scale;
+    }
+    z[pl][k] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wr[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) wr[k] = w[c * 36 + k];
+    const float bc = bias[c];
+    for (int pl = 0; pl < CIN_PIX && pix0 + pl < H * W; ++pl) {
+      float a = bc;
+#pragma unroll
+      for (int k = 0; k < 36; ++k) a = __builtin_fmaf(wr[k], z[pl][k], a);
+      out[((size_t)b * H * W + pix0 + pl) * C + c] = (T)a;
+    }
+  }
+}
+
+// ---- last layer: conv_norm_out (apply + SiLU) + conv_out 3x3 (128 -> 3) + (v/2 + 0.5) clamp -> uint8 NHWC (PIL-ready).
+// A block owns an 8 x 16 tile of output pixels of one image.  The 10 x 18 halo of the RAW pre-norm activations is normalised,
+// SiLU'd and staged once in LDS (pixel stride 272 B so the 16 lanes of a fragment read hit 16 distinct 4-bank groups); the conv is
+// an MFMA GEMM [pixels x (9 taps * 128)] x [(9 * 128) x 16] with the 3 real output channels in rows 0..2 of a zero-padded weight
+// whose 36 B-fragments live in registers for the whole block.  Wave w owns tile rows 2w and 2w+1 (one 16-pixel fragment each).
+constexpr int CO_TH = 8, CO_TW = 16, CO_C = 128, CO_PIX_BYTES = CO_C * 2 + 16, CO_HALO_W = CO_TW + 2, CO_HALO_H = CO_TH + 2;
+constexpr int CO_LDS_BYTES = CO_HALO_H * CO_HALO_W * CO_PIX_BYTES;  // 48960
+template <typename T>
+__global__ __launch_bounds__(256) void vae_conv_out_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const T* __restrict__ w /*[16][9][128], rows 3..15 zero*/, const float* __restrict__ bias,
+                                                           uint8_t* __restrict__ out, int B, int H, int W) {
+  __shared__ __attribute__((aligned(16))) char halo[CO_LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int tiles_x = W / CO_TW;
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * CO_TH, x0 = tx * CO_TW;
+
+  // weights: B fragment ks (tap = ks / 4, channels (ks % 4) * 32 + g * 8 ..) of output row l15
+  Pack8 wf[36];
+#pragma unroll
+  for (int ks = 0; ks < 36; ++ks) wf[ks] = gload16(w + (size_t)l15 * (9 * CO_C) + ks * 32 + g * 8);
+
+  // stage the halo: thread -> channel chunk tid % 16 (its scale/shift stay in registers), pixel tid / 16 + 16 * it
+  {
+    const int ch = tid & 15;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = scale[(size_t)b * CO_C + ch * 8 + e];
+      sh[e] = shift[(size_t)b * CO_C + ch * 8 + e];
+    }
+    for (int hp = tid >> 4; hp < CO_HALO_H * CO_HALO_W; hp += 16) {
+      const int hy = hp / CO_HALO_W, hx = hp - hy * CO_HALO_W;
+      const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      Pack8 v;
+      v.u = (u32x4){0u, 0u, 0u, 0u};
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        float f[8];
+        unpack8<T>(gload16(x + (((size_t)b * H + yy) * W + xx) * CO_C + ch * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = silu(f[e] * sc[e] + sh[e]);
+        v = pack8<T>(f);
+      }
+      *reinterpret_cast<u32x4*>(halo + hp * CO_PIX_BYTES + ch * 16) = v.u;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[2];
+  acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int hp = (wave * 2 + f + dy) * CO_HALO_W + l15 + dx;
+        const Pack8 af = lds_read16(halo + hp * CO_PIX_BYTES + (kc * 4 + g) * 16);
+        acc[f] = mfma16<T>(wf[tap * 4 + kc], af, acc[f]);
+      }
+    }
+  }
+  // lane (l15, g = 0) holds output channels 0..3 (3 real) of pixel l15 of each fragment
+  if (g == 0) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int yy = y0 + wave * 2 + f, xx = x0 + l15;
+      uint8_t* o = out + (((size_t)b * H + yy) * W + xx) * 3;
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const float v = acc[f][n] + bias[n];
+        o[n] = (uint8_t)__float2int_rn(fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f) * 255.f);
+      }
+    }
+  }
+}
+
+// ---- mid-block attention helpers (one head of C = 512 over HW = h*w tokens)
+// row softmax of S[rows][n] (fp16/bf16 in place), scale applied first
+template <typename T> __global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ s, int n, float scale) {
+  T* row = s + (size_t)blockIdx.x * n;
+  __shared__ float red[4];
+  float m = -1e30f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, (float)row[i] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) sum += __expf((float)row[i] * scale - m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = threadIdx.x; i < n; i += 256) row[i] = (T)(__expf((float)row[i] * scale - m) * inv);
+}
+
+// out[c][r] = in[r][c]  (rows x cols -> cols x rows), per batch slice blockIdx.z
+template <typename T> __global__ void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, int cols) {
+  __shared__ T tile[32][33];
+  const size_t base = (size_t)blockIdx.z * rows * cols;
+  int r = blockIdx.y * 32 + threadIdx.y, c = blockIdx.x * 32 + threadIdx.x;
+  for (int k = 0; k < 32; k += 8)
+    if (r + k < rows && c < cols) tile[threadIdx.y + k][threadIdx.x] = in[base + (size_t)(r + k) * cols + c];
+  __syncthreads();
+  r = blockIdx.x * 32 + threadIdx.y;
+  c = blockIdx.y * 32 + threadIdx.x;
+  for (int k = 0; k < 32; k += 8)
+    if (r + k < cols && c < rows) out[base + (size_t)(r + k) * rows + c] = tile[threadIdx.x][threadIdx.y + k];
+}
+
+}  // namespace ecad

@@ -127,6 +127,15 @@ class PixArtAlphaPipeline:
 
     def decode(self, latents: torch.Tensor, output_type: str = "pil"):
         """VAE decode when a VAE module is attached (stays PyTorch/MIOpen); otherwise a linear latent->RGB preview."""
+        if self.vae is not None and hasattr(self.vae, "decode_to_uint8"):  # native decoder: latents -> uint8 NHWC in one call
+            arr = self.vae.decode_to_uint8(latents).cpu().numpy()
+            if output_type == "np":
+                return arr
+            if output_type == "pt":
+                return torch.from_numpy(arr).permute(0, 3, 1, 2).float() / 255.0
+            from PIL import Image
+
+            return [Image.fromarray(a) for a in arr]
         if self.vae is not None:
             img = self.vae.decode(latents / getattr(self.vae.config, "scaling_factor", 0.13025), return_dict=False)[0]
         else:

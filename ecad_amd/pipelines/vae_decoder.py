@@ -116,3 +116,66 @@ class AutoencoderKLDecoderOnly(nn.Module):
     def random_init(cls, seed: int = 0, device="cuda", dtype=torch.float16, **kw) -> "AutoencoderKLDecoderOnly":
         torch.manual_seed(seed)
         return cls(**kw).to(device=device, dtype=dtype).to(memory_format=torch.channels_last).eval()
+
+
+class HipVaeDecoder:
+    """The same decoder on the native engine (``ecad_vae_*`` in include/ecad_hip.h): latents in, uint8 NHWC RGB out.
+
+    ``decode_to_uint8`` is what the pipeline uses for ``output_type="pil"``; ``from_torch`` copies the weights of a
+    PyTorch ``AutoencoderKLDecoderOnly`` (or any state dict with diffusers' AutoencoderKL keys).
+    """
+
+    def __init__(self, scaling_factor: float = 0.18215, dtype: torch.dtype = torch.float16, device: int = 0):
+        import ctypes as C
+
+        from ecad_amd import _lib as L
+
+        self._C, self._L = C, L
+        self.lib = L.load()
+        self.dtype, self.device_index = dtype, device
+        self.config = SimpleNamespace(scaling_factor=scaling_factor, latent_channels=4)
+        self._h = C.c_void_p()
+        rc = self.lib.ecad_vae_create(device, L.ECAD_DTYPE_F16 if dtype == torch.float16 else L.ECAD_DTYPE_BF16, C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError((self.lib.ecad_vae_last_error(None) or b"ecad_vae_create failed").decode())
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            msg = (self.lib.ecad_vae_last_error(self._h) or b"error").decode()
+            raise ValueError(msg) if rc in (self._L.ECAD_E_INVALID, self._L.ECAD_E_UNSUPPORTED) else RuntimeError(msg)
+
+    def load_state_dict(self, state) -> "HipVaeDecoder":
+        C, L = self._C, self._L
+        codes = {torch.float16: L.ECAD_DTYPE_F16, torch.bfloat16: L.ECAD_DTYPE_BF16, torch.float32: L.ECAD_DTYPE_F32}
+        for name, t in state.items():
+            t = t.detach().contiguous()
+            if t.dtype not in codes:
+                t = t.float()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            self._chk(self.lib.ecad_vae_load_weights(self._h, name.encode(), t.data_ptr(), codes[t.dtype], shape, t.dim()))
+        self._chk(self.lib.ecad_vae_finalize_weights(self._h))
+        return self
+
+    @classmethod
+    def from_torch(cls, module: "AutoencoderKLDecoderOnly", device: int = 0, dtype: torch.dtype = torch.float16) -> "HipVaeDecoder":
+        return cls(module.config.scaling_factor, dtype, device).load_state_dict(module.state_dict())
+
+    def decode_to_uint8(self, latents: torch.Tensor, stream=None) -> torch.Tensor:
+        """latents: [B, 4, h, w] (un-scaled pipeline latents) -> uint8 [B, 8h, 8w, 3] on the device."""
+        lat = latents.to(device=torch.device("cuda", self.device_index), dtype=torch.float32).contiguous()
+        B, _, h, w = lat.shape
+        out = torch.empty((B, 8 * h, 8 * w, 3), dtype=torch.uint8, device=lat.device)
+        st = torch.cuda.current_stream() if stream is None else stream
+        self._chk(self.lib.ecad_vae_decode(self._h, lat.data_ptr(), B, h, w, float(self.config.scaling_factor), out.data_ptr(), int(st.cuda_stream)))
+        return out
+
+    def close(self):
+        if self._h and self._h.value:
+            self.lib.ecad_vae_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -145,6 +145,20 @@ int ecad_op_cache_accumulate(EcadEngine* e, void* h, int M, int D, int n_src, co
 int ecad_op_attention(EcadEngine* e, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo,
                       int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream);
 
+/* ---- decode tail: AutoencoderKL decoder + postprocess ------------------------------------------------
+ * Replaces `self.vae.decode(latents / scaling_factor)` and `image_processor.postprocess(..., "pil")` inside the reference's
+ * timed region (ecad/pipelines/pass_through.py:382-396).  SD / sd-vae-ft-ema geometry; weight names are diffusers'
+ * AutoencoderKL state-dict keys ("decoder.up_blocks.1.resnets.0.conv1.weight", ...); encoder.* / quant_conv.* are ignored. */
+typedef struct EcadVae EcadVae;
+int ecad_vae_create(int device, int dtype, EcadVae** out);
+void ecad_vae_destroy(EcadVae* v);
+const char* ecad_vae_last_error(const EcadVae* v);
+int ecad_vae_load_weights(EcadVae* v, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim);
+int ecad_vae_finalize_weights(EcadVae* v);
+/* latents_dev: [B, 4, h, w] float32 (un-scaled, as the pipeline holds them); out_u8_dev: [B, 8h, 8w, 3] uint8 RGB = the bytes
+ * PIL.Image.fromarray wants, after (x / 2 + 0.5).clamp(0, 1) * 255 rounding. */
+int ecad_vae_decode(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, uint8_t* out_u8_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ def _ref_uint8(vae, latents):
     return ((img / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("B,h,w", [(2, 16, 8), (1, 32, 32)])
+@pytest.mark.parametrize("B,h,w", [(2, 16, 8), (1, 32, 32), (3, 32, 32)])
 def test_hip_vae_decoder_matches_pytorch(B, h, w):
     from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
 

@@ -26,6 +26,14 @@ class PixArtPromptEmbedding(PromptEmbedding):
     negative_prompt_attention_mask: torch.Tensor
 
 
+class FluxPromptEmbedding(PromptEmbedding):
+    """Reference: ecad/types.py:20-35 (text_ids is recomputed at generation time and may be None)."""
+
+    prompt_embeds: torch.Tensor
+    pooled_prompt_embeds: torch.Tensor
+    text_ids: "torch.Tensor | None"
+
+
 class PipelineConfig(TypedDict):
     name: str
     kwargs: dict[str, Any]
@@ -53,6 +61,20 @@ class PixArtComponentScheduleDict(TypedDict):
     custom_compute_ff: NotRequired[CustomFuncDict]
 
 
+class FluxSingleComponentScheduleDict(TypedDict):
+    single_attn: bool
+    single_proj_mlp: bool
+    single_proj_out: bool
+
+
+class FluxFullComponentScheduleDict(TypedDict):
+    full_attn: bool
+    full_ff: bool
+    full_ff_context: bool
+
+
+FluxBlockScheduleDict = dict[str, Any]
+FluxCacheScheduleDict = dict[int, FluxBlockScheduleDict]
 PixArtBlockScheduleDict = dict[str, PixArtComponentScheduleDict]
 PixArtCacheScheduleDict = dict[int, PixArtBlockScheduleDict]
 CacheScheduleDict = dict[int, dict[str, Any]]

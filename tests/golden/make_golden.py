@@ -11,6 +11,10 @@ Outputs (data only -- inputs and expected outputs):
                                      schedule / population classes
   schedules/...                      the schedule JSON data files the bench / tests use
                                      (re-serialised through the reference's to_dict)
+  tests/golden/flux_mac_kat.npz      the same known answers for every FLUX schedule JSON
+                                     with metrics.by_inference_step (bits via the
+                                     reference's FluxCacheSchedule.to_numpy)
+  tests/golden/flux_vectors.json     FluxCacheSchedule / FluxPopulationIOManager vectors
 """
 import hashlib
 import json
@@ -175,6 +179,92 @@ def schedule_vectors():
         print(f"ga_seed_population: {len(cands)} candidates")
 
 
+def flux_golden():
+    from ecad.genetic.flux_population_io_manager import FluxPopulationIOManager
+    from ecad.schedulers.cache_scheduler.flux_cache_schedule import FluxCacheSchedule
+    from ecad.schedulers.cache_scheduler.generators.flux_schedule_generators import gen_default as flux_gen_default
+
+    def load(path):  # CacheSchedule.from_json does not forward num_single_blocks for every version of the file; be explicit
+        with open(path) as f:
+            d = json.load(f)
+        cs = d["cache_schedule"]
+        sch = cs["schedule"]
+        if len(sch) != cs["num_inference_steps"]:  # gen_default/default_1024x1024_gs_5.0_steps_08.json lists 50 steps but declares (and was measured with) 8
+            sch = {k: v for k, v in sch.items() if int(k) < cs["num_inference_steps"]}
+        return d, FluxCacheSchedule(
+            num_blocks=cs["num_blocks"], num_inference_steps=cs["num_inference_steps"], name=cs["name"], schedule=sch,
+            top_level_config=d.get("config"), attributes=cs.get("attributes"), metrics=d.get("metrics"), num_single_blocks=cs["num_single_blocks"])
+
+    names, bits, macs, geom = [], [], [], []
+    for p in sorted((REF / "schedules").rglob("*.json")):
+        rel = str(p.relative_to(REF / "schedules"))
+        if "flux" not in rel:
+            continue
+        with open(p) as f:
+            d = json.load(f)
+        m = (d.get("metrics") or {}).get("by_inference_step")
+        if not m or "cache_schedule" not in d:
+            continue
+        d, sched = load(p)
+        b = sched.to_numpy()
+        cfg = d.get("config") or {}
+        names.append(rel)
+        bits.append(np.packbits(b))
+        macs.append([m[f"{s:03}"]["macs"] for s in range(sched.num_inference_steps)])
+        geom.append([cfg.get("height", 256), cfg.get("width", 256), sched.num_blocks, sched.num_single_blocks, sched.num_inference_steps])
+    width = max(b.size for b in bits)  # step counts differ (8 / 20): pad the packed rows
+    bits = [np.pad(b, (0, width - b.size)) for b in bits]
+    macs = [mm + [0] * (max(len(q) for q in macs) - len(mm)) for mm in macs]
+    np.savez_compressed(OUT / "flux_mac_kat.npz", names=np.array(names), bits=np.stack(bits), macs=np.array(macs, dtype=np.int64), geom=np.array(geom, dtype=np.int64))
+    print(f"flux_mac_kat: {len(names)} schedules")
+
+    out = {}
+    named = {
+        "flux_256_ours_fast": "schedules_in_paper/flux_256/ours_fast.json",
+        "flux_256_ours_faster": "schedules_in_paper/flux_256/ours_faster.json",
+        "flux_1024_fast": "schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json",
+        "flux_1024_slow": "schedules_in_paper/flux_256_to_1024/slow_256_to_1024.json",
+    }
+    vec = {}
+    for key, rel in named.items():
+        d, sched = load(REF / "schedules" / rel)
+        dst = REPO / "schedules" / rel
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        sched.to_json(dst)  # data file, re-serialised through the reference's own to_dict
+        b = sched.to_numpy()
+        vec[key] = {"path": rel, "packed_hex": np.packbits(b).tobytes().hex(), "sum": int(b.sum()), "n": int(b.size),
+                    "sha256_of_bits": hashlib.sha256(b.astype(np.uint8).tobytes()).hexdigest(), "name": sched.name,
+                    "config": d.get("config"), "total_macs": d["metrics"]["total_macs"]}
+    out["to_numpy"] = vec
+    d, sched = load(REF / "schedules" / named["flux_1024_fast"])
+    dd = sched.to_dict()
+    out["to_dict_shape"] = {
+        "top_keys": list(dd.keys()), "cache_schedule_keys": list(dd["cache_schedule"].keys()),
+        "block_keys_step0": list(dd["cache_schedule"]["schedule"]["000"].keys()),
+        "entry_002_3": dd["cache_schedule"]["schedule"]["002"]["3"], "entry_002_single_5": dd["cache_schedule"]["schedule"]["002"]["single_5"],
+    }
+    out["components"] = sched.components
+    trace = []
+    sched.reset_step()
+    for s in range(20):
+        trace.append([sched.curr_step, bool(sched.get_recompute("3", "full_ff")), bool(sched.get_recompute("single_7", "single_proj_out"))])
+        sched.per_step_callback(s, 0)
+    out["step_trace"] = trace
+    rng = np.random.default_rng(4321)
+    n = 20 * (19 + 38) * 3
+    x = rng.integers(0, 2, size=n).astype(np.bool_)
+    sd = FluxPopulationIOManager.binary_vector_to_schedule_dict(x, 20, 19, 38, 3, 3)
+    rt = FluxCacheSchedule(19, 20, "rt", sd, num_single_blocks=38).to_numpy()
+    out["population"] = {"seed": 4321, "x_packed_hex": np.packbits(x).tobytes().hex(), "roundtrip_equal": bool((rt == x).all()),
+                         "entry_step5_block7": sd[5]["7"], "entry_step5_single_30": sd[5]["single_30"]}
+    d0 = next(flux_gen_default(19, 38, 20, 1024, 1024, 5))
+    out["default_schedule"] = {"name": d0.name, "all_true": bool(d0.to_numpy().all()), "n": int(d0.to_numpy().size), "config": d0.top_level_config}
+    with open(OUT / "flux_vectors.json", "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("flux_vectors.json written")
+
+
 if __name__ == "__main__":
     mac_kat()
     schedule_vectors()
+    flux_golden()

@@ -59,11 +59,50 @@ class EcadStats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class EcadFluxCfg(C.Structure):
+    _fields_ = [
+        ("num_layers", C.c_int32),
+        ("num_single_layers", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("head_dim", C.c_int32),
+        ("in_channels", C.c_int32),
+        ("joint_attention_dim", C.c_int32),
+        ("pooled_projection_dim", C.c_int32),
+        ("guidance_embeds", C.c_int32),
+        ("axes_dims_rope", C.c_int32 * 3),
+        ("max_batch", C.c_int32),
+        ("max_image_tokens", C.c_int32),
+        ("max_text_tokens", C.c_int32),
+        ("dtype", C.c_int32),
+        ("norm_eps", C.c_float),
+    ]
+
+
+class EcadFluxStats(C.Structure):
+    _fields_ = [
+        ("components_executed", C.c_int64),
+        ("components_cached", C.c_int64),
+        ("components_dead", C.c_int64),
+        ("linear_macs_reference", C.c_int64),
+        ("linear_macs_executed", C.c_int64),
+        ("attn_core_macs", C.c_int64),
+        ("cache_arena_bytes", C.c_int64),
+        ("weight_bytes", C.c_int64),
+        ("workspace_bytes", C.c_int64),
+        ("graph_nodes", C.c_int32),
+        ("launches_per_batch", C.c_int32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 _P = C.c_void_p
 _I = C.c_int
 _I64 = C.c_int64
+_F = C.c_float
 
-# name -> (restype, argtypes); every symbol include/ecad_hip.h declares
+# name -> (restype, argtypes); every symbol include/ecad_hip.h and include/ecad_flux.h declare
 SIGNATURES = {
     "ecad_abi_version": (_I, []),
     "ecad_create": (_I, [C.POINTER(EcadModelCfg), _I, C.POINTER(_P)]),
@@ -89,6 +128,24 @@ SIGNATURES = {
     "ecad_vae_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
     "ecad_vae_finalize_weights": (_I, [_P]),
     "ecad_vae_decode": (_I, [_P, _P, _I, _I, _I, C.c_float, _P, _P]),
+    # include/ecad_flux.h
+    "ecad_flux_create": (_I, [C.POINTER(EcadFluxCfg), _I, C.POINTER(_P)]),
+    "ecad_flux_destroy": (None, [_P]),
+    "ecad_flux_last_error": (C.c_char_p, [_P]),
+    "ecad_flux_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
+    "ecad_flux_finalize_weights": (_I, [_P]),
+    "ecad_flux_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _I]),
+    "ecad_flux_begin_image_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
+    "ecad_flux_step": (_I, [_P, _I, _P, _F, _F, _P, _P]),
+    "ecad_flux_run_schedule": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, C.POINTER(_F), _F, C.POINTER(_F), _I, _P]),
+    "ecad_flux_reset_cache": (_I, [_P]),
+    "ecad_flux_stats": (_I, [_P, C.POINTER(EcadFluxStats)]),
+    "ecad_flux_set_profiling": (_I, [_P, _I]),
+    "ecad_flux_get_profile": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ecad_flux_op_gemm": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I64, _I, _I, _I, _P]),
+    "ecad_flux_op_qk_norm_rope": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "ecad_flux_op_attention": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ecad_flux_op_ln_modulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I64, _P]),
 }
 
 _lib = None

@@ -17,6 +17,11 @@
 //   ds_read_b64_tr_b16 in the same permuted order); column 72 of the padded V tile is all ones, so the softmax
 //   denominator is accumulated by the same MFMAs (O^T row 72) -- no VALU row sums;
 //   chunks are combined with the usual running-max rescale (only matters for N > KC, i.e. 1024^2 images).
+//
+// DHC selects the head-dim class: 72 (PixArt: K padded to 96, V to 80) or 128 (FLUX joint attention over
+// [text | image] rows, cached_flux_transformer_block.py:178-182 / 63-66: K 128 (+8 pad), V 128 + ones column -> 144).
+// seg_t > 0 switches the row addressing to the two-segment joint layout of flux.hip: sequence position r of sample b
+// lives at row b*seg_t + r (text, r < seg_t) or seg_bt + b*(N - seg_t) + (r - seg_t) (image).
 #pragma once
 #include "common.h"
 
@@ -31,17 +36,25 @@ struct AttnArgs {
   int64_t ldq, ldk, ldv, ldo;  // row strides in elements
   int B, H, Nq, Nk, dh;
   float scale_log2e;  // (1/sqrt(dh)) * log2(e)
+  int seg_t, seg_bt;  // 0, 0: plain [B, N] rows; else the joint [text | image] layout (same for q, k, v, out)
 };
 
-constexpr int ATT_KS = 104;       // K tile row stride (elements): 96 padded head dim + 8
-constexpr int ATT_VS = 80;        // V tile row stride (elements): head dim padded to 80 (column dh = ones)
+template <int DHC> struct AttCfg;
+template <> struct AttCfg<72> { static constexpr int KSTEPS = 3, ND = 5, KS = 104, VS = 80, NCH = 9; };    // K: 96 padded + 8; V: 80 (col 72 = ones)
+template <> struct AttCfg<128> { static constexpr int KSTEPS = 4, ND = 9, KS = 136, VS = 152, NCH = 16; };  // K: 128 + 8; V: 144 (col 128 = ones) + 8
 constexpr int ATT_QB = 256;       // query rows per work item (8 waves x 16 rows x 2 rounds)
 constexpr float ATT_NEG = -1.0e30f;
 
-template <int KC> constexpr int attn_lds_bytes() { return KC * (ATT_KS + ATT_VS) * 2 + KC * 4; }
+template <int KC, int DHC = 72> constexpr int attn_lds_bytes() { return KC * (AttCfg<DHC>::KS + AttCfg<DHC>::VS) * 2 + KC * 4; }
 
-template <typename T, int KC, bool MASKED>
+ECAD_DEV size_t att_row(int b, int r, int n, int seg_t, int seg_bt) {
+  if (seg_t == 0) return (size_t)b * n + r;
+  return r < seg_t ? (size_t)b * seg_t + r : (size_t)seg_bt + (size_t)b * (n - seg_t) + (r - seg_t);
+}
+
+template <typename T, int KC, bool MASKED, int DHC = 72>
 __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
+  constexpr int ATT_KS = AttCfg<DHC>::KS, ATT_VS = AttCfg<DHC>::VS, KSTEPS = AttCfg<DHC>::KSTEPS, ND = AttCfg<DHC>::ND;
   extern __shared__ __attribute__((aligned(16))) char att_smem[];
   T* Ks = reinterpret_cast<T*>(att_smem);
   T* Vs = Ks + KC * ATT_KS;
@@ -55,7 +68,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
   const int dh = p.dh;
   const int nch = dh >> 3;            // 16-byte chunks per head row (9 for dh = 72)
   const int ch_per_tile = KC * nch;   // chunks in the K (or V) tile
-  constexpr int MAXL = (KC * 9 * 2 + 511) / 512;  // staging loads per thread (dh <= 72 -> 9 chunks per row)
+  constexpr int MAXL = (KC * AttCfg<DHC>::NCH * 2 + 511) / 512;  // staging loads per thread
 
   const T* Q = reinterpret_cast<const T*>(p.q);
   const T* K = reinterpret_cast<const T*>(p.k);
@@ -87,7 +100,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
         const int key = id / nch, c = id - key * nch;
         const int gk = kc * KC + key;
         if (gk < p.Nk) {
-          const T* base = isv ? V + ((size_t)b * p.Nk + gk) * p.ldv : K + ((size_t)b * p.Nk + gk) * p.ldk;
+          const size_t grow = att_row(b, gk, p.Nk, p.seg_t, p.seg_bt);
+          const T* base = isv ? V + grow * p.ldv : K + grow * p.ldk;
           stg[i] = gload16(base + (size_t)h * dh + c * 8);
         }
       }
@@ -123,24 +137,24 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
   for (; item < items; item += gridDim.x) {
     const int qb = item % nqb, bh = item / nqb;
     const int h = bh % p.H, b = bh / p.H;
-    f32x4 oacc[2][5];
+    f32x4 oacc[2][ND];
     float m_run[2] = {ATT_NEG, ATT_NEG};
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int nd = 0; nd < 5; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nd = 0; nd < ND; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // Q fragments of both rounds (B operand of S^T = K Q^T): lane holds Q[qrow][32*ks + 8g + j]; issued before the
     // staging barriers so their latency hides behind the LDS fill
-    Pack8 qfr[2][3];
+    Pack8 qfr[2][KSTEPS];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int qrow = qb * ATT_QB + r * 128 + wave * 16 + l15;
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
+      for (int ks = 0; ks < KSTEPS; ++ks) {
         const int d = 32 * ks + 8 * g;
         qfr[r][ks].u = (u32x4){0, 0, 0, 0};
-        if (qrow < p.Nq && d + 8 <= dh) qfr[r][ks] = gload16(Q + ((size_t)b * p.Nq + qrow) * p.ldq + (size_t)h * dh + d);
+        if (qrow < p.Nq && d + 8 <= dh) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * dh + d);
       }
     }
     for (int kc = 0; kc < nkc; ++kc) {
@@ -151,14 +165,14 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
       if (kc + 1 < nkc) load_stage(item, kc + 1);
       else if (item + (int)gridDim.x < items) load_stage(item + gridDim.x, 0);
 
-      auto round = [&](const Pack8 (&qf)[3], f32x4 (&oa)[5], float& m_r) {
+      auto round = [&](const Pack8 (&qf)[KSTEPS], f32x4 (&oa)[ND], float& m_r) {
         // ---- S^T strip: NF key fragments x 16 queries, all in registers
         f32x4 s[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < 3; ++ks) {
+          for (int ks = 0; ks < KSTEPS; ++ks) {
             Pack8 kf = lds_read16(Ks + (16 * f + l15) * ATT_KS + 32 * ks + 8 * g);
             s[f] = mfma16<T>(kf, qf[ks], s[f]);
           }
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
         const float alpha = fast_exp2(m_r - m_new);
         m_r = m_new;
 #pragma unroll
-        for (int nd = 0; nd < 5; ++nd)
+        for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
           for (int e = 0; e < 4; ++e) oa[nd][e] *= alpha;
 
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
           const int krow = 32 * s2 + 4 * g + (l15 >> 2);
           const int dcol = 4 * (l15 & 3);
 #pragma unroll
-          for (int nd = 0; nd < 5; ++nd) {
+          for (int nd = 0; nd < ND; ++nd) {
             Pack4 lo = lds_read_tr16(Vs + krow * ATT_VS + 16 * nd + dcol);
             Pack4 hi = lds_read_tr16(Vs + (krow + 16) * ATT_VS + 16 * nd + dcol);
             Pack8 vf;
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
       const int dl = dh & 15;  // column dh sits in d-fragment dh/16 at (g = dl/4, e = dl%4)
       float den = 1.f;
 #pragma unroll
-      for (int nd = 0; nd < 5; ++nd)
+      for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (nd == (dh >> 4) && e == (dl & 3)) den = oacc[r][nd][e];  // static indices only: no scratch
@@ -240,9 +254,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
       const float inv = 1.0f / den;
       const int qrow = qb * ATT_QB + r * 128 + wave * 16 + l15;
       if (qrow < p.Nq) {
-        T* orow = O + ((size_t)b * p.Nq + qrow) * p.ldo + (size_t)h * dh;
+        T* orow = O + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldo + (size_t)h * dh;
 #pragma unroll
-        for (int nd = 0; nd < 5; ++nd) {
+        for (int nd = 0; nd < ND; ++nd) {
           const int d = 16 * nd + 4 * g;
           if (d + 4 <= dh) {
             Pack4 o;

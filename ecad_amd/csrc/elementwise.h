@@ -226,7 +226,7 @@ template <typename T> __global__ void silu_kernel(const T* __restrict__ x, T* __
 }
 
 // mask (1 keep / 0 discard) -> additive bias (1 - m) * -10000  (pixart_transformer_2d_edited.py:282-289)
-__global__ void mask_bias_kernel(const uint8_t* __restrict__ mask, float* __restrict__ bias, int n) {
+static __global__ void mask_bias_kernel(const uint8_t* __restrict__ mask, float* __restrict__ bias, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) bias[i] = mask ? (1.0f - (float)(mask[i] != 0)) * -10000.0f : 0.f;
 }

@@ -1,0 +1,224 @@
+// fgemm.h -- MFMA GEMM for the FLUX blocks (D = 3072 = 12 x 256: the 144-column tiles of the PixArt kernels do not divide it).
+//
+//   C[M,N] = epilogue( [A | A2][M,K] @ W[N,K]^T + bias[N] )
+//
+// Replaces the cuBLAS calls behind diffusers' FluxAttnProcessor2_0 projections, FeedForward, proj_mlp / proj_out and the
+// adaLN linears (reference call sites: ecad/transformer_blocks/cached_flux_transformer_block.py:63-66,92-93,178-182,215-216)
+// and the gated residual tails `hidden = hidden + gate * out` (:128-129,256-257,267-269,273-274,285-287).
+//
+// Same LDS image / swizzle / LDS-DMA / MFMA operand order as gemm.h.  256 x BN tile, 8 waves laid out 4 (M) x 2 (N), each
+// owning 64 x BN/2:
+//   BN = 256: 2-stage ring (128 KiB), 0.0078 B of L2->LDS traffic per flop  -- the wide tile for N = 9216 / 12288
+//   BN = 128: 3-stage ring (144 KiB), counted vmcnt                       -- N = 3072 on 8192 image rows = 768 tiles = 3.0 rounds
+// Split A: K-steps >= k_split read A2 (lda2) instead of A -- the single-stream block's proj_out consumes
+// cat([attn, gelu(mlp)]) straight from the two cache slots (cached_flux_transformer_block.py:120-127) without a concat copy.
+// Row -> sample index is segment aware: rows [0, seg0) are text rows (rows_per_batch0 each), the rest image rows
+// (rows_per_batch1 each), the layout of the joint [text | image] hidden-state matrix (flux.hip).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace ecad {
+
+enum FGemmEpi { FEPI_BIAS = 0, FEPI_BIAS_GELU = 1, FEPI_BIAS_GATE_RESID = 2, FEPI_BIAS_SILU = 3 };
+
+template <typename T> struct FGemmArgs {
+  const T* A;
+  const T* A2;        // K-steps >= k_split come from here (null: single source)
+  const T* W;
+  const float* bias;  // [N] fp32 or null
+  T* C;               // output / cache slot (may be null for FEPI_BIAS_GATE_RESID)
+  T* resid;           // FEPI_BIAS_GATE_RESID: resid[m][n] += gate[b(m)][n] * out
+  const T* gate;      // gate[b * gate_stride + n]; null => gate 1
+  int64_t gate_stride;
+  int seg0, rows_per_batch0, rows_per_batch1;
+  int M, N, K;
+  int k_split;        // in elements (multiple of 64); >= K when A2 is null
+  int lda, lda2, ldw, ldc, ldr;
+};
+
+ECAD_DEV int seg_batch(int m, int seg0, int rpb0, int rpb1) { return m < seg0 ? m / rpb0 : (m - seg0) / rpb1; }
+
+template <int BN> constexpr int fgemm_stages() { return BN == 256 ? 2 : 3; }
+template <int BN> constexpr int fgemm_lds_bytes() {
+  constexpr int ring = fgemm_stages<BN>() * (256 + BN) * 128;
+  constexpr int ctile = 256 * (BN + 8) * 2;
+  return ring > ctile ? ring : ctile;
+}
+
+template <typename T, int BN, int EPI>
+__global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
+  constexpr int BM = 256, NW = 8, STAGES = fgemm_stages<BN>();
+  constexpr int FM = 4, FN = BN / 32;  // wave tile 64 x BN/2
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+  constexpr int A_INST = BM / 8 / NW;  // 4
+  constexpr int B_INST = BN / 8 / NW;  // 4 (BN 256) or 2 (BN 128)
+  constexpr int CS = BN + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {  // blocks b, b + 8 share an XCD: give each XCD a contiguous run of tile ids
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  if ((tiles_m & 3) == 0 && (tiles_n & 3) == 0) {  // 4 x 4 patches: the 16 resident tiles of a patch share 4 A panels and 4 W panels
+    const int patch = bid >> 4, within = bid & 15;
+    const int pn = tiles_n >> 2;
+    const int patch_m = patch / pn, patch_n = patch - patch_m * pn;
+    tm = patch_m * 4 + (within >> 2);
+    tn = patch_n * 4 + (within & 3);
+  } else {
+    tm = bid / tiles_n;
+    tn = bid - tm * tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const T* a_src[A_INST];
+  const T* a2_src[A_INST];
+  const T* b_src[B_INST];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int row = m0 + r;
+    row = row < p.M ? row : p.M - 1;
+    a_src[i] = p.A + (size_t)row * p.lda + c * 8;
+    a2_src[i] = p.A2 ? p.A2 + (size_t)row * p.lda2 + c * 8 : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INST; ++i) {
+    const int r = (wave * B_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = p.W + (size_t)(n0 + r) * p.ldw + c * 8;
+  }
+  const int nk = p.K / GEMM_BK;
+  const int ksplit = p.A2 ? p.k_split / GEMM_BK : nk;
+  int kissue = 0;
+  auto issue = [&](int stage) {
+    char* abase = smem + stage * STAGE_BYTES;
+    char* bbase = abase + A_BYTES;
+    if (kissue < ksplit) {
+#pragma unroll
+      for (int i = 0; i < A_INST; ++i) {
+        glds16(a_src[i], abase + (wave * A_INST + i) * 1024);
+        a_src[i] += GEMM_BK;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_INST; ++i) {
+        glds16(a2_src[i], abase + (wave * A_INST + i) * 1024);
+        a2_src[i] += GEMM_BK;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) {
+      glds16(b_src[i], bbase + (wave * B_INST + i) * 1024);
+      b_src[i] += GEMM_BK;
+    }
+    ++kissue;
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wm * 64 + l15) * 128;
+  const int b_row_off = (wn * (BN / 2) + l15) * 128;
+
+  issue(0);
+  if (STAGES == 3 && nk > 1) issue(1);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INST + B_INST) : "memory");  // only the newest stage may still be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading the stage about to be refilled
+    if (kt + STAGES - 1 < nk) {
+      int ns = stage + STAGES - 1;
+      ns = ns >= STAGES ? ns - STAGES : ns;
+      issue(ns);
+    }
+    const char* abase = smem + stage * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + g) ^ swz) * 16;
+      Pack8 af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+    }
+    stage = stage + 1 >= STAGES ? 0 : stage + 1;
+  }
+  __syncthreads();
+
+  // ---- epilogue 1: wave's 64 x BN/2 block -> row-major C tile in LDS (bias, activation, rounding)
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nl = wn * (BN / 2) + 16 * j + 4 * g;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wm * 64 + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[r];
+        if (EPI == FEPI_BIAS_GELU) v = gelu_tanh(v);
+        if (EPI == FEPI_BIAS_SILU) v = silu(v);
+        float_to_elem4<T>(o, r, v);
+      }
+      *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: wave w streams rows 32w .. 32w+31 in 16-byte chunks
+  constexpr int CPR = BN / 8;
+  constexpr int CHUNKS = 32 * CPR;
+  for (int id = lane; id < CHUNKS; id += 64) {
+    const int rl = id / CPR, cchunk = id - rl * CPR;
+    const int ml = wave * 32 + rl;
+    const int m = m0 + ml;
+    if (m >= p.M) continue;
+    const int n = n0 + cchunk * 8;
+    Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+    if (EPI == FEPI_BIAS_GATE_RESID) {
+      if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);
+      T* rp = p.resid + (size_t)m * p.ldr + n;
+      float o[8], h[8];
+      unpack8<T>(v, o);
+      unpack8<T>(gload16(rp), h);
+      if (p.gate) {
+        float gm[8];
+        const int b = seg_batch(m, p.seg0, p.rows_per_batch0, p.rows_per_batch1);
+        unpack8<T>(gload16(p.gate + (size_t)b * p.gate_stride + n), gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += round_elem<T>(gm[e] * o[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += o[e];
+      }
+      gstore16(rp, pack8<T>(h));
+    } else {
+      gstore16(p.C + (size_t)m * p.ldc + n, v);
+    }
+  }
+}
+
+}  // namespace ecad

@@ -1,0 +1,1019 @@
+// flux.hip -- the engine behind include/ecad_flux.h: FLUX.1 cached MMDiT denoising on MI355X.
+//
+// Reference semantics implemented here (paths under /root/reference/ecad):
+//   transformer_2d_models/flux_transformer_2d_edited.py:191-214,216-326   forward (19 joint blocks, cat, 38 single blocks, norm_out, proj_out)
+//   transformer_blocks/cached_flux_transformer_block.py:103-131,233-291    block data flow; cache gate :50-101,161-231
+//   schedulers/cache_scheduler/flux_cache_schedule.py:51-88                component order / bit layout
+//   image_generators/flux_image_generator.py:330-360                       the pipeline call (FluxPipeline + FlowMatchEuler [ext])
+//
+// Layout in HBM.  Hidden states live in ONE matrix hs[B*T + B*N][D]: text rows of all samples first, image rows after.  The
+// joint blocks work on the two row ranges (different weights per stream), the single-stream blocks on the whole matrix, so the
+// reference's torch.cat([encoder_hidden_states, hidden_states], dim=1) (:204-206) costs nothing; attention addresses sequence
+// position r of sample b through att_row() (attention.h).  The adaLN linears of every block (19 x 12D + 38 x 3D + 2D rows) are one
+// stacked matrix: they depend on the timestep only, so run_schedule computes the modulation vectors of ALL steps in one GEMM
+// before the loop.  The context embedder and the pooled-text embedding are step-invariant and hoisted into begin_image_batch.
+// Caches hold what the reference caches, with one change of representation: single_proj_mlp is cached AFTER the GELU
+// (gelu(cache) == the reference's gelu of its cached pre-activation), and single_attn / single_proj_mlp cache slots ARE the operand
+// buffers of proj_out (split-A GEMM), so neither a concat nor a cache copy exists.
+#include "../../include/ecad_flux.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+#include "elementwise.h"
+#include "fgemm.h"
+#include "flux_kernels.h"
+
+namespace ecad {
+
+static std::string g_flux_create_error;
+
+#define FHIPCHK(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return fail(ECAD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+enum FClass {
+  FC_GEMM_QKV = 0, FC_GEMM_ATTN_OUT, FC_GEMM_FF1, FC_GEMM_FF2, FC_GEMM_SQKV, FC_GEMM_SMLP, FC_GEMM_SOUT, FC_GEMM_MOD, FC_GEMM_SMALL,
+  FC_ATTN, FC_ROPE, FC_LN, FC_REPLAY, FC_MISC, FC_COUNT
+};
+static const char* fclass_names[FC_COUNT] = {"gemm_joint_qkv", "gemm_joint_attn_out", "gemm_joint_ff1_gelu", "gemm_joint_ff2", "gemm_single_qkv",
+                                             "gemm_single_mlp_gelu", "gemm_single_proj_out", "gemm_adaln_all_steps", "gemm_small", "attn_joint",
+                                             "qk_norm_rope", "ln_modulate", "cache_replay", "misc"};
+
+__global__ void flux_fill_kernel(float* p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// temb_silu[r] = silu(t[r] + g[r] + p[r % p_rows])   (CombinedTimestepGuidanceTextProjEmbeddings [ext]; every consumer applies SiLU first)
+template <typename T>
+__global__ void flux_temb_kernel(const T* __restrict__ t, const T* __restrict__ g, const T* __restrict__ p, T* __restrict__ out, int rows, int D, int p_rows) {
+  const size_t n = (size_t)rows * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / D, c = i - r * D;
+    float v = (float)t[i];
+    if (g) v = round_elem<T>(v + (float)g[i]);
+    v = round_elem<T>(v + (float)p[(r % p_rows) * D + c]);
+    out[i] = (T)silu(v);
+  }
+}
+template <typename T> __global__ void flux_unpad_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst, int rows, int cols) {
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols, c = i - r * cols;
+    dst[i] = src[r * lds_ + c];
+  }
+}
+
+struct FluxBase {
+  EcadFluxCfg cfg;
+  int dev = 0;
+  std::string err;
+  virtual ~FluxBase() {}
+  int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  virtual int init() = 0;
+  virtual int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
+  virtual int finalize_weights() = 0;
+  virtual int set_schedule(const uint8_t* bf, const uint8_t* bs, int steps) = 0;
+  virtual int begin_batch(int B, int gh, int gw, const void* enc, const void* pooled, int T, hipStream_t s) = 0;
+  virtual int step(int step_idx, const void* lat, float t, float g, void* out, hipStream_t s) = 0;
+  virtual int run_schedule(int B, int gh, int gw, const void* enc, const void* pooled, int T, float* lat, const float* ts, float g, const float* sig, int use_graph,
+                           hipStream_t s) = 0;
+  virtual int reset_cache() = 0;
+  virtual int stats(EcadFluxStats* s) = 0;
+  virtual int set_profiling(int on) = 0;
+  virtual int get_profile(int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) = 0;
+  virtual int op_gemm(int epi, int bn, const void* A, const void* A2, int k_split, const void* W, const float* bias, void* out, int M, int N, int K, void* resid,
+                      const void* gate, int64_t gate_stride, int seg0, int rpb0, int rpb1, hipStream_t s) = 0;
+  virtual int op_rope(void* qkv, int B, int T, int N, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* rope, hipStream_t s) = 0;
+  virtual int op_attention(const void* qkv, void* out, int B, int T, int N, hipStream_t s) = 0;
+  virtual int op_ln(const void* x, void* y, int B, int T, int N, const void* shift, const void* scale, int64_t mod_stride, hipStream_t s) = 0;
+};
+
+template <typename T> struct FOp {
+  enum Kind { GEMM, ATTN, ROPE, LN, REPLAY, COPY, SINUS, TEMB, EULER, UNPAD } kind;
+  int cls = FC_MISC;
+  int epi = 0, bn = 128;
+  FGemmArgs<T> g{};
+  AttnArgs a{};
+  FluxRowArgs f{};
+  int desc_off = -1, desc_n = 0;
+  const void* p0 = nullptr;
+  const void* p1 = nullptr;
+  const void* p2 = nullptr;
+  void* p3 = nullptr;
+  const float* w[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t n = 0;
+  int i0 = 0, i1 = 0, i2 = 0;
+  bool bind_in = false, bind_out = false;
+  double flops = 0, bytes = 0;
+};
+
+template <typename T> class FluxT : public FluxBase {
+ public:
+  int NL, NS, NH, D, CIN, JD, PD;
+  static constexpr int DH = 128, PROJ_PAD = 128, MAX_STEPS = 64;
+  size_t MODW = 0;
+  // ---- weights
+  char* warena = nullptr;
+  size_t warena_bytes = 0, warena_used = 0;
+  struct Dest { void* ptr; bool f32; int64_t rows, cols; bool loaded; };
+  std::map<std::string, Dest> dests;
+  struct JBlk {
+    T *w_qkv_i, *w_qkv_t, *w_out_i, *w_out_t, *w_ff1_i, *w_ff2_i, *w_ff1_t, *w_ff2_t;
+    float *b_qkv_i, *b_qkv_t, *b_out_i, *b_out_t, *b_ff1_i, *b_ff2_i, *b_ff1_t, *b_ff2_t, *nq, *nk, *naq, *nak;
+  };
+  struct SBlk {
+    T *w_qkv, *w_mlp, *w_out;
+    float *b_qkv, *b_mlp, *b_out, *nq, *nk;
+  };
+  std::vector<JBlk> jb;
+  std::vector<SBlk> sb;
+  T *w_x, *w_ctx, *w_t1, *w_t2, *w_g1, *w_g2, *w_p1, *w_p2, *w_mod, *w_proj;
+  float *b_x, *b_ctx, *b_t1, *b_t2, *b_g1, *b_g2, *b_p1, *b_p2, *b_mod, *b_proj;
+  bool finalized = false;
+  // ---- workspaces
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  T *hs, *xn, *qkv, *attn_o, *ffmid, *ctx0, *enc_buf, *pooled_buf, *tsin, *gsin, *te1, *t_emb, *g_emb, *p_emb, *temb_silu, *mod_all, *model_in, *proj;
+  T *cache_j, *cache_s;
+  float *lat_buf, *ts_dev, *gs_dev, *dt_dev, *rope;
+  FluxSrc* desc_dev = nullptr;
+  size_t desc_cap = 0;
+  std::vector<FluxSrc> desc_host;
+  // ---- schedule / plans
+  int steps = 0;
+  std::vector<uint8_t> ex_full, ex_single, live_sa, live_sm;  // executed flags [steps][blocks][3]; liveness of single attn / mlp
+  int B = 0, GH = 0, GW = 0, N = 0, Tt = 0;
+  bool plan_valid = false, batch_begun = false;
+  std::vector<std::vector<FOp<T>>> plan_step, plan_temb;  // per step
+  std::vector<FOp<T>> plan_begin, plan_temb_all, plan_run;
+  std::vector<float> ts_host, sig_host;
+  float g_host = -1.f;
+  EcadFluxStats st{};
+  // ---- graph / profiling
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[FC_COUNT], prof_flops[FC_COUNT], prof_bytes[FC_COUNT];
+  int64_t prof_launch[FC_COUNT];
+  int num_cus = 256;
+  int bn_wide = 256, bn_narrow = 128;
+  const void* call_in = nullptr;
+  void* call_out = nullptr;
+
+  ~FluxT() override {
+    hipSetDevice(dev);
+    if (graph_exec) hipGraphExecDestroy(graph_exec);
+    if (graph) hipGraphDestroy(graph);
+    if (cap_stream) hipStreamDestroy(cap_stream);
+    for (auto e : ev_pool) hipEventDestroy(e);
+    if (warena) hipFree(warena);
+    if (ws) hipFree(ws);
+    if (desc_dev) hipFree(desc_dev);
+  }
+
+  template <typename U> U* walloc(size_t n) {
+    size_t bytes = (n * sizeof(U) + 255) & ~(size_t)255;
+    U* p = reinterpret_cast<U*>(warena + warena_used);
+    warena_used += bytes;
+    return p;
+  }
+  void reg(const std::string& name, void* ptr, bool f32, int64_t rows, int64_t cols) { dests[name] = Dest{ptr, f32, rows, cols, false}; }
+  void reg_lin(const std::string& name, T* w, float* b, int64_t out, int64_t in) {
+    reg(name + ".weight", w, false, out, in);
+    reg(name + ".bias", b, true, 1, out);
+  }
+
+  // modulation-vector offsets (elements) inside one row of mod_all
+  size_t mo_joint(int i, int k) const { return ((size_t)i * 12 + k) * D; }
+  size_t mo_single(int i, int k) const { return ((size_t)NL * 12 + (size_t)i * 3 + k) * D; }
+  size_t mo_out(int k) const { return ((size_t)NL * 12 + (size_t)NS * 3 + k) * D; }
+
+  void layout_weights() {
+    const size_t d = D;
+    dests.clear();
+    warena_used = 0;
+    jb.assign(NL, JBlk{});
+    sb.assign(NS, SBlk{});
+    w_mod = walloc<T>(MODW * d);
+    b_mod = walloc<float>(MODW);
+    for (int i = 0; i < NL; ++i) {
+      JBlk& b = jb[i];
+      b.w_qkv_i = walloc<T>(3 * d * d); b.b_qkv_i = walloc<float>(3 * d);
+      b.w_qkv_t = walloc<T>(3 * d * d); b.b_qkv_t = walloc<float>(3 * d);
+      b.w_out_i = walloc<T>(d * d); b.b_out_i = walloc<float>(d);
+      b.w_out_t = walloc<T>(d * d); b.b_out_t = walloc<float>(d);
+      b.w_ff1_i = walloc<T>(4 * d * d); b.b_ff1_i = walloc<float>(4 * d);
+      b.w_ff2_i = walloc<T>(4 * d * d); b.b_ff2_i = walloc<float>(d);
+      b.w_ff1_t = walloc<T>(4 * d * d); b.b_ff1_t = walloc<float>(4 * d);
+      b.w_ff2_t = walloc<T>(4 * d * d); b.b_ff2_t = walloc<float>(d);
+      b.nq = walloc<float>(DH); b.nk = walloc<float>(DH); b.naq = walloc<float>(DH); b.nak = walloc<float>(DH);
+      const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+      reg_lin(p + "norm1.linear", w_mod + mo_joint(i, 0) * d, b_mod + mo_joint(i, 0), 6 * d, d);
+      reg_lin(p + "norm1_context.linear", w_mod + mo_joint(i, 6) * d, b_mod + mo_joint(i, 6), 6 * d, d);
+      const char* qn[3] = {"to_q", "to_k", "to_v"};
+      const char* an[3] = {"add_q_proj", "add_k_proj", "add_v_proj"};
+      for (int j = 0; j < 3; ++j) {
+        reg_lin(p + "attn." + qn[j], b.w_qkv_i + (size_t)j * d * d, b.b_qkv_i + (size_t)j * d, d, d);
+        reg_lin(p + "attn." + an[j], b.w_qkv_t + (size_t)j * d * d, b.b_qkv_t + (size_t)j * d, d, d);
+      }
+      reg_lin(p + "attn.to_out.0", b.w_out_i, b.b_out_i, d, d);
+      reg_lin(p + "attn.to_add_out", b.w_out_t, b.b_out_t, d, d);
+      reg(p + "attn.norm_q.weight", b.nq, true, 1, DH);
+      reg(p + "attn.norm_k.weight", b.nk, true, 1, DH);
+      reg(p + "attn.norm_added_q.weight", b.naq, true, 1, DH);
+      reg(p + "attn.norm_added_k.weight", b.nak, true, 1, DH);
+      reg_lin(p + "ff.net.0.proj", b.w_ff1_i, b.b_ff1_i, 4 * d, d);
+      reg_lin(p + "ff.net.2", b.w_ff2_i, b.b_ff2_i, d, 4 * d);
+      reg_lin(p + "ff_context.net.0.proj", b.w_ff1_t, b.b_ff1_t, 4 * d, d);
+      reg_lin(p + "ff_context.net.2", b.w_ff2_t, b.b_ff2_t, d, 4 * d);
+    }
+    for (int i = 0; i < NS; ++i) {
+      SBlk& b = sb[i];
+      b.w_qkv = walloc<T>(3 * d * d); b.b_qkv = walloc<float>(3 * d);
+      b.w_mlp = walloc<T>(4 * d * d); b.b_mlp = walloc<float>(4 * d);
+      b.w_out = walloc<T>(5 * d * d); b.b_out = walloc<float>(d);
+      b.nq = walloc<float>(DH); b.nk = walloc<float>(DH);
+      const std::string p = "single_transformer_blocks." + std::to_string(i) + ".";
+      reg_lin(p + "norm.linear", w_mod + mo_single(i, 0) * d, b_mod + mo_single(i, 0), 3 * d, d);
+      const char* qn[3] = {"to_q", "to_k", "to_v"};
+      for (int j = 0; j < 3; ++j) reg_lin(p + "attn." + qn[j], b.w_qkv + (size_t)j * d * d, b.b_qkv + (size_t)j * d, d, d);
+      reg(p + "attn.norm_q.weight", b.nq, true, 1, DH);
+      reg(p + "attn.norm_k.weight", b.nk, true, 1, DH);
+      reg_lin(p + "proj_mlp", b.w_mlp, b.b_mlp, 4 * d, d);
+      reg_lin(p + "proj_out", b.w_out, b.b_out, d, 5 * d);
+    }
+    reg_lin("norm_out.linear", w_mod + mo_out(0) * d, b_mod + mo_out(0), 2 * d, d);
+    w_x = walloc<T>(d * CIN); b_x = walloc<float>(d);
+    w_ctx = walloc<T>(d * JD); b_ctx = walloc<float>(d);
+    w_t1 = walloc<T>(d * 256); b_t1 = walloc<float>(d);
+    w_t2 = walloc<T>(d * d); b_t2 = walloc<float>(d);
+    w_g1 = walloc<T>(d * 256); b_g1 = walloc<float>(d);
+    w_g2 = walloc<T>(d * d); b_g2 = walloc<float>(d);
+    w_p1 = walloc<T>(d * PD); b_p1 = walloc<float>(d);
+    w_p2 = walloc<T>(d * d); b_p2 = walloc<float>(d);
+    w_proj = walloc<T>((size_t)PROJ_PAD * d); b_proj = walloc<float>(PROJ_PAD);
+    reg_lin("x_embedder", w_x, b_x, d, CIN);
+    reg_lin("context_embedder", w_ctx, b_ctx, d, JD);
+    reg_lin("time_text_embed.timestep_embedder.linear_1", w_t1, b_t1, d, 256);
+    reg_lin("time_text_embed.timestep_embedder.linear_2", w_t2, b_t2, d, d);
+    if (cfg.guidance_embeds) {
+      reg_lin("time_text_embed.guidance_embedder.linear_1", w_g1, b_g1, d, 256);
+      reg_lin("time_text_embed.guidance_embedder.linear_2", w_g2, b_g2, d, d);
+    }
+    reg_lin("time_text_embed.text_embedder.linear_1", w_p1, b_p1, d, PD);
+    reg_lin("time_text_embed.text_embedder.linear_2", w_p2, b_p2, d, d);
+    reg_lin("proj_out", w_proj, b_proj, CIN, d);
+  }
+
+  int init() override {
+    NL = cfg.num_layers; NS = cfg.num_single_layers; NH = cfg.num_heads; D = NH * cfg.head_dim; CIN = cfg.in_channels;
+    JD = cfg.joint_attention_dim; PD = cfg.pooled_projection_dim;
+    if (cfg.head_dim != DH) return fail(ECAD_E_UNSUPPORTED, "head_dim %d unsupported (FLUX: 128)", cfg.head_dim);
+    if (cfg.axes_dims_rope[0] + cfg.axes_dims_rope[1] + cfg.axes_dims_rope[2] != DH) return fail(ECAD_E_INVALID, "axes_dims_rope must sum to head_dim");
+    if (cfg.axes_dims_rope[0] % 2 || cfg.axes_dims_rope[1] % 2 || cfg.axes_dims_rope[2] % 2) return fail(ECAD_E_INVALID, "axes_dims_rope must be even");
+    if (NL < 0 || NS < 0 || NH < 1) return fail(ECAD_E_INVALID, "bad layer / head counts");
+    if (CIN != 64) return fail(ECAD_E_UNSUPPORTED, "in_channels %d unsupported (packed 2x2 x 16 latent channels = 64)", CIN);
+    if (JD % 64 || PD % 64) return fail(ECAD_E_UNSUPPORTED, "joint_attention_dim / pooled_projection_dim must be multiples of 64");
+    if (cfg.max_batch < 1 || cfg.max_image_tokens < 1 || cfg.max_text_tokens < 1) return fail(ECAD_E_INVALID, "max_batch / max_image_tokens / max_text_tokens must be positive");
+    FHIPCHK(hipSetDevice(dev));
+    FHIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    { hipDeviceProp_t pr; FHIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    if (const char* e = getenv("ECAD_FLUX_BN_WIDE")) bn_wide = atoi(e) == 128 ? 128 : 256;
+    if (const char* e = getenv("ECAD_FLUX_BN_NARROW")) bn_narrow = atoi(e) == 256 ? 256 : 128;
+    MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
+
+    // ---- weights: a dry layout pass sizes the arena
+    warena = nullptr;
+    layout_weights();
+    warena_bytes = warena_used + 4096;
+    FHIPCHK(hipMalloc((void**)&warena, warena_bytes));
+    FHIPCHK(hipMemset(warena, 0, warena_bytes));
+    layout_weights();
+    st.weight_bytes = (int64_t)warena_used;
+
+    // ---- workspaces + cache arena, sized for the largest batch
+    const size_t d = D, Bm = cfg.max_batch, Nm = cfg.max_image_tokens, Tm = cfg.max_text_tokens;
+    const size_t R = Bm * (Nm + Tm), BT = Bm * Tm, BNr = Bm * Nm, rows = (size_t)MAX_STEPS * Bm;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_hs = take(R * d * sizeof(T)), o_xn = take(R * d * sizeof(T)), o_qkv = take(R * 3 * d * sizeof(T)), o_ao = take(R * d * sizeof(T));
+    const size_t o_ff = take(R * 4 * d * sizeof(T)), o_ctx0 = take(BT * d * sizeof(T)), o_enc = take(BT * JD * sizeof(T)), o_pool = take(Bm * PD * sizeof(T));
+    const size_t o_tsin = take(rows * 256 * sizeof(T)), o_gsin = take(rows * 256 * sizeof(T)), o_te1 = take(rows * d * sizeof(T));
+    const size_t o_temb = take(rows * d * sizeof(T)), o_gemb = take(rows * d * sizeof(T)), o_pemb = take(Bm * d * sizeof(T)), o_tes = take(rows * d * sizeof(T));
+    const size_t o_mod = take(rows * MODW * sizeof(T)), o_min = take(BNr * CIN * sizeof(T)), o_proj = take(BNr * PROJ_PAD * sizeof(T));
+    const size_t o_lat = take(BNr * CIN * sizeof(float)), o_ts = take(rows * sizeof(float)), o_gs = take(rows * sizeof(float)), o_dt = take(MAX_STEPS * sizeof(float));
+    const size_t o_rope = take((Nm + Tm) * (DH / 2) * 2 * sizeof(float));
+    const size_t ws_only = off;
+    const size_t per_j = (R + BNr + BT) * d, per_s = R * 6 * d;
+    const size_t o_cj = take((size_t)NL * per_j * sizeof(T)), o_cs = take((size_t)NS * per_s * sizeof(T));
+    ws_bytes = off;
+    FHIPCHK(hipMalloc((void**)&ws, ws_bytes));
+    FHIPCHK(hipMemset(ws, 0, ws_only));
+    hs = (T*)(ws + o_hs); xn = (T*)(ws + o_xn); qkv = (T*)(ws + o_qkv); attn_o = (T*)(ws + o_ao); ffmid = (T*)(ws + o_ff); ctx0 = (T*)(ws + o_ctx0);
+    enc_buf = (T*)(ws + o_enc); pooled_buf = (T*)(ws + o_pool); tsin = (T*)(ws + o_tsin); gsin = (T*)(ws + o_gsin); te1 = (T*)(ws + o_te1);
+    t_emb = (T*)(ws + o_temb); g_emb = (T*)(ws + o_gemb); p_emb = (T*)(ws + o_pemb); temb_silu = (T*)(ws + o_tes); mod_all = (T*)(ws + o_mod);
+    model_in = (T*)(ws + o_min); proj = (T*)(ws + o_proj); lat_buf = (float*)(ws + o_lat); ts_dev = (float*)(ws + o_ts); gs_dev = (float*)(ws + o_gs);
+    dt_dev = (float*)(ws + o_dt); rope = (float*)(ws + o_rope); cache_j = (T*)(ws + o_cj); cache_s = (T*)(ws + o_cs);
+    st.workspace_bytes = (int64_t)ws_only;
+    st.cache_arena_bytes = (int64_t)(ws_bytes - ws_only);
+    return set_kernel_attrs();
+  }
+
+  int set_kernel_attrs() {
+#define FATTR(BN, E) FHIPCHK(hipFuncSetAttribute((const void*)fgemm_kernel<T, BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<BN>()))
+    FATTR(128, FEPI_BIAS); FATTR(128, FEPI_BIAS_GELU); FATTR(128, FEPI_BIAS_GATE_RESID); FATTR(128, FEPI_BIAS_SILU);
+    FATTR(256, FEPI_BIAS); FATTR(256, FEPI_BIAS_GELU); FATTR(256, FEPI_BIAS_GATE_RESID); FATTR(256, FEPI_BIAS_SILU);
+#undef FATTR
+    FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
+    FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) override {
+    FHIPCHK(hipSetDevice(dev));
+    auto it = dests.find(name);
+    if (it == dests.end()) return fail(ECAD_E_INVALID, "unknown FLUX weight name '%s'", name);
+    Dest& d = it->second;
+    int64_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= shape[i];
+    if (numel != d.rows * d.cols) return fail(ECAD_E_INVALID, "weight '%s': expected %lld elements, got %lld", name, (long long)(d.rows * d.cols), (long long)numel);
+    if (dtype != ECAD_DTYPE_F16 && dtype != ECAD_DTYPE_BF16 && dtype != ECAD_DTYPE_F32) return fail(ECAD_E_INVALID, "weight '%s': bad dtype %d", name, dtype);
+    const size_t esz = dtype == ECAD_DTYPE_F32 ? 4 : 2;
+    void* stage = nullptr;
+    FHIPCHK(hipMalloc(&stage, numel * esz));
+    hipError_t e = hipMemcpy(stage, ptr, numel * esz, hipMemcpyDefault);
+    if (e != hipSuccess) { hipFree(stage); return fail(ECAD_E_HIP, "hipMemcpy of weight '%s' failed: %s", name, hipGetErrorString(e)); }
+    const int grid = (int)((numel + 255) / 256 < 8192 ? (numel + 255) / 256 : 8192);
+#define CONV(SRC, DST) hipLaunchKernelGGL((convert_kernel<SRC, DST>), dim3(grid), dim3(256), 0, 0, (const SRC*)stage, (DST*)d.ptr, (size_t)numel)
+    if (d.f32) {
+      if (dtype == ECAD_DTYPE_F16) CONV(f16_t, float); else if (dtype == ECAD_DTYPE_BF16) CONV(bf16_t, float); else CONV(float, float);
+    } else {
+      if (dtype == ECAD_DTYPE_F16) CONV(f16_t, T); else if (dtype == ECAD_DTYPE_BF16) CONV(bf16_t, T); else CONV(float, T);
+    }
+#undef CONV
+    e = hipDeviceSynchronize();
+    hipFree(stage);
+    if (e != hipSuccess) return fail(ECAD_E_HIP, "weight conversion failed: %s", hipGetErrorString(e));
+    d.loaded = true;
+    finalized = false;
+    return ECAD_OK;
+  }
+  int finalize_weights() override {
+    for (auto& kv : dests)
+      if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "weight '%s' was never loaded", kv.first.c_str());
+    finalized = true;
+    plan_valid = false;
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  int set_schedule(const uint8_t* bf, const uint8_t* bs, int nsteps) override {
+    if (nsteps < 1 || nsteps > MAX_STEPS) return fail(ECAD_E_INVALID, "num_inference_steps %d out of range [1, %d]", nsteps, MAX_STEPS);
+    steps = nsteps;
+    auto resolve = [&](const uint8_t* bits, int blocks, std::vector<uint8_t>& ex) {
+      ex.assign((size_t)steps * blocks * 3, 0);
+      std::vector<uint8_t> have((size_t)blocks * 3, 0);
+      for (int s = 0; s < steps; ++s)
+        for (int i = 0; i < blocks * 3; ++i) {
+          const size_t k = (size_t)s * blocks * 3 + i;
+          ex[k] = (bits[k] != 0) || !have[i];  // recompute or cache empty (cached_flux_transformer_block.py:56-66,79-93,171-182,208-216)
+          have[i] |= ex[k];
+        }
+    };
+    resolve(bf, NL, ex_full);
+    resolve(bs, NS, ex_single);
+    // single_attn / single_proj_mlp executions whose value no proj_out ever consumes (proj_out replays its cache until the component is
+    // recomputed again): mathematically dead in the reference too; skipped here.
+    live_sa.assign((size_t)steps * NS, 0);
+    live_sm.assign((size_t)steps * NS, 0);
+    auto exs = [&](int s, int i, int c) { return ex_single[((size_t)s * NS + i) * 3 + c] != 0; };
+    for (int i = 0; i < NS; ++i)
+      for (int c = 0; c < 2; ++c)
+        for (int s = 0; s < steps; ++s) {
+          if (!exs(s, i, c)) continue;
+          bool live = false;
+          for (int s2 = s; s2 < steps; ++s2) {
+            if (s2 > s && exs(s2, i, c)) break;  // overwritten before any consumer
+            if (exs(s2, i, 2)) { live = true; break; }
+          }
+          (c == 0 ? live_sa : live_sm)[(size_t)s * NS + i] = live;
+        }
+    st.components_executed = st.components_cached = st.components_dead = 0;
+    for (auto v : ex_full) (v ? st.components_executed : st.components_cached)++;
+    for (int s = 0; s < steps; ++s)
+      for (int i = 0; i < NS; ++i)
+        for (int c = 0; c < 3; ++c) {
+          if (!exs(s, i, c)) { st.components_cached++; continue; }
+          const bool live = c == 2 || (c == 0 ? live_sa : live_sm)[(size_t)s * NS + i];
+          if (live) st.components_executed++; else st.components_dead++;
+        }
+    plan_valid = false;
+    batch_begun = false;
+    return ECAD_OK;
+  }
+  bool exf(int s, int i, int c) const { return ex_full[((size_t)s * NL + i) * 3 + c] != 0; }
+  bool exs_(int s, int i, int c) const { return ex_single[((size_t)s * NS + i) * 3 + c] != 0; }
+  // a cache written at step s is read only if the component is NOT executed at step s + 1
+  bool wlive_f(int s, int i, int c) const { return s + 1 < steps && !exf(s + 1, i, c); }
+  bool wlive_s(int s, int i, int c) const { return s + 1 < steps && !exs_(s + 1, i, c); }
+
+  // -------------------------------------------------------------------------------------------
+  // plan construction
+  int pick_bn(int Nn) const { return (Nn % 256 == 0 && Nn >= 2 * D) ? bn_wide : ((Nn % 256 == 0 && bn_narrow == 256) ? 256 : 128); }
+  FOp<T> mk_gemm(int cls, int epi, const T* A, int lda, const T* W, const float* bias, T* C, int ldc, int M, int Nn, int K) {
+    FOp<T> o;
+    o.kind = FOp<T>::GEMM; o.cls = cls; o.epi = epi; o.bn = pick_bn(Nn);
+    o.g.A = A; o.g.A2 = nullptr; o.g.W = W; o.g.bias = bias; o.g.C = C; o.g.resid = nullptr; o.g.gate = nullptr; o.g.gate_stride = 0;
+    o.g.seg0 = 0; o.g.rows_per_batch0 = 1; o.g.rows_per_batch1 = 1; o.g.M = M; o.g.N = Nn; o.g.K = K; o.g.k_split = K; o.g.lda = lda; o.g.lda2 = 0; o.g.ldw = K; o.g.ldc = ldc; o.g.ldr = 0;
+    o.flops = 2.0 * M * Nn * K;
+    o.bytes = ((double)M * K + (double)Nn * K + (double)M * Nn) * sizeof(T);
+    return o;
+  }
+  struct Range { T* h; T* xn; int M, seg0, rpb0, rpb1; size_t row0; };
+  Range r_img() const { return Range{hs + (size_t)B * Tt * D, xn + (size_t)B * Tt * D, B * N, 0, 1, N, (size_t)B * Tt}; }
+  Range r_txt() const { return Range{hs, xn, B * Tt, B * Tt, Tt, 1, 0}; }
+  Range r_all() const { return Range{hs, xn, B * (Tt + N), B * Tt, Tt, N, 0}; }
+  void set_resid(FOp<T>& o, const Range& r, T* cache_slot, const T* gate) {
+    o.epi = FEPI_BIAS_GATE_RESID;
+    o.g.C = cache_slot; o.g.ldc = D; o.g.resid = r.h; o.g.ldr = D; o.g.gate = gate; o.g.gate_stride = (int64_t)MODW;
+    o.g.seg0 = r.seg0; o.g.rows_per_batch0 = r.rpb0; o.g.rows_per_batch1 = r.rpb1;
+    o.bytes += (double)o.g.M * D * sizeof(T) * (cache_slot ? 3 : 2);
+  }
+  typedef std::vector<FluxSrc> Pend;
+  void fill_rows(FOp<T>& o, const Range& r, Pend& pend, size_t src_row_shift) {
+    o.f = FluxRowArgs{};
+    o.f.h = r.h; o.f.y = r.xn; o.f.M = r.M; o.f.D = D; o.f.seg0 = r.seg0; o.f.rows_per_batch0 = r.rpb0; o.f.rows_per_batch1 = r.rpb1;
+    o.f.gate_stride = (int64_t)MODW; o.f.mod_stride = (int64_t)MODW; o.f.eps = cfg.norm_eps;
+    o.f.n_src = (int)pend.size();
+    if (!pend.empty()) {
+      o.desc_off = (int)desc_host.size();
+      o.desc_n = (int)pend.size();
+      for (auto p : pend) {
+        p.cache = reinterpret_cast<const T*>(p.cache) + src_row_shift * D;
+        desc_host.push_back(p);
+      }
+    }
+    pend.clear();
+  }
+  void emit_ln(std::vector<FOp<T>>& ops, const Range& r, Pend& pend, const T* shift, const T* scale, size_t src_row_shift = 0) {
+    FOp<T> o;
+    o.kind = FOp<T>::LN; o.cls = FC_LN;
+    const int ns = (int)pend.size();
+    fill_rows(o, r, pend, src_row_shift);
+    o.f.shift = shift; o.f.scale = scale;
+    o.bytes = (double)r.M * D * sizeof(T) * (2 + ns + (ns ? 1 : 0));
+    ops.push_back(o);
+  }
+  void emit_flush(std::vector<FOp<T>>& ops, const Range& r, Pend& pend) {
+    if (pend.empty()) return;
+    FOp<T> o;
+    o.kind = FOp<T>::REPLAY; o.cls = FC_REPLAY;
+    const int ns = (int)pend.size();
+    fill_rows(o, r, pend, 0);
+    o.bytes = (double)r.M * D * sizeof(T) * (2 + ns);
+    ops.push_back(o);
+  }
+  void emit_attention(std::vector<FOp<T>>& ops, const float* wq, const float* wk, const float* wqt, const float* wkt, T* out) {
+    FOp<T> ro;
+    ro.kind = FOp<T>::ROPE; ro.cls = FC_ROPE; ro.w[0] = wq; ro.w[1] = wk; ro.w[2] = wqt; ro.w[3] = wkt;
+    ro.bytes = (double)B * (Tt + N) * 2 * D * sizeof(T) * 2;
+    ops.push_back(ro);
+    FOp<T> ao;
+    ao.kind = FOp<T>::ATTN; ao.cls = FC_ATTN;
+    AttnArgs& a = ao.a;
+    a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.out = out; a.bias = nullptr; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+    a.B = B; a.H = NH; a.Nq = a.Nk = Tt + N; a.dh = DH; a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+    a.seg_t = Tt; a.seg_bt = B * Tt;
+    const double S = Tt + N;
+    ao.flops = 4.0 * B * S * S * D;
+    ao.bytes = (double)B * S * 4 * D * sizeof(T);
+    ops.push_back(ao);
+  }
+
+  const T* mod_ptr(int s, size_t off) const { return mod_all + (size_t)s * B * MODW + off; }
+  T* cj(int i, int which) const {  // joint caches: 0 attn [R, D], 1 ff [B*N, D], 2 ff_context [B*T, D]
+    const size_t R = (size_t)B * (Tt + N), per = (R + (size_t)B * N + (size_t)B * Tt) * D;
+    T* base = cache_j + (size_t)i * per;
+    return which == 0 ? base : which == 1 ? base + R * D : base + (R + (size_t)B * N) * D;
+  }
+  T* cs(int i, int which) const {  // single caches: 0 attn [R, D], 1 gelu(mlp) [R, 4D], 2 proj_out [R, D]
+    const size_t R = (size_t)B * (Tt + N), per = R * 6 * D;
+    T* base = cache_s + (size_t)i * per;
+    return which == 0 ? base : which == 1 ? base + R * D : base + R * 5 * D;
+  }
+
+  void emit_temb(std::vector<FOp<T>>& ops, size_t r0, int rows) {
+    auto sinus = [&](const float* src, T* dst) {
+      FOp<T> o; o.kind = FOp<T>::SINUS; o.p0 = src; o.p3 = dst; o.i0 = rows; ops.push_back(o);
+    };
+    sinus(ts_dev + r0, tsin + r0 * 256);
+    ops.push_back(mk_gemm(FC_GEMM_SMALL, FEPI_BIAS_SILU, tsin + r0 * 256, 256, w_t1, b_t1, te1 + r0 * D, D, rows, D, 256));
+    ops.push_back(mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, te1 + r0 * D, D, w_t2, b_t2, t_emb + r0 * D, D, rows, D, D));
+    if (cfg.guidance_embeds) {
+      sinus(gs_dev + r0, gsin + r0 * 256);
+      ops.push_back(mk_gemm(FC_GEMM_SMALL, FEPI_BIAS_SILU, gsin + r0 * 256, 256, w_g1, b_g1, te1 + r0 * D, D, rows, D, 256));
+      ops.push_back(mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, te1 + r0 * D, D, w_g2, b_g2, g_emb + r0 * D, D, rows, D, D));
+    }
+    FOp<T> t; t.kind = FOp<T>::TEMB; t.p0 = t_emb + r0 * D; t.p1 = cfg.guidance_embeds ? g_emb + r0 * D : nullptr; t.p2 = p_emb; t.p3 = temb_silu + r0 * D; t.i0 = rows;
+    ops.push_back(t);
+    ops.push_back(mk_gemm(FC_GEMM_MOD, FEPI_BIAS, temb_silu + r0 * D, D, w_mod, b_mod, mod_all + r0 * MODW, (int)MODW, rows, (int)MODW, D));
+  }
+
+  void emit_step(std::vector<FOp<T>>& ops, int s, bool bind) {
+    const size_t BT = (size_t)B * Tt;
+    const int BNr = B * N, R = B * (Tt + N);
+    {  // residual streams: text <- hoisted context embedding, image <- x_embedder(latents)
+      FOp<T> c; c.kind = FOp<T>::COPY; c.p0 = ctx0; c.p3 = hs; c.n = BT * D * sizeof(T); c.bytes = 2.0 * c.n; ops.push_back(c);
+      FOp<T> x = mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, model_in, CIN, w_x, b_x, hs + BT * D, D, BNr, D, CIN);
+      x.bind_in = bind;
+      ops.push_back(x);
+    }
+    Pend pend_img, pend_txt, pend_all;
+    const Range RI = r_img(), RT = r_txt(), RA = r_all();
+    for (int i = 0; i < NL; ++i) {
+      const JBlk& b = jb[i];
+      auto m = [&](int k) { return mod_ptr(s, mo_joint(i, k)); };
+      if (exf(s, i, 0)) {
+        emit_ln(ops, RI, pend_img, m(0), m(1));
+        emit_ln(ops, RT, pend_txt, m(6), m(7));
+        ops.push_back(mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RI.xn, D, b.w_qkv_i, b.b_qkv_i, qkv + BT * 3 * D, 3 * D, BNr, 3 * D, D));
+        ops.push_back(mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RT.xn, D, b.w_qkv_t, b.b_qkv_t, qkv, 3 * D, (int)BT, 3 * D, D));
+        emit_attention(ops, b.nq, b.nk, b.naq, b.nak, attn_o);
+        const bool wl = wlive_f(s, i, 0);
+        FOp<T> oi = mk_gemm(FC_GEMM_ATTN_OUT, 0, attn_o + BT * D, D, b.w_out_i, b.b_out_i, nullptr, D, BNr, D, D);
+        set_resid(oi, RI, wl ? cj(i, 0) + BT * D : nullptr, m(2));
+        ops.push_back(oi);
+        FOp<T> ot = mk_gemm(FC_GEMM_ATTN_OUT, 0, attn_o, D, b.w_out_t, b.b_out_t, nullptr, D, (int)BT, D, D);
+        set_resid(ot, RT, wl ? cj(i, 0) : nullptr, m(8));
+        ops.push_back(ot);
+      } else {
+        pend_img.push_back(FluxSrc{cj(i, 0) + BT * D, m(2)});
+        pend_txt.push_back(FluxSrc{cj(i, 0), m(8)});
+      }
+      if (exf(s, i, 1)) {
+        emit_ln(ops, RI, pend_img, m(3), m(4));
+        ops.push_back(mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RI.xn, D, b.w_ff1_i, b.b_ff1_i, ffmid + BT * 4 * D, 4 * D, BNr, 4 * D, D));
+        FOp<T> o = mk_gemm(FC_GEMM_FF2, 0, ffmid + BT * 4 * D, 4 * D, b.w_ff2_i, b.b_ff2_i, nullptr, D, BNr, D, 4 * D);
+        set_resid(o, RI, wlive_f(s, i, 1) ? cj(i, 1) : nullptr, m(5));
+        ops.push_back(o);
+      } else {
+        pend_img.push_back(FluxSrc{cj(i, 1), m(5)});
+      }
+      if (exf(s, i, 2)) {
+        emit_ln(ops, RT, pend_txt, m(9), m(10));
+        ops.push_back(mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RT.xn, D, b.w_ff1_t, b.b_ff1_t, ffmid, 4 * D, (int)BT, 4 * D, D));
+        FOp<T> o = mk_gemm(FC_GEMM_FF2, 0, ffmid, 4 * D, b.w_ff2_t, b.b_ff2_t, nullptr, D, (int)BT, D, 4 * D);
+        set_resid(o, RT, wlive_f(s, i, 2) ? cj(i, 2) : nullptr, m(11));
+        ops.push_back(o);
+      } else {
+        pend_txt.push_back(FluxSrc{cj(i, 2), m(11)});
+      }
+    }
+    // cat([text, image]) is the layout itself; pending per-stream replays are flushed before the rows are treated as one matrix
+    emit_flush(ops, RI, pend_img);
+    emit_flush(ops, RT, pend_txt);
+    for (int i = 0; i < NS; ++i) {
+      const SBlk& b = sb[i];
+      auto m = [&](int k) { return mod_ptr(s, mo_single(i, k)); };
+      const bool la = live_sa[(size_t)s * NS + i] != 0, lm = live_sm[(size_t)s * NS + i] != 0, eo = exs_(s, i, 2);
+      if (la || lm) emit_ln(ops, RA, pend_all, m(0), m(1));
+      if (lm) ops.push_back(mk_gemm(FC_GEMM_SMLP, FEPI_BIAS_GELU, xn, D, b.w_mlp, b.b_mlp, cs(i, 1), 4 * D, R, 4 * D, D));
+      if (la) {
+        ops.push_back(mk_gemm(FC_GEMM_SQKV, FEPI_BIAS, xn, D, b.w_qkv, b.b_qkv, qkv, 3 * D, R, 3 * D, D));
+        emit_attention(ops, b.nq, b.nk, nullptr, nullptr, cs(i, 0));
+      }
+      if (eo) {
+        if (!(la || lm)) emit_flush(ops, RA, pend_all);
+        FOp<T> o = mk_gemm(FC_GEMM_SOUT, 0, cs(i, 0), D, b.w_out, b.b_out, nullptr, D, R, D, 5 * D);
+        o.g.A2 = cs(i, 1);  // K columns >= D of the concatenation come from the gelu(mlp) slot
+        o.g.lda2 = 4 * D;
+        o.g.k_split = D;
+        set_resid(o, RA, wlive_s(s, i, 2) ? cs(i, 2) : nullptr, m(2));
+        ops.push_back(o);
+      } else {
+        pend_all.push_back(FluxSrc{cs(i, 2), m(2)});
+      }
+    }
+    // hidden_states[:, T:] -> norm_out (AdaLayerNormContinuous: chunk order scale, shift) -> proj_out   (:301-304)
+    emit_ln(ops, RI, pend_all, mod_ptr(s, mo_out(1)), mod_ptr(s, mo_out(0)), BT);
+    FOp<T> po = mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, RI.xn, D, w_proj, b_proj, proj, PROJ_PAD, BNr, PROJ_PAD, D);
+    ops.push_back(po);
+  }
+
+  int build_plans() {
+    if (!finalized) return fail(ECAD_E_NOT_READY, "weights not finalized");
+    if (steps == 0) return fail(ECAD_E_NOT_READY, "schedule not set");
+    desc_host.clear();
+    plan_step.assign(steps, {});
+    plan_temb.assign(steps, {});
+    plan_begin.clear(); plan_temb_all.clear(); plan_run.clear();
+    const size_t BT = (size_t)B * Tt;
+    // begin: context embedder + pooled-text embedding (step invariant)
+    plan_begin.push_back(mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, enc_buf, JD, w_ctx, b_ctx, ctx0, D, (int)BT, D, JD));
+    plan_begin.push_back(mk_gemm(FC_GEMM_SMALL, FEPI_BIAS_SILU, pooled_buf, PD, w_p1, b_p1, te1, D, B, D, PD));
+    plan_begin.push_back(mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, te1, D, w_p2, b_p2, p_emb, D, B, D, D));
+    for (int s = 0; s < steps; ++s) {
+      emit_temb(plan_temb[s], (size_t)s * B, B);
+      emit_step(plan_step[s], s, true);
+      FOp<T> u; u.kind = FOp<T>::UNPAD; u.bind_out = true; plan_step[s].push_back(u);
+    }
+    emit_temb(plan_temb_all, 0, steps * B);
+    {
+      FOp<T> e0; e0.kind = FOp<T>::EULER; e0.i0 = -1; plan_run.push_back(e0);  // round the incoming latents to the model dtype, fill model_in
+      plan_run.insert(plan_run.end(), plan_temb_all.begin(), plan_temb_all.end());
+      for (int s = 0; s < steps; ++s) {
+        emit_step(plan_run, s, false);
+        FOp<T> e; e.kind = FOp<T>::EULER; e.i0 = s; plan_run.push_back(e);
+      }
+    }
+    // descriptors -> device, patch pointers
+    if (desc_host.size() > desc_cap) {
+      if (desc_dev) hipFree(desc_dev);
+      desc_cap = desc_host.size() + 1024;
+      FHIPCHK(hipMalloc((void**)&desc_dev, desc_cap * sizeof(FluxSrc)));
+    }
+    if (!desc_host.empty()) FHIPCHK(hipMemcpy(desc_dev, desc_host.data(), desc_host.size() * sizeof(FluxSrc), hipMemcpyHostToDevice));
+    auto patch = [&](std::vector<FOp<T>>& ops) {
+      for (auto& o : ops)
+        if (o.desc_off >= 0) o.f.srcs = desc_dev + o.desc_off;
+    };
+    for (auto& p : plan_step) patch(p);
+    patch(plan_run);
+    if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    st.graph_nodes = 0;
+    st.launches_per_batch = (int)plan_run.size() + (int)plan_begin.size();
+
+    // ---- accounting (per sample)
+    const int64_t n = N, t = Tt, d = D, S = n + t;
+    const int64_t cost_full[3] = {4 * S * d * d, 8 * n * d * d, 8 * t * d * d}, cost_single[3] = {3 * S * d * d, 4 * S * d * d, 5 * S * d * d};
+    const int64_t over = n * CIN * d + t * JD * d + (cfg.guidance_embeds ? 2 : 1) * (256 * d + d * d) + (PD * d + d * d) + (int64_t)NL * 12 * d * d + (int64_t)NS * 3 * d * d +
+                         2 * d * d + n * d * CIN;
+    st.linear_macs_reference = st.linear_macs_executed = st.attn_core_macs = 0;
+    for (int s = 0; s < steps; ++s) {
+      st.linear_macs_reference += over;
+      st.linear_macs_executed += over - t * JD * d - (PD * d + d * d);
+      for (int i = 0; i < NL; ++i)
+        for (int c = 0; c < 3; ++c)
+          if (exf(s, i, c)) { st.linear_macs_reference += cost_full[c]; st.linear_macs_executed += cost_full[c]; if (c == 0) st.attn_core_macs += 2 * S * S * d; }
+      for (int i = 0; i < NS; ++i)
+        for (int c = 0; c < 3; ++c)
+          if (exs_(s, i, c)) {
+            st.linear_macs_reference += cost_single[c];
+            const bool live = c == 2 || (c == 0 ? live_sa : live_sm)[(size_t)s * NS + i];
+            if (live) { st.linear_macs_executed += cost_single[c]; if (c == 0) st.attn_core_macs += 2 * S * S * d; }
+          }
+    }
+    st.linear_macs_executed += t * JD * d + (PD * d + d * d);  // hoisted: once per batch
+    plan_valid = true;
+    return ECAD_OK;
+  }
+
+  int ensure_shapes(int B_, int gh, int gw, int T_) {
+    if (B_ < 1 || B_ > cfg.max_batch) return fail(ECAD_E_INVALID, "batch %d outside [1, max_batch=%d]", B_, cfg.max_batch);
+    if (gh < 1 || gw < 1 || gh * gw > cfg.max_image_tokens) return fail(ECAD_E_INVALID, "image grid %dx%d exceeds max_image_tokens %d", gh, gw, cfg.max_image_tokens);
+    if (T_ < 1 || T_ > cfg.max_text_tokens) return fail(ECAD_E_INVALID, "text tokens %d outside [1, %d]", T_, cfg.max_text_tokens);
+    if (!plan_valid || B_ != B || gh != GH || gw != GW || T_ != Tt) {
+      B = B_; GH = gh; GW = gw; N = gh * gw; Tt = T_;
+      int rc = build_rope();
+      if (rc) return rc;
+      return build_plans();
+    }
+    return ECAD_OK;
+  }
+
+  // EmbedND / rope [ext]: pair p of axis a rotates by ids[a] * theta^(-2p / axes_dim[a]); text ids are all zero, image ids (0, row, col)
+  int build_rope() {
+    const int S = Tt + N, half = DH / 2;
+    std::vector<float> tab((size_t)S * half * 2);
+    for (int r = 0; r < S; ++r) {
+      double ids[3] = {0, 0, 0};
+      if (r >= Tt) { ids[1] = (r - Tt) / GW; ids[2] = (r - Tt) % GW; }
+      int p = 0;
+      for (int a = 0; a < 3; ++a) {
+        const int dim = cfg.axes_dims_rope[a];
+        for (int k = 0; k < dim / 2; ++k, ++p) {
+          const double omega = 1.0 / pow(10000.0, (double)(2 * k) / (double)dim);
+          const double ang = ids[a] * omega;
+          tab[((size_t)r * half + p) * 2] = (float)cos(ang);
+          tab[((size_t)r * half + p) * 2 + 1] = (float)sin(ang);
+        }
+      }
+    }
+    FHIPCHK(hipMemcpy(rope, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // launch
+  template <int BNT> int launch_gemm_bn(int epi, const FGemmArgs<T>& g, hipStream_t s) {
+    const int tiles = ((g.M + 255) / 256) * (g.N / BNT);
+    constexpr int lds = fgemm_lds_bytes<BNT>();
+    switch (epi) {
+      case FEPI_BIAS: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS>), dim3(tiles), dim3(512), lds, s, g); break;
+      case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(512), lds, s, g); break;
+      case FEPI_BIAS_GATE_RESID: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS_GATE_RESID>), dim3(tiles), dim3(512), lds, s, g); break;
+      case FEPI_BIAS_SILU: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS_SILU>), dim3(tiles), dim3(512), lds, s, g); break;
+      default: return fail(ECAD_E_INVALID, "bad epilogue %d", epi);
+    }
+    return ECAD_OK;
+  }
+  int launch_gemm(int epi, int bn, const FGemmArgs<T>& g, hipStream_t s) {
+    if (g.K % GEMM_BK || g.M < 1 || g.N % bn) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K %% 64, N %% %d)", g.M, g.N, g.K, bn);
+    if (g.A2 && (g.k_split % GEMM_BK || g.k_split <= 0 || g.k_split >= g.K)) return fail(ECAD_E_INVALID, "bad k_split %d", g.k_split);
+    return bn == 256 ? launch_gemm_bn<256>(epi, g, s) : launch_gemm_bn<128>(epi, g, s);
+  }
+  int launch_attn(const AttnArgs& a, hipStream_t s) {
+    constexpr int lds = attn_lds_bytes<128, 128>();
+    const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
+    const int grid = items < num_cus ? items : num_cus;
+    if (a.Nk % 128) hipLaunchKernelGGL((attn_kernel<T, 128, true, 128>), dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((attn_kernel<T, 128, false, 128>), dim3(grid), dim3(512), lds, s, a);
+    return ECAD_OK;
+  }
+  int launch_rope(T* buf, int rows, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* tab, int seg0, int T_, int N_, hipStream_t s) {
+    const size_t items = (size_t)rows * NH * 2;
+    hipLaunchKernelGGL((flux_qk_norm_rope_kernel<T>), dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, buf, rows, NH, DH, wq, wk, wqt, wkt, tab, seg0, T_ > 0 ? T_ : 1,
+                       N_ > 0 ? N_ : 1, cfg.norm_eps);
+    return ECAD_OK;
+  }
+  int launch_ln(const FluxRowArgs& f, hipStream_t s) {
+    const int cpr = f.D / 8, grid = (f.M + 3) / 4;
+    if (cpr <= 64) hipLaunchKernelGGL((flux_ln_modulate_kernel<T, 1>), dim3(grid), dim3(256), 0, s, f);
+    else if (cpr <= 64 * 3) hipLaunchKernelGGL((flux_ln_modulate_kernel<T, 3>), dim3(grid), dim3(256), 0, s, f);
+    else if (cpr <= 64 * 6) hipLaunchKernelGGL((flux_ln_modulate_kernel<T, 6>), dim3(grid), dim3(256), 0, s, f);
+    else return fail(ECAD_E_UNSUPPORTED, "D=%d too wide for the LN kernel", f.D);
+    return ECAD_OK;
+  }
+  void launch_replay(const FluxRowArgs& f, hipStream_t s) {
+    const size_t total = (size_t)f.M * (f.D / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((flux_replay_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, f);
+  }
+
+  int launch_op(const FOp<T>& o, hipStream_t s) {
+    switch (o.kind) {
+      case FOp<T>::GEMM: {
+        if (o.bind_in) { FGemmArgs<T> g = o.g; g.A = (const T*)call_in; return launch_gemm(o.epi, o.bn, g, s); }
+        return launch_gemm(o.epi, o.bn, o.g, s);
+      }
+      case FOp<T>::ATTN: return launch_attn(o.a, s);
+      case FOp<T>::ROPE: return launch_rope(qkv, B * (Tt + N), o.w[0], o.w[1], o.w[2], o.w[3], rope, B * Tt, Tt, N, s);
+      case FOp<T>::LN: return launch_ln(o.f, s);
+      case FOp<T>::REPLAY: launch_replay(o.f, s); break;
+      case FOp<T>::COPY: FHIPCHK(hipMemcpyAsync(o.p3, o.p0, o.n, hipMemcpyDeviceToDevice, s)); break;
+      case FOp<T>::SINUS: hipLaunchKernelGGL((timestep_sinusoid_kernel<T>), dim3(o.i0), dim3(128), 0, s, (const float*)o.p0, (T*)o.p3, o.i0); break;
+      case FOp<T>::TEMB: {
+        const size_t n = (size_t)o.i0 * D;
+        hipLaunchKernelGGL((flux_temb_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)o.p0, (const T*)o.p1, (const T*)o.p2, (T*)o.p3, o.i0, D, B);
+        break;
+      }
+      case FOp<T>::EULER: {
+        const size_t n = (size_t)B * N * CIN;
+        hipLaunchKernelGGL((flux_euler_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lat_buf, proj, (int64_t)PROJ_PAD, model_in,
+                           o.i0 >= 0 ? dt_dev + o.i0 : nullptr, B * N, CIN);
+        break;
+      }
+      case FOp<T>::UNPAD: {
+        const size_t n = (size_t)B * N * CIN;
+        hipLaunchKernelGGL((flux_unpad_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, proj, (int64_t)PROJ_PAD, (T*)call_out, B * N, CIN);
+        break;
+      }
+    }
+    return ECAD_OK;
+  }
+
+  int run_ops(const std::vector<FOp<T>>& ops, hipStream_t s, bool allow_profile) {
+    const bool prof = profiling && allow_profile;
+    if (prof)
+      while (ev_pool.size() < 2 * ops.size()) { hipEvent_t e; FHIPCHK(hipEventCreate(&e)); ev_pool.push_back(e); }
+    size_t k = 0;
+    for (const auto& o : ops) {
+      if (prof) FHIPCHK(hipEventRecord(ev_pool[2 * k], s));
+      int rc = launch_op(o, s);
+      if (rc) return rc;
+      if (prof) FHIPCHK(hipEventRecord(ev_pool[2 * k + 1], s));
+      ++k;
+    }
+    FHIPCHK(hipGetLastError());
+    if (prof) {
+      FHIPCHK(hipStreamSynchronize(s));
+      for (size_t i = 0; i < ops.size(); ++i) {
+        float ms = 0;
+        FHIPCHK(hipEventElapsedTime(&ms, ev_pool[2 * i], ev_pool[2 * i + 1]));
+        const int c = ops[i].cls;
+        prof_ms[c] += ms; prof_launch[c]++; prof_flops[c] += ops[i].flops; prof_bytes[c] += ops[i].bytes;
+      }
+    }
+    return ECAD_OK;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  int stage_inputs(const void* enc, const void* pooled, hipStream_t s) {
+    FHIPCHK(hipMemcpyAsync(enc_buf, enc, (size_t)B * Tt * JD * sizeof(T), hipMemcpyDeviceToDevice, s));
+    FHIPCHK(hipMemcpyAsync(pooled_buf, pooled, (size_t)B * PD * sizeof(T), hipMemcpyDeviceToDevice, s));
+    return ECAD_OK;
+  }
+  int begin_batch(int B_, int gh, int gw, const void* enc, const void* pooled, int T_, hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    if (!enc || !pooled) return fail(ECAD_E_INVALID, "enc_dev / pooled_dev is NULL");
+    int rc = ensure_shapes(B_, gh, gw, T_);
+    if (rc) return rc;
+    if ((rc = stage_inputs(enc, pooled, s))) return rc;
+    if ((rc = run_ops(plan_begin, s, true))) return rc;
+    batch_begun = true;
+    return ECAD_OK;
+  }
+  int step(int step_idx, const void* lat, float t, float g, void* out, hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    if (!batch_begun || !plan_valid) return fail(ECAD_E_NOT_READY, "ecad_flux_begin_image_batch must be called before ecad_flux_step");
+    if (step_idx < 0 || step_idx >= steps) return fail(ECAD_E_INVALID, "step_idx %d outside [0, %d)", step_idx, steps);
+    if (!lat || !out) return fail(ECAD_E_INVALID, "NULL pointer argument");
+    hipLaunchKernelGGL(flux_fill_kernel, dim3(1), dim3(64), 0, s, ts_dev + (size_t)step_idx * B, t, B);
+    hipLaunchKernelGGL(flux_fill_kernel, dim3(1), dim3(64), 0, s, gs_dev + (size_t)step_idx * B, g, B);
+    ts_host.clear();  // the per-step path overwrote rows of ts_dev / gs_dev
+    call_in = lat; call_out = out;
+    int rc = run_ops(plan_temb[step_idx], s, true);
+    if (rc) return rc;
+    return run_ops(plan_step[step_idx], s, true);
+  }
+  int run_schedule(int B_, int gh, int gw, const void* enc, const void* pooled, int T_, float* lat, const float* ts, float g, const float* sig, int use_graph,
+                   hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    if (!enc || !pooled || !lat || !ts || !sig) return fail(ECAD_E_INVALID, "NULL pointer argument");
+    int rc = ensure_shapes(B_, gh, gw, T_);
+    if (rc) return rc;
+    if (B > 64) return fail(ECAD_E_INVALID, "batch too large");
+    std::vector<float> tsv(ts, ts + steps), sgv(sig, sig + steps + 1);
+    if (tsv != ts_host || sgv != sig_host || g != g_host) {  // constants of the schedule: uploaded once, synchronously, outside the graph
+      std::vector<float> trow((size_t)steps * B), grow((size_t)steps * B, g), dt(steps);
+      for (int i = 0; i < steps; ++i) {
+        for (int b = 0; b < B; ++b) trow[(size_t)i * B + b] = ts[i];
+        dt[i] = sig[i + 1] - sig[i];
+      }
+      FHIPCHK(hipMemcpy(ts_dev, trow.data(), trow.size() * sizeof(float), hipMemcpyHostToDevice));
+      FHIPCHK(hipMemcpy(gs_dev, grow.data(), grow.size() * sizeof(float), hipMemcpyHostToDevice));
+      FHIPCHK(hipMemcpy(dt_dev, dt.data(), dt.size() * sizeof(float), hipMemcpyHostToDevice));
+      ts_host = tsv; sig_host = sgv; g_host = g;
+    }
+    if ((rc = stage_inputs(enc, pooled, s))) return rc;
+    const size_t nlat = (size_t)B * N * CIN;
+    FHIPCHK(hipMemcpyAsync(lat_buf, lat, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (use_graph && !profiling) {
+      if (!graph_exec) {
+        FHIPCHK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+        rc = run_ops(plan_begin, cap_stream, false);
+        if (!rc) rc = run_ops(plan_run, cap_stream, false);
+        hipError_t e = hipStreamEndCapture(cap_stream, &graph);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(ECAD_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        FHIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+        size_t nn = 0;
+        hipGraphGetNodes(graph, nullptr, &nn);
+        st.graph_nodes = (int)nn;
+      }
+      FHIPCHK(hipGraphLaunch(graph_exec, s));
+    } else {
+      if ((rc = run_ops(plan_begin, s, true))) return rc;
+      if ((rc = run_ops(plan_run, s, true))) return rc;
+    }
+    FHIPCHK(hipMemcpyAsync(lat, lat_buf, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    batch_begun = false;
+    return ECAD_OK;
+  }
+  int reset_cache() override { batch_begun = false; return ECAD_OK; }
+  int stats(EcadFluxStats* s) override { *s = st; return ECAD_OK; }
+  int set_profiling(int on) override {
+    profiling = on != 0;
+    for (int i = 0; i < FC_COUNT; ++i) { prof_ms[i] = prof_flops[i] = prof_bytes[i] = 0; prof_launch[i] = 0; }
+    return ECAD_OK;
+  }
+  int get_profile(int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) override {
+    int n = 0;
+    for (int i = 0; i < FC_COUNT && n < maxc; ++i, ++n) {
+      names[n] = fclass_names[i]; ms[n] = prof_ms[i]; launches[n] = prof_launch[i]; flops[n] = prof_flops[i]; bytes[n] = prof_bytes[i];
+    }
+    return n;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  int op_gemm(int epi, int bn, const void* A, const void* A2, int k_split, const void* W, const float* bias, void* out, int M, int Nn, int K, void* resid,
+              const void* gate, int64_t gate_stride, int seg0, int rpb0, int rpb1, hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    if (bn != 128 && bn != 256) return fail(ECAD_E_INVALID, "bn must be 128 or 256");
+    if (epi == FEPI_BIAS_GATE_RESID && !resid) return fail(ECAD_E_INVALID, "epilogue 2 needs resid");
+    FGemmArgs<T> g{};
+    g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate = (const T*)gate; g.gate_stride = gate_stride;
+    g.seg0 = seg0; g.rows_per_batch0 = rpb0 > 0 ? rpb0 : 1; g.rows_per_batch1 = rpb1 > 0 ? rpb1 : 1; g.M = M; g.N = Nn; g.K = K; g.ldw = K; g.ldc = Nn; g.ldr = Nn;
+    if (A2) { g.lda = k_split; g.A2 = (const T*)A2; g.lda2 = K - k_split; g.k_split = k_split; }
+    else { g.lda = K; g.A2 = nullptr; g.k_split = K; }
+    int rc = launch_gemm(epi, bn, g, s);
+    if (rc) return rc;
+    FHIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int op_rope(void* buf, int B_, int T_, int N_, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* tab, hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    launch_rope((T*)buf, B_ * (T_ + N_), wq, wk, wqt, wkt, tab, B_ * T_, T_, N_, s);
+    FHIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int op_attention(const void* buf, void* out, int B_, int T_, int N_, hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    AttnArgs a{};
+    const T* q = (const T*)buf;
+    a.q = q; a.k = q + D; a.v = q + 2 * D; a.out = out; a.bias = nullptr; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D; a.B = B_; a.H = NH; a.Nq = a.Nk = T_ + N_; a.dh = DH;
+    a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH)); a.seg_t = T_; a.seg_bt = B_ * T_;
+    launch_attn(a, s);
+    FHIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int op_ln(const void* x, void* y, int B_, int T_, int N_, const void* shift, const void* scale, int64_t mod_stride, hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    FluxRowArgs f{};
+    f.h = const_cast<void*>(x); f.y = y; f.n_src = 0; f.M = B_ * (T_ + N_); f.D = D; f.seg0 = B_ * T_; f.rows_per_batch0 = T_ > 0 ? T_ : 1; f.rows_per_batch1 = N_ > 0 ? N_ : 1;
+    f.shift = shift; f.scale = scale; f.mod_stride = mod_stride; f.eps = cfg.norm_eps;
+    int rc = launch_ln(f, s);
+    if (rc) return rc;
+    FHIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+};
+
+}  // namespace ecad
+
+// ================================================================================================
+using namespace ecad;
+struct EcadFlux { FluxBase* impl; };
+
+extern "C" {
+
+int ecad_flux_create(const EcadFluxCfg* cfg, int device, EcadFlux** out) {
+  if (!cfg || !out) { g_flux_create_error = "NULL argument"; return ECAD_E_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_flux_create_error = "no HIP device visible"; return ECAD_E_HIP; }
+  if (device < 0 || device >= ndev) { g_flux_create_error = "device index out of range"; return ECAD_E_INVALID; }
+  FluxBase* impl = nullptr;
+  if (cfg->dtype == ECAD_DTYPE_F16) impl = new FluxT<f16_t>();
+  else if (cfg->dtype == ECAD_DTYPE_BF16) impl = new FluxT<bf16_t>();
+  else { g_flux_create_error = "dtype must be ECAD_DTYPE_F16 or ECAD_DTYPE_BF16"; return ECAD_E_INVALID; }
+  impl->cfg = *cfg;
+  impl->dev = device;
+  int rc = impl->init();
+  if (rc) { g_flux_create_error = impl->err; delete impl; return rc; }
+  *out = new EcadFlux{impl};
+  return ECAD_OK;
+}
+void ecad_flux_destroy(EcadFlux* e) { if (e) { delete e->impl; delete e; } }
+const char* ecad_flux_last_error(const EcadFlux* e) { return e ? e->impl->err.c_str() : g_flux_create_error.c_str(); }
+
+#define FENG(e) if (!(e)) return ECAD_E_INVALID; FluxBase* E = (e)->impl
+
+int ecad_flux_load_weights(EcadFlux* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { FENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
+int ecad_flux_finalize_weights(EcadFlux* e) { FENG(e); return E->finalize_weights(); }
+int ecad_flux_set_schedule(EcadFlux* e, const uint8_t* bf, const uint8_t* bs, int steps) { FENG(e); if (!bf || !bs) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bf, bs, steps); }
+int ecad_flux_begin_image_batch(EcadFlux* e, int B, int gh, int gw, const void* enc, const void* pooled, int T, void* stream) { FENG(e); return E->begin_batch(B, gh, gw, enc, pooled, T, (hipStream_t)stream); }
+int ecad_flux_step(EcadFlux* e, int step_idx, const void* lat, float t, float g, void* out, void* stream) { FENG(e); return E->step(step_idx, lat, t, g, out, (hipStream_t)stream); }
+int ecad_flux_run_schedule(EcadFlux* e, int B, int gh, int gw, const void* enc, const void* pooled, int T, float* lat, const float* ts, float g, const float* sig, int use_graph, void* stream) {
+  FENG(e); return E->run_schedule(B, gh, gw, enc, pooled, T, lat, ts, g, sig, use_graph, (hipStream_t)stream);
+}
+int ecad_flux_reset_cache(EcadFlux* e) { FENG(e); return E->reset_cache(); }
+int ecad_flux_stats(EcadFlux* e, EcadFluxStats* s) { FENG(e); if (!s) return E->fail(ECAD_E_INVALID, "NULL stats"); return E->stats(s); }
+int ecad_flux_set_profiling(EcadFlux* e, int on) { FENG(e); return E->set_profiling(on); }
+int ecad_flux_get_profile(EcadFlux* e, int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) { FENG(e); return E->get_profile(maxc, names, ms, launches, flops, bytes); }
+int ecad_flux_op_gemm(EcadFlux* e, int epi, int bn, const void* A, const void* A2, int k_split, const void* W, const float* bias, void* out, int M, int N, int K, void* resid, const void* gate, int64_t gate_stride, int seg0, int rpb0, int rpb1, void* stream) {
+  FENG(e); return E->op_gemm(epi, bn, A, A2, k_split, W, bias, out, M, N, K, resid, gate, gate_stride, seg0, rpb0, rpb1, (hipStream_t)stream);
+}
+int ecad_flux_op_qk_norm_rope(EcadFlux* e, void* qkv, int B, int T, int N, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* rope, void* stream) {
+  FENG(e); return E->op_rope(qkv, B, T, N, wq, wk, wqt, wkt, rope, (hipStream_t)stream);
+}
+int ecad_flux_op_attention(EcadFlux* e, const void* qkv, void* out, int B, int T, int N, void* stream) { FENG(e); return E->op_attention(qkv, out, B, T, N, (hipStream_t)stream); }
+int ecad_flux_op_ln_modulate(EcadFlux* e, const void* x, void* y, int B, int T, int N, const void* shift, const void* scale, int64_t mod_stride, void* stream) {
+  FENG(e); return E->op_ln(x, y, B, T, N, shift, scale, mod_stride, (hipStream_t)stream);
+}
+
+}  // extern "C"

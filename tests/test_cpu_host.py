@@ -17,7 +17,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     from ecad_amd import _lib
 
     lib = _lib.load()
-    header = (ROOT / "include" / "ecad_hip.h").read_text()
+    header = (ROOT / "include" / "ecad_hip.h").read_text() + (ROOT / "include" / "ecad_flux.h").read_text()
     declared = set(re.findall(r"\b(ecad_[a-z_0-9]+)\s*\(", header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:

@@ -1,0 +1,273 @@
+"""FLUX row, -m gpu: the HIP path through the C ABI (include/ecad_flux.h) vs the CPU oracle
+(oracle/flux_ref.py) on the same seeded inputs and schedules.
+
+Floating-point tolerances (stated; the layer arithmetic is "restated, not verified against diffusers"):
+  * single ops vs fp32 torch on the same (already rounded) operands: rel-L2 <= 2e-3 fp16 / 1e-2 bf16
+  * one transformer forward, engine vs fp32 oracle with weights rounded to the engine dtype: rel-L2 <= 6e-3 fp16 / 4e-2 bf16
+  * final latents after a full schedule: rel-L2 <= 1.5e-2 fp16 / 6e-2 bf16
+  * paths that must be the same arithmetic (hipGraph vs eager, step API vs run_schedule bookkeeping): bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flux_ref  # noqa: E402  (checker only)
+from oracle.schedule_ref import resolve_executed  # noqa: E402
+
+DTYPES = [(torch.float16, 2e-3), (torch.bfloat16, 1e-2)]
+
+
+def tiny_cfg(layers=2, single=3):
+    return flux_ref.FluxConfig(num_layers=layers, num_single_layers=single, num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64)
+
+
+def make_engine(cfg, dtype, max_batch=2, max_n=256, max_t=128):
+    from ecad_amd.flux_engine import EcadFluxEngine
+
+    return EcadFluxEngine(
+        num_layers=cfg.num_layers, num_single_layers=cfg.num_single_layers, num_heads=cfg.num_attention_heads, head_dim=cfg.attention_head_dim,
+        in_channels=cfg.in_channels, joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim,
+        guidance_embeds=cfg.guidance_embeds, axes_dims_rope=cfg.axes_dims_rope, max_batch=max_batch, max_image_tokens=max_n, max_text_tokens=max_t, dtype=dtype)
+
+
+@pytest.fixture(scope="module")
+def op_engine():
+    return {dt: make_engine(tiny_cfg(1, 1), dt) for dt, _ in DTYPES}
+
+
+# ------------------------------------------------------------------------------------------------ single ops
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("bn", [128, 256])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (512, 768, 256), (1000, 512, 1088)])
+def test_fgemm_bias_and_activations(op_engine, dtype, tol, bn, M, N, K):
+    eng = op_engine[dtype]
+    g = torch.Generator().manual_seed(M + N + K + bn)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dtype).cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = A.float() @ W.float().T + bias
+    for epi, fn in ((0, lambda x: x), (1, lambda x: torch.nn.functional.gelu(x, approximate="tanh")), (3, torch.nn.functional.silu)):
+        out = eng.op_gemm(epi, bn, A, W, bias)
+        torch.cuda.synchronize()
+        assert rel_l2(out.float(), fn(ref)) <= tol, (epi, bn)
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("bn", [128, 256])
+def test_fgemm_split_a_gated_residual_two_segments(op_engine, dtype, tol, bn):
+    """proj_out of the single-stream block: A = [attn | gelu(mlp)] from two buffers; resid += gate[b] * out with the
+    [text | image] row layout (text rows of all samples first)."""
+    eng = op_engine[dtype]
+    B, T, N, D = 2, 40, 150, 256
+    R = B * (T + N)
+    g = torch.Generator().manual_seed(9 + bn)
+    A1 = (torch.randn(R, D, generator=g) * 0.5).to(dtype).cuda()
+    A2 = (torch.randn(R, 4 * D, generator=g) * 0.5).to(dtype).cuda()
+    W = (torch.randn(D, 5 * D, generator=g) / math.sqrt(5 * D)).to(dtype).cuda()
+    bias = torch.randn(D, generator=g).cuda()
+    gate = torch.randn(B, 3 * D, generator=g).to(dtype).cuda()  # gate vector of sample b at gate[b, D:2D]
+    resid0 = torch.randn(R, D, generator=g).to(dtype).cuda()
+    resid = resid0.clone()
+    out = eng.op_gemm(2, bn, A1, W, bias, A2=A2, resid=resid, gate=gate[:, D:], seg0=B * T, rows_per_batch0=T, rows_per_batch1=N)
+    torch.cuda.synchronize()
+    ref = torch.cat([A1, A2], 1).float() @ W.float().T + bias
+    assert rel_l2(out.float(), ref) <= tol
+    b_of_row = torch.cat([torch.arange(B).repeat_interleave(T), torch.arange(B).repeat_interleave(N)]).cuda()
+    want = resid0.float() + gate[:, D : 2 * D].float()[b_of_row] * ref
+    assert rel_l2(resid.float(), want) <= tol
+    # no cache copy requested, no gate: plain accumulate
+    resid2 = resid0.clone()
+    eng.op_gemm(2, bn, A1, W, bias, A2=A2, resid=resid2, want_out=False)
+    torch.cuda.synchronize()
+    assert rel_l2(resid2.float(), resid0.float() + ref) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_qk_norm_rope_matches_oracle(op_engine, dtype, tol):
+    eng = op_engine[dtype]
+    cfg = tiny_cfg(1, 1)
+    B, T, gh, gw = 2, 24, 5, 7
+    N, D, H = gh * gw, cfg.dim, cfg.num_attention_heads
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B * (T + N), 3 * D, generator=g).to(dtype)
+    w = {k: 1 + 0.2 * torch.randn(128, generator=g) for k in ("q", "k", "aq", "ak")}
+    ids = torch.cat([torch.zeros(T, 3), flux_ref.latent_image_ids(gh, gw)], 0)
+    cos, sin = flux_ref.rope_table(ids)
+    rope = torch.stack([cos, sin], -1).contiguous().cuda()
+    got = eng.op_qk_norm_rope(qkv.cuda().clone(), B, T, N, w["q"].cuda(), w["k"].cuda(), rope, wq_txt=w["aq"].cuda(), wk_txt=w["ak"].cuda())
+    torch.cuda.synchronize()
+
+    def ref_part(x, wt, pos_cos, pos_sin):  # x [rows_of_one_sample, D]
+        xh = x.float().view(1, -1, H, 128).transpose(1, 2)
+        xh = xh * torch.rsqrt(xh.pow(2).mean(-1, keepdim=True) + 1e-6) * wt
+        return flux_ref.apply_rope(xh, pos_cos, pos_sin).transpose(1, 2).reshape(-1, D)
+
+    want = qkv.float().clone()
+    for b in range(B):
+        tr, ir = slice(b * T, (b + 1) * T), slice(B * T + b * N, B * T + (b + 1) * N)
+        for which, (wi, wt) in enumerate((("q", "aq"), ("k", "ak"))):
+            cs = slice(which * D, (which + 1) * D)
+            want[tr, cs] = ref_part(qkv[tr, cs], w[wt], cos[:T], sin[:T])
+            want[ir, cs] = ref_part(qkv[ir, cs], w[wi], cos[T:], sin[T:])
+    assert rel_l2(got.float(), want) <= tol
+    assert torch.equal(got[:, 2 * D :].cpu(), qkv[:, 2 * D :])  # v untouched
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("T,N", [(32, 64), (40, 150), (128, 384)])
+def test_joint_attention_matches_sdpa(op_engine, dtype, tol, T, N):
+    eng = op_engine[dtype]
+    B, H, D = 2, 2, 256
+    S = T + N
+    g = torch.Generator().manual_seed(T + N)
+    qkv = torch.randn(B * S, 3 * D, generator=g).to(dtype)
+    out = eng.op_attention(qkv.cuda(), B, T, N)
+    torch.cuda.synchronize()
+    want = torch.zeros(B * S, D)
+    for b in range(B):
+        rows = torch.cat([torch.arange(b * T, (b + 1) * T), torch.arange(B * T + b * N, B * T + (b + 1) * N)])
+        x = qkv[rows].float()
+        q, k, v = [x[:, i * D : (i + 1) * D].view(S, H, 128).transpose(0, 1) for i in range(3)]
+        o = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(128), -1) @ v
+        want[rows] = o.transpose(0, 1).reshape(S, D)
+    assert rel_l2(out.float(), want) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_ln_modulate_two_segments(op_engine, dtype, tol):
+    eng = op_engine[dtype]
+    B, T, N, D = 2, 24, 100, 256
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B * (T + N), D, generator=g).to(dtype)
+    mod = (torch.randn(B, 2 * D, generator=g) * 0.3).to(dtype)
+    modc = mod.cuda()
+    y = eng.op_ln_modulate(x.cuda(), B, T, N, modc[:, :D], modc[:, D:])  # views: row stride 2D
+    torch.cuda.synchronize()
+    b_of_row = torch.cat([torch.arange(B).repeat_interleave(T), torch.arange(B).repeat_interleave(N)])
+    ln = torch.nn.functional.layer_norm(x.float(), (D,), eps=1e-6)
+    want = ln * (1 + mod[:, D:].float()[b_of_row]) + mod[:, :D].float()[b_of_row]
+    assert rel_l2(y.float(), want) <= tol
+
+
+# ------------------------------------------------------------------------------------------------ engine
+def rand_bits(steps, blocks, p, seed):
+    return np.random.default_rng(seed).random((steps, blocks, 3)) < p
+
+
+def make_pair(cfg, dtype, bits_full, bits_single, seed=0, **kw):
+    w = flux_ref.make_weights(cfg, seed=seed)
+    eng = make_engine(cfg, dtype, **kw)
+    eng.load_state_dict(w)
+    eng.set_schedule(bits_full, bits_single)
+    return eng, flux_ref.FluxOracle(cfg, w, round_dtype=None if dtype is None else dtype)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
+def test_step_parity_random_schedule(dtype, tol):
+    """ecad_flux_step == FluxTransformer2DEdited.forward at every schedule row, caches (and dead-component skipping) included."""
+    cfg = tiny_cfg(2, 3)
+    steps, B, T, gh, gw = 6, 2, 32, 8, 8
+    bf, bs = rand_bits(steps, cfg.num_layers, 0.5, 11), rand_bits(steps, cfg.num_single_layers, 0.5, 12)
+    eng, ref = make_pair(cfg, dtype, bf, bs)
+    # weights only are rounded in the oracle; activations stay fp32 there
+    ref.round_dtype = None
+    lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, B, gh, gw, T)
+    enc_d, pooled_d = enc.to(dtype), pooled.to(dtype)
+    eng.begin_image_batch(enc_d.cuda(), pooled_d.cuda(), gh, gw)
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    for s in range(steps):
+        x = torch.randn(B, gh * gw, 64, generator=g).to(dtype)
+        t, gd = 900.0 - 130 * s, 4992.0
+        got = eng.step(s, x.cuda(), t, gd)
+        torch.cuda.synchronize()
+        want = ref.forward(x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), gd), ids, s, bf[s], bs[s])
+        worst = max(worst, rel_l2(got.float(), want))
+    print(f"flux step parity {dtype}: worst rel-L2 {worst:.2e}")
+    assert worst <= tol
+    st = eng.stats()
+    ef, es = resolve_executed(bf), resolve_executed(bs)
+    assert st["components_executed"] + st["components_dead"] == int(ef.sum() + es.sum())
+    assert st["components_cached"] == int((~ef).sum() + (~es).sum())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-2), (torch.bfloat16, 6e-2)])
+def test_run_schedule_matches_oracle_and_graph_is_bit_exact(dtype, tol):
+    cfg = tiny_cfg(2, 2)
+    steps, B, T, gh, gw = 8, 2, 32, 8, 8
+    bf, bs = rand_bits(steps, cfg.num_layers, 0.6, 21), rand_bits(steps, cfg.num_single_layers, 0.6, 22)
+    eng, ref = make_pair(cfg, dtype, bf, bs)
+    ref.round_dtype = None
+    lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, B, gh, gw, T)
+    enc_d, pooled_d = enc.to(dtype), pooled.to(dtype)
+    sig = flux_ref.flow_match_sigmas(steps, gh * gw)
+    t_model, g_model = flux_ref.model_scalars(sig, 5.0, dtype)
+    outs = []
+    for use_graph in (False, True, True):
+        x = lat.clone().cuda()
+        eng.run_schedule(x, enc_d.cuda(), pooled_d.cuda(), gh, gw, t_model.numpy(), float(g_model[0]), sig, use_graph=use_graph)
+        torch.cuda.synchronize()
+        outs.append(x.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert eng.stats()["graph_nodes"] > 0
+    # oracle: same rounded scalars, latents rounded to the model dtype between steps
+    xo = lat.to(dtype).float()
+    ref.reset_cache()
+    for s in range(steps):
+        v = ref.forward(xo, enc_d.float(), pooled_d.float(), t_model[s].expand(B), g_model.expand(B), ids, s, bf[s], bs[s])
+        xo = (xo + (float(sig[s + 1]) - float(sig[s])) * v).to(dtype).float()
+    err = rel_l2(outs[0], xo)
+    print(f"flux final latents {dtype}: rel-L2 {err:.2e}")
+    assert err <= tol
+
+
+def test_forced_recompute_and_all_cached_steps_are_exact_replays():
+    """A flag that is false on an empty cache recomputes (same result as the flag being true); a fully cached step with the
+    same inputs and timestep reproduces the previous prediction bit for bit."""
+    cfg = tiny_cfg(2, 2)
+    dtype = torch.bfloat16
+    B, T, gh, gw = 1, 32, 4, 8
+    lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, B, gh, gw, T)
+    on_f, on_s = np.ones((2, 2, 3), bool), np.ones((2, 2, 3), bool)
+    off_f, off_s = on_f.copy(), on_s.copy()
+    off_f[0, 1, 0] = False
+    off_s[0, 0, 1] = False
+    off_f[1], off_s[1] = False, False
+    w = flux_ref.make_weights(cfg, seed=1)
+    x = lat.to(dtype).cuda()
+    res = []
+    for bf, bs in ((on_f, on_s), (off_f, off_s)):
+        eng = make_engine(cfg, dtype)
+        eng.load_state_dict(w)
+        eng.set_schedule(bf, bs)
+        eng.begin_image_batch(enc.to(dtype).cuda(), pooled.to(dtype).cuda(), gh, gw)
+        v0 = eng.step(0, x, 500.0, 4992.0)
+        v1 = eng.step(1, x, 500.0, 4992.0)
+        torch.cuda.synchronize()
+        res.append((v0.cpu(), v1.cpu()))
+    assert torch.equal(res[0][0], res[1][0])  # forced recompute at step 0
+    assert torch.equal(res[1][0], res[1][1])  # all-cached replay
+    assert torch.equal(res[0][0], res[0][1])  # recomputing everything on the same inputs is deterministic too
+
+
+def test_flux_errors():
+    from ecad_amd.flux_engine import EcadFluxEngine
+
+    with pytest.raises(ValueError):
+        EcadFluxEngine(num_layers=1, num_single_layers=1, num_heads=2, head_dim=64)
+    cfg = tiny_cfg(1, 1)
+    eng = make_engine(cfg, torch.bfloat16)
+    with pytest.raises(ValueError):
+        eng.set_schedule(np.ones((2, 3, 3), bool), np.ones((2, 1, 3), bool))
+    eng.set_schedule(np.ones((2, 1, 3), bool), np.ones((2, 1, 3), bool))
+    lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, 1, 4, 4, 16)
+    with pytest.raises(RuntimeError):  # weights never loaded
+        eng.begin_image_batch(enc.bfloat16().cuda(), pooled.bfloat16().cuda(), 4, 4)
+    with pytest.raises(ValueError):
+        eng.load_state_dict({"not.a.weight": torch.zeros(1)})

@@ -41,7 +41,7 @@ struct AttnArgs {
 
 template <int DHC> struct AttCfg;
 template <> struct AttCfg<72> { static constexpr int KSTEPS = 3, ND = 5, KS = 104, VS = 80, NCH = 9; };    // K: 96 padded + 8; V: 80 (col 72 = ones)
-template <> struct AttCfg<128> { static constexpr int KSTEPS = 4, ND = 9, KS = 136, VS = 152, NCH = 16; };  // K: 128 + 8; V: 144 (col 128 = ones) + 8
+template <> struct AttCfg<128> { static constexpr int KSTEPS = 4, ND = 9, KS = 136, VS = 144, NCH = 16; };  // K: 128 + 8; V: 144 (col 128 = ones): 288 B rows tile the banks
 constexpr int ATT_QB = 256;       // query rows per work item (8 waves x 16 rows x 2 rounds)
 constexpr float ATT_NEG = -1.0e30f;
 

@@ -1,0 +1,203 @@
+// attention128.h -- joint [text | image] attention of the FLUX blocks, head dim 128 (FluxAttnProcessor2_0 /
+// FluxSingleAttnProcessor2_0 [ext]; reference call sites ecad/transformer_blocks/cached_flux_transformer_block.py:63-66,178-182).
+//
+// Same data flow as attention.h (persistent workgroups over (sample, head, 256-query block); K/V chunk of 128 keys staged once
+// in LDS and shared by 8 waves; S^T = K Q^T strip in registers; exp2'd P packs straight into the B operand of O^T = V^T P^T;
+// the ones column of the V tile accumulates the softmax denominator), restructured for d_h = 128 where the LDS fragment reads,
+// not the MFMAs, bound the kernel: a wave owns 32 query rows and BOTH 16-row fragments consume every K / V fragment it reads
+// (half the LDS traffic of two sequential rounds), the score strip covers 64 keys at a time (32 VGPRs for both fragments), and
+// the V tile row stride is 144 elements (288 B = 8 banks mod 64: the 8 rows x 32 B of a 32-lane transposed read tile the 64
+// banks exactly; the 152-element stride of the generic kernel collides).
+#pragma once
+#include "attention.h"
+#include "common.h"
+
+namespace ecad {
+
+constexpr int A128_KC = 128, A128_KS = 136, A128_VS = 144, A128_DH = 128;
+constexpr int A128_LDS_BYTES = A128_KC * (A128_KS + A128_VS) * 2 + A128_KC * 4;  // 74240
+
+template <typename T, bool TAIL>
+__global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
+  constexpr int KC = A128_KC, KS = A128_KS, VS = A128_VS, DH = A128_DH, ND = 9, KSTEPS = 4, NCH = 16;
+  extern __shared__ __attribute__((aligned(16))) char att_smem[];
+  T* Ks = reinterpret_cast<T*>(att_smem);
+  T* Vs = Ks + KC * KS;
+  float* bias_s = reinterpret_cast<float*>(Vs + KC * VS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  constexpr int MAXL = KC * NCH * 2 / 512;  // 8 staging loads per thread
+
+  const T* Q = reinterpret_cast<const T*>(p.q);
+  const T* K = reinterpret_cast<const T*>(p.k);
+  const T* V = reinterpret_cast<const T*>(p.v);
+  T* O = reinterpret_cast<T*>(p.out);
+  const int nqb = (p.Nq + ATT_QB - 1) / ATT_QB;
+  const int nkc = (p.Nk + KC - 1) / KC;
+  const int items = p.B * p.H * nqb;
+
+  for (int i = tid; i < KC * (KS + VS) / 8; i += 512) reinterpret_cast<u32x4*>(att_smem)[i] = (u32x4){0, 0, 0, 0};
+  __syncthreads();
+  for (int i = tid; i < KC; i += 512) Vs[i * VS + DH] = (T)1.0f;
+
+  // staging: thread owns chunk column c = tid % 16 of keys tid / 16 + 32 i, K tile for i < 4 and V tile for i >= 4
+  Pack8 stg[MAXL];
+  auto load_stage = [&](int item, int kc) {
+    const int bh = item / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const int c = tid & 15;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      const int key = (tid >> 4) + 32 * (i & 3);
+      const int gk = kc * KC + key;
+      stg[i].u = (u32x4){0, 0, 0, 0};
+      if (!TAIL || gk < p.Nk) {
+        const size_t grow = att_row(b, gk, p.Nk, p.seg_t, p.seg_bt);
+        const T* base = i >= 4 ? V + grow * p.ldv : K + grow * p.ldk;
+        stg[i] = gload16(base + (size_t)h * DH + c * 8);
+      }
+    }
+  };
+  auto store_stage = [&](int kc) {
+    const int c = tid & 15;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      const int key = (tid >> 4) + 32 * (i & 3);
+      T* dst = i >= 4 ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
+      *reinterpret_cast<u32x4*>(dst) = stg[i].u;
+    }
+    if (TAIL)
+      for (int i = tid; i < KC; i += 512) bias_s[i] = kc * KC + i < p.Nk ? 0.f : ATT_NEG;
+  };
+
+  int item = blockIdx.x;
+  if (item < items) load_stage(item, 0);
+  for (; item < items; item += gridDim.x) {
+    const int qb = item % nqb, bh = item / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    f32x4 oacc[2][ND];
+    float m_run[2] = {ATT_NEG, ATT_NEG};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Pack8 qfr[2][KSTEPS];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int qrow = qb * ATT_QB + wave * 32 + r * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        qfr[r][ks].u = (u32x4){0, 0, 0, 0};
+        if (qrow < p.Nq) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * DH + 32 * ks + 8 * g);
+      }
+    }
+    for (int kc = 0; kc < nkc; ++kc) {
+      __syncthreads();  // every wave finished reading the previous chunk
+      store_stage(kc);
+      __syncthreads();
+      if (kc + 1 < nkc) load_stage(item, kc + 1);
+      else if (item + (int)gridDim.x < items) load_stage(item + gridDim.x, 0);
+
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        const T* Kh = Ks + half * 64 * KS;
+        const T* Vh = Vs + half * 64 * VS;
+        // ---- S^T strips of both query fragments for 64 keys: every K fragment read feeds two MFMAs
+        f32x4 s[2][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          s[0][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          s[1][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            const Pack8 kf = lds_read16(Kh + (16 * f + l15) * KS + 32 * ks + 8 * g);
+            s[0][f] = mfma16<T>(kf, qfr[0][ks], s[0][f]);
+            s[1][f] = mfma16<T>(kf, qfr[1][ks], s[1][f]);
+          }
+        }
+        float m_new[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float mt = ATT_NEG;
+          if (TAIL) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + half * 64 + 16 * f + 4 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                s[r][f][e] = s[r][f][e] * p.scale_log2e + bv[e];
+                mt = fmaxf(mt, s[r][f][e]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[r][f][e]);
+            mt *= p.scale_log2e;
+          }
+          mt = fmaxf(mt, __shfl_xor(mt, 16));
+          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          m_new[r] = fmaxf(m_run[r], mt);
+          const float alpha = fast_exp2(m_run[r] - m_new[r]);
+          m_run[r] = m_new[r];
+#pragma unroll
+          for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oacc[r][nd][e] *= alpha;
+        }
+        // ---- O^T += V^T P^T: k slot (g, j) of 32-key step s2 <-> key 32 s2 + (j < 4 ? 4g + j : 16 + 4g + j - 4)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Pack8 pf[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float p0, p1;
+              if (TAIL) {
+                p0 = fast_exp2(s[r][2 * s2][e] - m_new[r]);
+                p1 = fast_exp2(s[r][2 * s2 + 1][e] - m_new[r]);
+              } else {
+                p0 = fast_exp2(__builtin_fmaf(s[r][2 * s2][e], p.scale_log2e, -m_new[r]));
+                p1 = fast_exp2(__builtin_fmaf(s[r][2 * s2 + 1][e], p.scale_log2e, -m_new[r]));
+              }
+              float_to_elem<T>(pf[r], e, p0);
+              float_to_elem<T>(pf[r], 4 + e, p1);
+            }
+          const int krow = 32 * s2 + 4 * g + (l15 >> 2);
+          const int dcol = 4 * (l15 & 3);
+#pragma unroll
+          for (int nd = 0; nd < ND; ++nd) {
+            const Pack4 lo = lds_read_tr16(Vh + krow * VS + 16 * nd + dcol);
+            const Pack4 hi = lds_read_tr16(Vh + (krow + 16) * VS + 16 * nd + dcol);
+            Pack8 vf;
+            vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
+            oacc[0][nd] = mfma16<T>(vf, pf[0], oacc[0][nd]);
+            oacc[1][nd] = mfma16<T>(vf, pf[1], oacc[1][nd]);
+          }
+        }
+      }
+    }
+    // ---- denominator = O^T row 128 (ones column: d-fragment 8, g = 0, e = 0), normalise, store 4 consecutive d per lane
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float den = __shfl(oacc[r][8][0], l15);
+      const float inv = 1.0f / den;
+      const int qrow = qb * ATT_QB + wave * 32 + r * 16 + l15;
+      if (qrow < p.Nq) {
+        T* orow = O + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldo + (size_t)h * DH;
+#pragma unroll
+        for (int nd = 0; nd < 8; ++nd) {
+          Pack4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) float_to_elem4<T>(o, e, oacc[r][nd][e] * inv);
+          *reinterpret_cast<u32x2*>(orow + 16 * nd + 4 * g) = o.u;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace ecad

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "attention.h"
+#include "attention128.h"
 #include "common.h"
 #include "elementwise.h"
 #include "fgemm.h"
@@ -178,7 +179,8 @@ template <typename T> class FluxT : public FluxBase {
   double prof_ms[FC_COUNT], prof_flops[FC_COUNT], prof_bytes[FC_COUNT];
   int64_t prof_launch[FC_COUNT];
   int num_cus = 256;
-  int bn_wide = 256, bn_narrow = 128;
+  int bn_force = 0;  // env ECAD_FLUX_BN=128|256 forces one tile width wherever it divides N (A/B)
+  bool attn_generic = false;  // env ECAD_FLUX_ATTN=generic: the d_h-templated kernel of attention.h (A/B)
   const void* call_in = nullptr;
   void* call_out = nullptr;
 
@@ -300,8 +302,8 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipSetDevice(dev));
     FHIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     { hipDeviceProp_t pr; FHIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    if (const char* e = getenv("ECAD_FLUX_BN_WIDE")) bn_wide = atoi(e) == 128 ? 128 : 256;
-    if (const char* e = getenv("ECAD_FLUX_BN_NARROW")) bn_narrow = atoi(e) == 256 ? 256 : 128;
+    if (const char* e = getenv("ECAD_FLUX_BN")) bn_force = atoi(e) == 128 ? 128 : atoi(e) == 256 ? 256 : 0;
+    if (const char* e = getenv("ECAD_FLUX_ATTN")) attn_generic = strcmp(e, "generic") == 0;
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
 
     // ---- weights: a dry layout pass sizes the arena
@@ -348,6 +350,8 @@ template <typename T> class FluxT : public FluxBase {
 #undef FATTR
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
+    FHIPCHK(hipFuncSetAttribute((const void*)attn128_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A128_LDS_BYTES));
+    FHIPCHK(hipFuncSetAttribute((const void*)attn128_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, A128_LDS_BYTES));
     return ECAD_OK;
   }
 
@@ -442,10 +446,19 @@ template <typename T> class FluxT : public FluxBase {
 
   // -------------------------------------------------------------------------------------------
   // plan construction
-  int pick_bn(int Nn) const { return (Nn % 256 == 0 && Nn >= 2 * D) ? bn_wide : ((Nn % 256 == 0 && bn_narrow == 256) ? 256 : 128); }
+  // Tile width per GEMM shape.  A 256-wide tile moves 0.0078 B/flop through L2->LDS instead of 0.0117 and measured ~0.8x the time
+  // per flop (single proj_out: 1039 vs 837 TFLOP/s), but halves the tile count, so the partially filled last round of workgroups
+  // can cost more than it saves (joint ff2 on 8192 image rows: 384 tiles = 1.5 rounds vs 768 = 3.0 rounds: 106 ms vs 88 ms).
+  int pick_bn(int M, int Nn) const {
+    if (Nn % 256) return 128;
+    if (bn_force) return bn_force;
+    const int tm = (M + 255) / 256;
+    const int r256 = (tm * (Nn / 256) + num_cus - 1) / num_cus, r128 = (tm * (Nn / 128) + num_cus - 1) / num_cus;
+    return 1.6 * r256 <= 1.0 * r128 ? 256 : 128;
+  }
   FOp<T> mk_gemm(int cls, int epi, const T* A, int lda, const T* W, const float* bias, T* C, int ldc, int M, int Nn, int K) {
     FOp<T> o;
-    o.kind = FOp<T>::GEMM; o.cls = cls; o.epi = epi; o.bn = pick_bn(Nn);
+    o.kind = FOp<T>::GEMM; o.cls = cls; o.epi = epi; o.bn = pick_bn(M, Nn);
     o.g.A = A; o.g.A2 = nullptr; o.g.W = W; o.g.bias = bias; o.g.C = C; o.g.resid = nullptr; o.g.gate = nullptr; o.g.gate_stride = 0;
     o.g.seg0 = 0; o.g.rows_per_batch0 = 1; o.g.rows_per_batch1 = 1; o.g.M = M; o.g.N = Nn; o.g.K = K; o.g.k_split = K; o.g.lda = lda; o.g.lda2 = 0; o.g.ldw = K; o.g.ldc = ldc; o.g.ldr = 0;
     o.flops = 2.0 * M * Nn * K;
@@ -750,6 +763,11 @@ template <typename T> class FluxT : public FluxBase {
     constexpr int lds = attn_lds_bytes<128, 128>();
     const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
     const int grid = items < num_cus ? items : num_cus;
+    if (!attn_generic) {  // attention128.h: both query fragments of a wave share every K / V fragment read
+      if (a.Nk % 128) hipLaunchKernelGGL((attn128_kernel<T, true>), dim3(grid), dim3(512), A128_LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((attn128_kernel<T, false>), dim3(grid), dim3(512), A128_LDS_BYTES, s, a);
+      return ECAD_OK;
+    }
     if (a.Nk % 128) hipLaunchKernelGGL((attn_kernel<T, 128, true, 128>), dim3(grid), dim3(512), lds, s, a);
     else hipLaunchKernelGGL((attn_kernel<T, 128, false, 128>), dim3(grid), dim3(512), lds, s, a);
     return ECAD_OK;

@@ -1,0 +1,31 @@
+"""FlowMatchEulerDiscreteScheduler with dynamic shifting, as FluxPipeline drives it [ext] (the pipeline the reference calls at
+``ecad/image_generators/flux_image_generator.py:330-360``): host-side constants only -- the update ``x <- x + (sigma[i+1] -
+sigma[i]) * v`` itself runs inside the engine's captured graph (``ecad_flux_run_schedule``)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def calculate_shift(image_seq_len: int, base_seq_len: int = 256, max_seq_len: int = 4096, base_shift: float = 0.5, max_shift: float = 1.16) -> float:
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    return image_seq_len * m + (base_shift - m * base_seq_len)
+
+
+def flow_match_sigmas(num_steps: int, image_seq_len: int) -> np.ndarray:
+    """sigmas[0..num_steps], last = 0: linspace(1, 1/n, n) passed through time_shift(mu, 1, .)."""
+    sig = np.linspace(1.0, 1.0 / num_steps, num_steps)
+    mu = calculate_shift(image_seq_len)
+    sig = math.exp(mu) / (math.exp(mu) + (1.0 / sig - 1.0))
+    return np.concatenate([sig, [0.0]]).astype(np.float32)
+
+
+def model_scalars(sigmas: np.ndarray, guidance_scale: float, dtype: torch.dtype):
+    """(timesteps_x1000 [steps] float32 numpy, guidance_x1000 float): what the transformer sees after `timestep / 1000` is handed
+    over in the model dtype and multiplied by 1000 in that dtype (flux_transformer_2d_edited.py:270-274)."""
+    t = torch.from_numpy(sigmas[:-1].copy()) * 1000.0
+    t_in = (t / 1000.0).to(dtype)
+    g = torch.tensor([guidance_scale], dtype=torch.float32).to(dtype)
+    return (t_in * 1000).float().numpy(), float((g * 1000).float()[0])

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""FLUX.1-dev geometry at 1024x1024 (N = 4096 image tokens + T = 512 text tokens, D = 3072, 19 + 38 blocks), batch 2, 20 steps with
+the reference's transferred schedule (schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json); random-init weights.
+Prints images/s, the per-kernel-class device-time breakdown and achieved TFLOP/s per class."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from ecad_amd.schedulers.cache_scheduler.flux_cache_schedule import FluxCacheSchedule  # noqa: E402
+from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import FluxTransformer2DEdited, synthetic_state_dict  # noqa: E402
+from ecad_amd.pipelines.flow_match import flow_match_sigmas, model_scalars  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--schedule", default="schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json")
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--text", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=19)
+    ap.add_argument("--single", type=int, default=38)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--json", default=None, help="write the result + per-class profile here")
+    a = ap.parse_args()
+    t0 = time.time()
+    sched = FluxCacheSchedule.from_json(ROOT / a.schedule)
+    bf, bs = sched.to_device_bits()
+    bf, bs = bf[:, : a.layers], bs[:, : a.single]
+    model = FluxTransformer2DEdited(num_layers=a.layers, num_single_layers=a.single, guidance_embeds=True, max_batch=a.batch, max_image_tokens=a.grid * a.grid,
+                                    max_text_tokens=a.text, torch_dtype=torch.bfloat16)
+    model.load_state_dict(synthetic_state_dict(model.config, 0, device="cuda", dtype=torch.bfloat16))
+    eng = model.engine
+    eng.set_schedule(bf, bs)
+    print(f"[{time.time() - t0:5.1f}s] engine ready: {eng.stats()}", flush=True)
+    B, N, T = a.batch, a.grid * a.grid, a.text
+    g = torch.Generator(device="cuda").manual_seed(1)
+    enc = (torch.randn(B, T, 4096, generator=g, device="cuda") * 0.1).bfloat16()
+    pooled = (torch.randn(B, 768, generator=g, device="cuda") * 0.5).bfloat16()
+    steps = bf.shape[0]
+    sig = flow_match_sigmas(steps, N)
+    tm, gm = model_scalars(sig, 5.0, torch.bfloat16)
+
+    def run(graph):
+        x = torch.randn(B, N, 64, generator=g, device="cuda")
+        eng.run_schedule(x, enc, pooled, a.grid, a.grid, tm, gm, sig, use_graph=graph)
+        return x
+
+    x = run(True)
+    torch.cuda.synchronize()
+    print(f"[{time.time() - t0:5.1f}s] warm; latents finite: {bool(torch.isfinite(x).all())}, std {float(x.std()):.3f}", flush=True)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(a.iters):
+        run(True)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / a.iters
+    st = eng.stats()
+    tflop = 2 * (st["linear_macs_reference"] + st["attn_core_macs"]) * B / 1e12
+    print(f"flux {a.grid * 16}x{a.grid * 16} batch {B}: {ms:.1f} ms per batch = {B / ms * 1e3:.3f} images/s; reference-equivalent {tflop / B:.1f} TFLOP/image -> {tflop / ms * 1e3:.0f} TFLOP/s whole job")
+    if not a.no_profile:
+        eng.set_profiling(True)
+        run(False)
+        torch.cuda.synchronize()
+        prof = eng.get_profile()
+        eng.set_profiling(False)
+        tot = sum(v["ms"] for v in prof.values())
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+            if v["launches"]:
+                print(f"  {k:24s} {v['ms']:9.2f} ms {100 * v['ms'] / tot:5.1f} %  {v['launches']:5d} launches  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:7.0f} TFLOP/s  {v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:7.0f} GB/s")
+        print(f"  sum {tot:.1f} ms")
+        if a.json:
+            Path(a.json).write_text(json.dumps({"workload": f"flux {a.grid * 16}x{a.grid * 16} batch {B}, {a.schedule}", "ms_per_batch": ms, "images_per_s": B / ms * 1e3,
+                                                "reference_equivalent_tflop_per_image": tflop / B, "whole_job_tflops": tflop / ms * 1e3, "stats": st, "profile": prof}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

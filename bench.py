@@ -105,6 +105,93 @@ def cpu_baseline(weights: dict[str, torch.Tensor], bits: np.ndarray, images: int
     }
 
 
+def main_flux(args, world, rank, device):
+    """Secondary workload (BASELINE config 5): FLUX.1-dev geometry at 1024x1024, batch 2, 20 steps,
+    schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json, bf16 (the reference's dtype), random-init weights; replicas per rank."""
+    from ecad_amd.pipelines.flow_match import flow_match_sigmas, model_scalars
+    from ecad_amd.schedulers.cache_scheduler.flux_cache_schedule import FluxCacheSchedule
+    from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import FluxTransformer2DEdited, synthetic_state_dict
+
+    B, grid, T = 2, 64, 512
+    sched_path = "schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json"
+    sched = FluxCacheSchedule.from_json(ROOT / sched_path)
+    model = FluxTransformer2DEdited(guidance_embeds=True, max_batch=B, max_image_tokens=grid * grid, max_text_tokens=T, torch_dtype=torch.bfloat16, device=device.index)
+    model.load_state_dict(synthetic_state_dict(model.config, 0, device=str(device), dtype=torch.bfloat16))
+    eng = model.engine
+    eng.set_schedule(*sched.to_device_bits())
+    log("flux engine ready")
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    enc = (torch.randn(B, T, 4096, generator=g, device=device) * 0.1).bfloat16()
+    pooled = (torch.randn(B, 768, generator=g, device=device) * 0.5).bfloat16()
+    lat0 = torch.randn(B, grid * grid, 64, generator=g, device=device)
+    sig = flow_match_sigmas(sched.num_inference_steps, grid * grid)
+    tm, gm = model_scalars(sig, 5.0, torch.bfloat16)
+
+    def one_batch(graph=True):
+        return eng.run_schedule(lat0.clone(), enc, pooled, grid, grid, tm, gm, sig, use_graph=graph)
+
+    use_graph = not args.no_graph
+    for _ in range(max(args.warmup, 1)):
+        out = one_batch(use_graph)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all(), "non-finite latents"
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_batch(use_graph)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        st = eng.stats()
+        value = world * B * args.steps / elapsed
+        flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"])
+        res = {
+            "metric": "images/sec at fixed schedule (FLUX.1-dev 1024, 20-step, fast_256_to_1024) [secondary]", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": f"FLUX.1-dev geometry 1024x1024 (N=4096 + T=512 tokens, D=3072, 19+38 blocks), 20 steps, {sched_path}, batch=2 (no CFG; guidance 5 embedded), 1xMI355X per rank",
+                "batch_per_gpu": B, "timed_region": "context/pooled embedding hoist, all-step adaLN GEMM, 20 transformer steps with cache gate, flow-match Euler; packed latents out (no VAE/PIL)",
+                "weights": "random-init FLUX.1-dev shapes, 11.9 B parameters (no checkpoint available offline)", "hipgraph": bool(use_graph and st["graph_nodes"] > 0),
+                "kernel_launches_per_batch": st["launches_per_batch"], "ms_per_image": 1000.0 * elapsed / (args.steps * B),
+                "reference_equivalent_tflop_per_image": flop_per_image / 1e12, "whole_job_mfma_fraction": value / world * flop_per_image / 1e12 / PEAK_MFMA_TFLOPS,
+                "components_executed_cached_dead": [st["components_executed"], st["components_cached"], st["components_dead"]],
+                "published_reference_a6000_images_per_s": 0.144,
+            },
+        }
+        if not args.no_roofline:
+            eng.set_profiling(True)
+            one_batch(False)
+            torch.cuda.synchronize()
+            prof = eng.get_profile()
+            eng.set_profiling(False)
+            mf = {k: v for k, v in prof.items() if (k.startswith("gemm") or k.startswith("attn")) and v["launches"] > 0}
+            dom = max(mf, key=lambda k: mf[k]["ms"])
+            d = mf[dom]
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            gem = [v for k, v in mf.items() if k.startswith("gemm")]
+            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS,
+                               "traffic": None, "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "flops_per_launch": d["flops"] / d["launches"],
+                               "avg_launch_ms": d["ms"] / d["launches"], "launches_measured": d["launches"],
+                               "all_gemm_tflops": sum(v["flops"] for v in gem) / (sum(v["ms"] for v in gem) * 1e-3) / 1e12}
+            res["time_breakdown_ms_per_batch"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
+            res["time_breakdown_ms_per_batch"]["_sum"] = round(sum(v["ms"] for v in prof.values()), 3)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,8 +202,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--decode-tail", action="store_true", help="also measure the secondary PNG-ready rate (HIP VAE decode + PIL)")
     ap.add_argument("--no-decode-tail", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024"],
-                    help="alpha256 = BASELINE metric config (default); sigma1024 = BASELINE config 3 (secondary, not the headline)")
+    ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024", "flux1024"],
+                    help="alpha256 = BASELINE metric config (default); sigma1024 / flux1024 = BASELINE configs 3 / 5 (secondary, not the headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,6 +218,9 @@ def main():
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    if args.workload == "flux1024":
+        return main_flux(args, world, rank, device)
 
     from ecad_amd.engine import EcadEngine
     from ecad_amd.pipelines.dpm_solver import DPMSolverMultistepScheduler

@@ -1,6 +1,7 @@
 """Image-generator registry (reference: ``ecad/image_generators/load_image_generator.py:16-84``)."""
 from __future__ import annotations
 
+from ecad_amd.image_generators.flux_image_generator import FluxImageGenerator
 from ecad_amd.image_generators.image_generator import ImageGenerator
 from ecad_amd.image_generators.pixart_image_generator import PixArtAlphaImageGenerator, PixArtSigmaImageGenerator
 
@@ -9,7 +10,7 @@ class ImageGeneratorRegistry:
     registry: dict[str, type[ImageGenerator]] = {
         "PixArtAlphaImageGenerator": PixArtAlphaImageGenerator,
         "PixArtSigmaImageGenerator": PixArtSigmaImageGenerator,
-        # "FluxImageGenerator": next row, not built yet
+        "FluxImageGenerator": FluxImageGenerator,
     }
 
     @classmethod

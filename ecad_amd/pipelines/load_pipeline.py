@@ -1,12 +1,13 @@
 """Pipeline registry (reference: ``ecad/pipelines/load_pipeline.py:16-58``).
 
-``pixart_alpha`` / ``pixart_sigma`` resolve to the native-engine pipeline; ``tgate``,
-``pass_through`` and ``flux`` are outside the hot-path scope and raise.
+``pixart_alpha`` / ``pixart_sigma`` / ``flux`` resolve to the native-engine pipelines; ``tgate`` and
+``pass_through`` are outside the hot-path scope and raise.
 """
 from __future__ import annotations
 
 from typing import Any, Callable
 
+from ecad_amd.pipelines.flux import FluxPipeline
 from ecad_amd.pipelines.pixart_alpha import PixArtAlphaPipeline, PixArtSigmaPipeline
 
 
@@ -14,8 +15,9 @@ class PipelineRegistry:
     _registry: dict[str, type] = {
         "pixart_alpha": PixArtAlphaPipeline,
         "pixart_sigma": PixArtSigmaPipeline,
+        "flux": FluxPipeline,
     }
-    _out_of_scope = ("tgate", "flux", "pass_through")
+    _out_of_scope = ("tgate", "pass_through")
 
     @classmethod
     def get(cls, name: str, default_name: str | None = None) -> type | None:

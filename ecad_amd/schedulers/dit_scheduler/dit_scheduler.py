@@ -51,3 +51,22 @@ class DiTScheduler:
 
     def per_step_callback(self, step: int, timestep: Any = None, **kwargs: Any) -> None:
         self._last_step = step
+
+
+class FluxDiTSchedule(PixArtDiTSchedule):
+    """Reference: ``ecad/schedulers/dit_scheduler/flux_dit_schedule.py:16-149``.  The reference's own forward already
+    short-circuits the fx graph (``flux_transformer_2d_edited.py:191-214,288-293``), so only the step counter and
+    ``num_single_blocks`` are kept."""
+
+    def __init__(self, num_blocks: int, num_inference_steps: int, name: str = "default", top_level_config=None, attributes=None, metrics=None,
+                 num_single_blocks: int = 38, **kw):
+        super().__init__(num_blocks, num_inference_steps, name, top_level_config, attributes, metrics)
+        self.num_single_blocks = num_single_blocks
+
+    @classmethod
+    def from_json(cls, file_path: Path) -> "FluxDiTSchedule":
+        with Path(file_path).open() as f:
+            data = json.load(f)
+        body = data["dit_schedule"]  # KeyError => caller falls back to the default
+        return cls(body["num_blocks"], body["num_inference_steps"], body.get("name", "default"), data.get("config"), body.get("attributes"), data.get("metrics"),
+                   num_single_blocks=body["num_single_blocks"])

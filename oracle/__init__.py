@@ -17,6 +17,9 @@ What is restated here (each function cites the reference file:line it follows):
   that ``ecad/transformer_2d_models/pixart_transformer_2d_edited.py`` and
   ``ecad/transformer_blocks/cached_transformer_block.py`` drive, including the
   cache gate.
+* ``flux_ref``      -- the same for FLUX.1 (``flux_transformer_2d_edited.py``, ``cached_flux_transformer_block.py``):
+  joint + single-stream blocks with the six-component cache gate, RoPE, flow-match Euler loop.  Its schedule/MAC half
+  (``schedule_ref.flux_*``) is PINNED on the reference's 38 FLUX schedule metrics and captured ``FluxCacheSchedule`` vectors.
 * ``dpm_solver_ref`` / ``pipeline_ref`` -- the denoising loop mirrored at
   ``ecad/pipelines/pass_through.py:297-380`` and DPM-Solver++(2M).
 

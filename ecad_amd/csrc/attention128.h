@@ -7,19 +7,25 @@
 // not the MFMAs, bound the kernel: a wave owns 32 query rows and BOTH 16-row fragments consume every K / V fragment it reads
 // (half the LDS traffic of two sequential rounds), the score strip covers 64 keys at a time (32 VGPRs for both fragments), and
 // the V tile row stride is 144 elements (288 B = 8 banks mod 64: the 8 rows x 32 B of a 32-lane transposed read tile the 64
-// banks exactly; the 152-element stride of the generic kernel collides).
+// banks exactly).  Also instantiated for the PixArt head dim 72 (engine.hip), where it replaced the two-sequential-rounds kernel
+// of attention.h: self-attention 9.1 -> 7.1 ms per alpha-256 batch, 256 -> 185 ms per Sigma-1024 batch.  Measured null: skipping
+// the accumulator rescale when no running maximum moved (ballot + branch cost what the 72 multiplies did).
 #pragma once
 #include "attention.h"
 #include "common.h"
 
 namespace ecad {
 
-constexpr int A128_KC = 128, A128_KS = 136, A128_VS = 144, A128_DH = 128;
-constexpr int A128_LDS_BYTES = A128_KC * (A128_KS + A128_VS) * 2 + A128_KC * 4;  // 74240
+constexpr int A128_KC = 128;
+constexpr int A128_LDS_BYTES = attn_lds_bytes<A128_KC, 128>();  // 74240
+constexpr int A72_LDS_BYTES = attn_lds_bytes<A128_KC, 72>();    // 47616
 
-template <typename T, bool TAIL>
+// TAIL: keys beyond Nk are masked and (PixArt cross-attention) the additive per-key bias p.bias is applied.
+// DHC = 128 (FLUX) or 72 (PixArt: K zero-padded to 96, V to 80 in LDS only; the generic kernel's strides).
+template <typename T, bool TAIL, int DHC = 128>
 __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
-  constexpr int KC = A128_KC, KS = A128_KS, VS = A128_VS, DH = A128_DH, ND = 9, KSTEPS = 4, NCH = 16;
+  constexpr int KC = A128_KC, KS = AttCfg<DHC>::KS, VS = AttCfg<DHC>::VS, DH = DHC, ND = AttCfg<DHC>::ND, KSTEPS = AttCfg<DHC>::KSTEPS, NCH = AttCfg<DHC>::NCH;
+  constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0);  // d-fragments that hold real output columns
   extern __shared__ __attribute__((aligned(16))) char att_smem[];
   T* Ks = reinterpret_cast<T*>(att_smem);
   T* Vs = Ks + KC * KS;
@@ -27,7 +33,7 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  constexpr int MAXL = KC * NCH * 2 / 512;  // 8 staging loads per thread
+  constexpr int MAXL = (KC * NCH * 2 + 511) / 512;  // staging loads per thread: 8 (d_h 128) / 5 (d_h 72)
 
   const T* Q = reinterpret_cast<const T*>(p.q);
   const T* K = reinterpret_cast<const T*>(p.k);
@@ -41,34 +47,49 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
   __syncthreads();
   for (int i = tid; i < KC; i += 512) Vs[i * VS + DH] = (T)1.0f;
 
-  // staging: thread owns chunk column c = tid % 16 of keys tid / 16 + 32 i, K tile for i < 4 and V tile for i >= 4
+  // staging ids run over [K chunks | V chunks]; for d_h = 128 a thread owns one chunk column of 4 K rows and 4 V rows
   Pack8 stg[MAXL];
   auto load_stage = [&](int item, int kc) {
     const int bh = item / nqb;
     const int h = bh % p.H, b = bh / p.H;
-    const int c = tid & 15;
 #pragma unroll
     for (int i = 0; i < MAXL; ++i) {
-      const int key = (tid >> 4) + 32 * (i & 3);
-      const int gk = kc * KC + key;
+      int id = tid + i * 512;
       stg[i].u = (u32x4){0, 0, 0, 0};
-      if (!TAIL || gk < p.Nk) {
-        const size_t grow = att_row(b, gk, p.Nk, p.seg_t, p.seg_bt);
-        const T* base = i >= 4 ? V + grow * p.ldv : K + grow * p.ldk;
-        stg[i] = gload16(base + (size_t)h * DH + c * 8);
+      if (id < 2 * KC * NCH) {
+        const bool isv = id >= KC * NCH;
+        id = isv ? id - KC * NCH : id;
+        const int key = id / NCH, c = id - key * NCH;
+        const int gk = kc * KC + key;
+        if (!TAIL || gk < p.Nk) {
+          const size_t grow = att_row(b, gk, p.Nk, p.seg_t, p.seg_bt);
+          const T* base = isv ? V + grow * p.ldv : K + grow * p.ldk;
+          stg[i] = gload16(base + (size_t)h * DH + c * 8);
+        }
       }
     }
   };
-  auto store_stage = [&](int kc) {
-    const int c = tid & 15;
+  auto store_stage = [&](int item, int kc) {
 #pragma unroll
     for (int i = 0; i < MAXL; ++i) {
-      const int key = (tid >> 4) + 32 * (i & 3);
-      T* dst = i >= 4 ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
-      *reinterpret_cast<u32x4*>(dst) = stg[i].u;
+      int id = tid + i * 512;
+      if (id < 2 * KC * NCH) {
+        const bool isv = id >= KC * NCH;
+        id = isv ? id - KC * NCH : id;
+        const int key = id / NCH, c = id - key * NCH;
+        T* dst = isv ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
+        *reinterpret_cast<u32x4*>(dst) = stg[i].u;
+      }
     }
-    if (TAIL)
-      for (int i = tid; i < KC; i += 512) bias_s[i] = kc * KC + i < p.Nk ? 0.f : ATT_NEG;
+    if (TAIL) {
+      const int b = (item / nqb) / p.H;
+      for (int i = tid; i < KC; i += 512) {
+        const int gk = kc * KC + i;
+        float bv = ATT_NEG;
+        if (gk < p.Nk) bv = p.bias ? p.bias[(size_t)b * p.Nk + gk] * 1.4426950408889634f : 0.f;
+        bias_s[i] = bv;
+      }
+    }
   };
 
   int item = blockIdx.x;
@@ -89,12 +110,12 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         qfr[r][ks].u = (u32x4){0, 0, 0, 0};
-        if (qrow < p.Nq) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * DH + 32 * ks + 8 * g);
+        if (qrow < p.Nq && 32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * DH + 32 * ks + 8 * g);
       }
     }
     for (int kc = 0; kc < nkc; ++kc) {
       __syncthreads();  // every wave finished reading the previous chunk
-      store_stage(kc);
+      store_stage(item, kc);
       __syncthreads();
       if (kc + 1 < nkc) load_stage(item, kc + 1);
       else if (item + (int)gridDim.x < items) load_stage(item + gridDim.x, 0);
@@ -180,20 +201,23 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
         }
       }
     }
-    // ---- denominator = O^T row 128 (ones column: d-fragment 8, g = 0, e = 0), normalise, store 4 consecutive d per lane
+    // ---- denominator = O^T row DH (ones column: d-fragment DH / 16, g = (DH % 16) / 4, e = DH % 4), normalise, store
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const float den = __shfl(oacc[r][8][0], l15);
+      constexpr int DL = DH & 15;
+      const float den = __shfl(oacc[r][DH >> 4][DL & 3], l15 + 16 * (DL >> 2));
       const float inv = 1.0f / den;
       const int qrow = qb * ATT_QB + wave * 32 + r * 16 + l15;
       if (qrow < p.Nq) {
         T* orow = O + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldo + (size_t)h * DH;
 #pragma unroll
-        for (int nd = 0; nd < 8; ++nd) {
-          Pack4 o;
+        for (int nd = 0; nd < NDO; ++nd) {
+          if (16 * nd + 4 * g + 4 <= DH) {
+            Pack4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) float_to_elem4<T>(o, e, oacc[r][nd][e] * inv);
-          *reinterpret_cast<u32x2*>(orow + 16 * nd + 4 * g) = o.u;
+            for (int e = 0; e < 4; ++e) float_to_elem4<T>(o, e, oacc[r][nd][e] * inv);
+            *reinterpret_cast<u32x2*>(orow + 16 * nd + 4 * g) = o.u;
+          }
         }
       }
     }

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "attention.h"
+#include "attention128.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
@@ -193,6 +194,7 @@ template <typename T> class EngineT : public EngineBase {
     gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = 0;
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
+    if (const char* at = getenv("ECAD_ATTN")) attn_shared = strcmp(at, "generic") != 0;
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
       if (strcmp(gi, "persistent") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
@@ -696,7 +698,22 @@ template <typename T> class EngineT : public EngineBase {
     hipLaunchKernelGGL((attn_kernel<T, KC, MASKED>), dim3(items < cap ? items : cap), dim3(512), lds, s, a);
     return ECAD_OK;
   }
+  int attn_shared = 1;  // attention128.h structure (both query fragments of a wave share each K / V fragment read); env ECAD_ATTN=generic: attention.h
+  bool attn_shared_attr[2] = {};
   int launch_attn(const AttnArgs& a, bool masked, hipStream_t s) {
+    if (attn_shared && a.dh == 72) {
+      const bool tail = masked || a.Nk % 128;
+      if (!attn_shared_attr[tail]) {
+        if (tail) HIPCHK(hipFuncSetAttribute((const void*)attn128_kernel<T, true, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, A72_LDS_BYTES));
+        else HIPCHK(hipFuncSetAttribute((const void*)attn128_kernel<T, false, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, A72_LDS_BYTES));
+        attn_shared_attr[tail] = true;
+      }
+      const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
+      const int grid = items < num_cus ? items : num_cus;
+      if (tail) hipLaunchKernelGGL((attn128_kernel<T, true, 72>), dim3(grid), dim3(512), A72_LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((attn128_kernel<T, false, 72>), dim3(grid), dim3(512), A72_LDS_BYTES, s, a);
+      return ECAD_OK;
+    }
     // KC = 128 keys per LDS chunk for both kinds (a 256-key strip in registers spills: 64 score + 36 staging VGPRs)
     if (masked || a.Nk % 128) return launch_attn_t<128, true>(a, 0, 1, s);
     return launch_attn_t<128, false>(a, 1, 1, s);

@@ -128,6 +128,8 @@ SIGNATURES = {
     "ecad_vae_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
     "ecad_vae_finalize_weights": (_I, [_P]),
     "ecad_vae_decode": (_I, [_P, _P, _I, _I, _I, C.c_float, _P, _P]),
+    "ecad_vae_create_ex": (_I, [_I, _I, _I, _I, C.POINTER(_P)]),
+    "ecad_vae_decode_ex": (_I, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P]),
     # include/ecad_flux.h
     "ecad_flux_create": (_I, [C.POINTER(EcadFluxCfg), _I, C.POINTER(_P)]),
     "ecad_flux_destroy": (None, [_P]),

@@ -42,6 +42,8 @@ template <typename TS, typename TD> __global__ void vae_relayout_kernel(const TS
 
 struct VaeBase {
   int dev = 0;
+  int latent_ch = 4;   // 4: SD / PixArt VAE; 16: FLUX VAE
+  bool use_pq = true;  // post_quant_conv present (AutoencoderKL use_post_quant_conv; False for the FLUX VAE)
   std::string err;
   virtual ~VaeBase() {}
   int fail(int code, const char* fmt, ...) {
@@ -56,7 +58,7 @@ struct VaeBase {
   virtual int init() = 0;
   virtual int load(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
   virtual int finalize() = 0;
-  virtual int decode(const float* lat, int B, int h, int w, float scaling, uint8_t* out, hipStream_t s) = 0;
+  virtual int decode(const float* lat, int B, int h, int w, float scaling, float shift, uint8_t* out, hipStream_t s) = 0;
 };
 
 template <typename T> struct VaeT : VaeBase {
@@ -108,8 +110,9 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipMalloc(&zero_page, 256));
     VHIPCHK(hipMemset(zero_page, 0, 256));
     allocs.push_back(zero_page);
-    REG("post_quant_conv.weight", F32, 4, 4) REG("post_quant_conv.bias", F32, 4, 0)
-    REG("decoder.conv_in.weight", F32, 512, 36) REG("decoder.conv_in.bias", F32, 512, 0)
+    if (latent_ch != 4 && latent_ch != 16) return fail(ECAD_E_UNSUPPORTED, "latent_channels %d unsupported (4 or 16)", latent_ch);
+    if (use_pq) { REG("post_quant_conv.weight", F32, latent_ch, latent_ch) REG("post_quant_conv.bias", F32, latent_ch, 0) }
+    REG("decoder.conv_in.weight", F32, 512, latent_ch * 9) REG("decoder.conv_in.bias", F32, 512, 0)
     int rc;
     if ((rc = reg_resnet("decoder.mid_block.resnets.0.", 512, 512))) return rc;
     if ((rc = reg_resnet("decoder.mid_block.resnets.1.", 512, 512))) return rc;
@@ -135,6 +138,7 @@ template <typename T> struct VaeT : VaeBase {
     auto it = wt.find(name);
     if (it == wt.end()) {
       if (strncmp(name, "encoder.", 8) == 0 || strncmp(name, "quant_conv.", 11) == 0) return ECAD_OK;  // encoder half is unused
+      if (!use_pq && strncmp(name, "post_quant_conv.", 16) == 0) return ECAD_OK;
       return fail(ECAD_E_INVALID, "unknown VAE weight '%s'", name);
     }
     W& w = it->second;
@@ -229,7 +233,7 @@ template <typename T> struct VaeT : VaeBase {
     return conv(t2, p + "conv2", out, res, B, H, W, cout, cout, 9, 0, s);
   }
 
-  int decode(const float* lat, int B, int h, int w, float scaling, uint8_t* out, hipStream_t s) override {
+  int decode(const float* lat, int B, int h, int w, float scaling, float shift, uint8_t* out, hipStream_t s) override {
     VHIPCHK(hipSetDevice(dev));
     if (!finalized) return fail(ECAD_E_NOT_READY, "VAE weights not finalized");
     if (B < 1 || h < 4 || w < 4 || (h * w) % 128 || (w & 1)) return fail(ECAD_E_INVALID, "latent %dx%dx%d unsupported (h*w must be a multiple of 128, w even)", B, h, w);
@@ -237,8 +241,15 @@ template <typename T> struct VaeT : VaeBase {
     if (rc) return rc;
     T *x = bufA, *y = bufB, *t = bufC;
     int H = h, Wd = w;
-    hipLaunchKernelGGL((vae_conv_in_kernel<T>), dim3((H * Wd + CIN_PIX - 1) / CIN_PIX, B), dim3(256), 0, s, lat, W_<float>("post_quant_conv.weight"), W_<float>("post_quant_conv.bias"),
-                       W_<float>("decoder.conv_in.weight"), W_<float>("decoder.conv_in.bias"), x, B, H, Wd, 512, 1.0f / scaling);
+    {
+      const float* pqw = use_pq ? W_<float>("post_quant_conv.weight") : nullptr;
+      const float* pqb = use_pq ? W_<float>("post_quant_conv.bias") : nullptr;
+      const dim3 grid((H * Wd + CIN_PIX - 1) / CIN_PIX, B);
+      if (latent_ch == 4)
+        hipLaunchKernelGGL((vae_conv_in_kernel<T, 4>), grid, dim3(256), 0, s, lat, pqw, pqb, W_<float>("decoder.conv_in.weight"), W_<float>("decoder.conv_in.bias"), x, B, H, Wd, 512, 1.0f / scaling, shift);
+      else
+        hipLaunchKernelGGL((vae_conv_in_kernel<T, 16>), grid, dim3(256), 0, s, lat, pqw, pqb, W_<float>("decoder.conv_in.weight"), W_<float>("decoder.conv_in.bias"), x, B, H, Wd, 512, 1.0f / scaling, shift);
+    }
     // ---- mid block
     if ((rc = resnet("decoder.mid_block.resnets.0.", x, y, t, bufD, B, H, Wd, 512, 512, s))) return rc;
     {  // attention: one head of 512 channels over H*W tokens; result back into x
@@ -296,7 +307,9 @@ using namespace ecad;
 struct EcadVae { VaeBase* impl; };
 
 extern "C" {
-int ecad_vae_create(int device, int dtype, EcadVae** out) {
+int ecad_vae_create_ex(int device, int dtype, int latent_channels, int use_post_quant_conv, EcadVae** out);
+int ecad_vae_create(int device, int dtype, EcadVae** out) { return ecad_vae_create_ex(device, dtype, 4, 1, out); }
+int ecad_vae_create_ex(int device, int dtype, int latent_channels, int use_post_quant_conv, EcadVae** out) {
   if (!out) return ECAD_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_vae_create_error = "no HIP device visible"; return ECAD_E_HIP; }
@@ -305,6 +318,8 @@ int ecad_vae_create(int device, int dtype, EcadVae** out) {
   else if (dtype == ECAD_DTYPE_BF16) impl = new VaeT<bf16_t>();
   else { g_vae_create_error = "dtype must be f16 or bf16"; return ECAD_E_INVALID; }
   impl->dev = device;
+  impl->latent_ch = latent_channels;
+  impl->use_pq = use_post_quant_conv != 0;
   int rc = impl->init();
   if (rc) { g_vae_create_error = impl->err; delete impl; return rc; }
   *out = new EcadVae{impl};
@@ -319,6 +334,10 @@ int ecad_vae_load_weights(EcadVae* v, const char* name, const void* ptr, int dty
 int ecad_vae_finalize_weights(EcadVae* v) { return v ? v->impl->finalize() : ECAD_E_INVALID; }
 int ecad_vae_decode(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, uint8_t* out_u8_dev, void* stream) {
   if (!v || !latents_dev || !out_u8_dev) return ECAD_E_INVALID;
-  return v->impl->decode(latents_dev, B, h, w, scaling_factor, out_u8_dev, (hipStream_t)stream);
+  return v->impl->decode(latents_dev, B, h, w, scaling_factor, 0.f, out_u8_dev, (hipStream_t)stream);
+}
+int ecad_vae_decode_ex(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, float shift_factor, uint8_t* out_u8_dev, void* stream) {
+  if (!v || !latents_dev || !out_u8_dev) return ECAD_E_INVALID;
+  return v->impl->decode(latents_dev, B, h, w, scaling_factor, shift_factor, out_u8_dev, (hipStream_t)stream);
 }
 }

@@ -252,37 +252,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
-// ---- first layer: latents fp32 NCHW [B,4,h,w] / scaling -> post_quant_conv (1x1, 4->4) -> conv_in (3x3, 4->C) -> NHWC
-// A block owns CIN_PIX consecutive pixels of one image; each thread keeps the 36 weights of its channel(s) in registers.
+// ---- first layer: latents fp32 NCHW [B,CL,h,w] / scaling + shift -> [post_quant_conv (1x1, CL->CL)] -> conv_in (3x3, CL->C) -> NHWC
+// CL = 4 (SD / PixArt VAE, with post_quant_conv) or 16 (FLUX VAE: no post_quant_conv, shift_factor 0.1159).
+// A block owns CIN_PIX consecutive pixels of one image; each thread keeps the CL*9 weights of its channel(s) in registers.
 constexpr int CIN_PIX = 32;
-template <typename T>
+template <typename T, int CL>
 __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restrict__ lat, const float* __restrict__ pq_w, const float* __restrict__ pq_b,
-                                                          const float* __restrict__ w /*[C][4][3][3]*/, const float* __restrict__ bias, T* __restrict__ out,
-                                                          int B, int H, int W, int C, float inv_scale) {
+                                                          const float* __restrict__ w /*[C][CL][3][3]*/, const float* __restrict__ bias, T* __restrict__ out,
+                                                          int B, int H, int W, int C, float inv_scale, float shift) {
+  constexpr int KK = CL * 9;
   const int pix0 = blockIdx.x * CIN_PIX, b = blockIdx.y;
-  __shared__ float z[CIN_PIX][36];  // [pixel][ci * 9 + tap]: post_quant_conv output at the 9 neighbours (0 outside the image)
-  for (int id = threadIdx.x; id < CIN_PIX * 36; id += 256) {
-    const int pl = id / 36, k = id % 36, co = k / 9, tap = k % 9;
+  __shared__ float z[CIN_PIX][KK];  // [pixel][ci * 9 + tap]: (post_quant_conv'd) latent at the 9 neighbours (0 outside the image)
+  for (int id = threadIdx.x; id < CIN_PIX * KK; id += 256) {
+    const int pl = id / KK, k = id % KK, co = k / 9, tap = k % 9;
     const int pix = pix0 + pl;
     const int y = pix / W, x = pix % W;
     const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
     float v = 0.f;
     if (pix < H * W && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      v = pq_b[co];
-      for (int ci = 0; ci < 4; ++ci) v += pq_w[co * 4 + ci] * lat[(((size_t)b * 4 + ci) * H + yy) * W + xx] * inv_scale;
+      if (pq_w) {
+        v = pq_b[co];
+        for (int ci = 0; ci < CL; ++ci) v += pq_w[co * CL + ci] * (lat[(((size_t)b * CL + ci) * H + yy) * W + xx] * inv_scale + shift);
+      } else {
+        v = lat[(((size_t)b * CL + co) * H + yy) * W + xx] * inv_scale + shift;
+      }
     }
     z[pl][k] = v;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    float wr[36];
+    float wr[KK];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) wr[k] = w[c * 36 + k];
+    for (int k = 0; k < KK; ++k) wr[k] = w[c * KK + k];
     const float bc = bias[c];
     for (int pl = 0; pl < CIN_PIX && pix0 + pl < H * W; ++pl) {
       float a = bc;
 #pragma unroll
-      for (int k = 0; k < 36; ++k) a = __builtin_fmaf(wr[k], z[pl][k], a);
+      for (int k = 0; k < KK; ++k) a = __builtin_fmaf(wr[k], z[pl][k], a);
       out[((size_t)b * H * W + pix0 + pl) * C + c] = (T)a;
     }
   }

@@ -113,7 +113,17 @@ class FluxPipeline:
         return (image,) if not return_dict else {"images": image}
 
     def decode(self, latents: torch.Tensor, output_type: str = "pil"):
-        """16-channel FLUX VAE decode when a VAE module is attached (PyTorch); otherwise a labelled channel-mean preview."""
+        """16-channel FLUX VAE decode: the native decoder (``HipVaeDecoder`` with the FLUX geometry) or any torch module with ``.decode``;
+        without a VAE a labelled three-channel preview of the latents."""
+        if self.vae is not None and hasattr(self.vae, "decode_to_uint8"):
+            arr = self.vae.decode_to_uint8(latents).cpu().numpy()
+            if output_type == "np":
+                return arr
+            if output_type == "pt":
+                return torch.from_numpy(arr).permute(0, 3, 1, 2).float() / 255.0
+            from PIL import Image
+
+            return [Image.fromarray(a) for a in arr]
         if self.vae is not None:
             cfg = self.vae.config
             img = self.vae.decode(latents / getattr(cfg, "scaling_factor", 0.3611) + getattr(cfg, "shift_factor", 0.1159), return_dict=False)[0]

@@ -100,16 +100,22 @@ class Decoder(nn.Module):
 class AutoencoderKLDecoderOnly(nn.Module):
     """``vae.decode(latents / scaling_factor, return_dict=False)[0]`` surface the pipeline uses."""
 
-    def __init__(self, scaling_factor: float = 0.18215, latent_channels: int = 4):
+    def __init__(self, scaling_factor: float = 0.18215, latent_channels: int = 4, use_post_quant_conv: bool = True, shift_factor: float = 0.0):
         super().__init__()
-        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1) if use_post_quant_conv else None
         self.decoder = Decoder(latent_channels)
-        self.config = SimpleNamespace(scaling_factor=scaling_factor, latent_channels=latent_channels)
+        self.config = SimpleNamespace(scaling_factor=scaling_factor, latent_channels=latent_channels, use_post_quant_conv=use_post_quant_conv, shift_factor=shift_factor)
+
+    @classmethod
+    def flux(cls) -> "AutoencoderKLDecoderOnly":
+        """Geometry of the FLUX.1 VAE [ext]: 16 latent channels, no post_quant_conv, scaling 0.3611, shift 0.1159."""
+        return cls(scaling_factor=0.3611, latent_channels=16, use_post_quant_conv=False, shift_factor=0.1159)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):
         p = next(self.parameters())
-        x = self.decoder(self.post_quant_conv(z.to(p.dtype).contiguous(memory_format=torch.channels_last)))
+        z = z.to(p.dtype).contiguous(memory_format=torch.channels_last)
+        x = self.decoder(self.post_quant_conv(z) if self.post_quant_conv is not None else z)
         return (x,)
 
     @classmethod
@@ -125,7 +131,8 @@ class HipVaeDecoder:
     PyTorch ``AutoencoderKLDecoderOnly`` (or any state dict with diffusers' AutoencoderKL keys).
     """
 
-    def __init__(self, scaling_factor: float = 0.18215, dtype: torch.dtype = torch.float16, device: int = 0):
+    def __init__(self, scaling_factor: float = 0.18215, dtype: torch.dtype = torch.float16, device: int = 0, latent_channels: int = 4,
+                 use_post_quant_conv: bool = True, shift_factor: float = 0.0):
         import ctypes as C
 
         from ecad_amd import _lib as L
@@ -133,9 +140,9 @@ class HipVaeDecoder:
         self._C, self._L = C, L
         self.lib = L.load()
         self.dtype, self.device_index = dtype, device
-        self.config = SimpleNamespace(scaling_factor=scaling_factor, latent_channels=4)
+        self.config = SimpleNamespace(scaling_factor=scaling_factor, latent_channels=latent_channels, use_post_quant_conv=use_post_quant_conv, shift_factor=shift_factor)
         self._h = C.c_void_p()
-        rc = self.lib.ecad_vae_create(device, L.ECAD_DTYPE_F16 if dtype == torch.float16 else L.ECAD_DTYPE_BF16, C.byref(self._h))
+        rc = self.lib.ecad_vae_create_ex(device, L.ECAD_DTYPE_F16 if dtype == torch.float16 else L.ECAD_DTYPE_BF16, latent_channels, int(use_post_quant_conv), C.byref(self._h))
         if rc != 0:
             raise RuntimeError((self.lib.ecad_vae_last_error(None) or b"ecad_vae_create failed").decode())
 
@@ -158,15 +165,18 @@ class HipVaeDecoder:
 
     @classmethod
     def from_torch(cls, module: "AutoencoderKLDecoderOnly", device: int = 0, dtype: torch.dtype = torch.float16) -> "HipVaeDecoder":
-        return cls(module.config.scaling_factor, dtype, device).load_state_dict(module.state_dict())
+        c = module.config
+        return cls(c.scaling_factor, dtype, device, c.latent_channels, getattr(c, "use_post_quant_conv", True), getattr(c, "shift_factor", 0.0) or 0.0).load_state_dict(module.state_dict())
 
     def decode_to_uint8(self, latents: torch.Tensor, stream=None) -> torch.Tensor:
-        """latents: [B, 4, h, w] (un-scaled pipeline latents) -> uint8 [B, 8h, 8w, 3] on the device."""
+        """latents: [B, latent_channels, h, w] (un-scaled pipeline latents) -> uint8 [B, 8h, 8w, 3] on the device."""
         lat = latents.to(device=torch.device("cuda", self.device_index), dtype=torch.float32).contiguous()
         B, _, h, w = lat.shape
         out = torch.empty((B, 8 * h, 8 * w, 3), dtype=torch.uint8, device=lat.device)
         st = torch.cuda.current_stream() if stream is None else stream
-        self._chk(self.lib.ecad_vae_decode(self._h, lat.data_ptr(), B, h, w, float(self.config.scaling_factor), out.data_ptr(), int(st.cuda_stream)))
+        if lat.shape[1] != self.config.latent_channels:
+            raise ValueError(f"latents have {lat.shape[1]} channels, decoder expects {self.config.latent_channels}")
+        self._chk(self.lib.ecad_vae_decode_ex(self._h, lat.data_ptr(), B, h, w, float(self.config.scaling_factor), float(self.config.shift_factor), out.data_ptr(), int(st.cuda_stream)))
         return out
 
     def close(self):

@@ -158,6 +158,10 @@ int ecad_vae_finalize_weights(EcadVae* v);
 /* latents_dev: [B, 4, h, w] float32 (un-scaled, as the pipeline holds them); out_u8_dev: [B, 8h, 8w, 3] uint8 RGB = the bytes
  * PIL.Image.fromarray wants, after (x / 2 + 0.5).clamp(0, 1) * 255 rounding. */
 int ecad_vae_decode(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, uint8_t* out_u8_dev, void* stream);
+/* FLUX VAE (16 latent channels, no post_quant_conv, z = latents / scaling_factor + shift_factor; FluxPipeline.__call__ [ext] as called
+ * from ecad/image_generators/flux_image_generator.py:330-360): latent_channels 4 or 16. */
+int ecad_vae_create_ex(int device, int dtype, int latent_channels, int use_post_quant_conv, EcadVae** out);
+int ecad_vae_decode_ex(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, float shift_factor, uint8_t* out_u8_dev, void* stream);
 
 #ifdef __cplusplus
 }

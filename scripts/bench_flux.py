@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--json", default=None, help="write the result + per-class profile here")
+    ap.add_argument("--decode-tail", action="store_true", help="also time the 16-channel VAE decode + uint8 postprocess on the native decoder")
     a = ap.parse_args()
     t0 = time.time()
     sched = FluxCacheSchedule.from_json(ROOT / a.schedule)
@@ -66,6 +67,23 @@ def main():
     st = eng.stats()
     tflop = 2 * (st["linear_macs_reference"] + st["attn_core_macs"]) * B / 1e12
     print(f"flux {a.grid * 16}x{a.grid * 16} batch {B}: {ms:.1f} ms per batch = {B / ms * 1e3:.3f} images/s; reference-equivalent {tflop / B:.1f} TFLOP/image -> {tflop / ms * 1e3:.0f} TFLOP/s whole job")
+    if a.decode_tail:
+        from ecad_amd.pipelines.flux import FluxPipeline
+        from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
+
+        torch.manual_seed(0)
+        vae = HipVaeDecoder.from_torch(AutoencoderKLDecoderOnly.flux(), dtype=torch.bfloat16)
+        lat = FluxPipeline._unpack_latents(run(True).bfloat16(), a.grid * 16, a.grid * 16)
+        for _ in range(2):
+            img = vae.decode_to_uint8(lat)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(3):
+            img = vae.decode_to_uint8(lat)
+        e.record()
+        torch.cuda.synchronize()
+        dms = s.elapsed_time(e) / 3
+        print(f"decode tail (HIP FLUX-geometry VAE, random init): {dms:.1f} ms per batch of {B} -> png-ready {B / (ms + dms) * 1e3:.3f} images/s; image {tuple(img.shape)} {img.dtype}")
     if not a.no_profile:
         eng.set_profiling(True)
         run(False)

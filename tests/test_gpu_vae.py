@@ -40,6 +40,34 @@ def test_hip_vae_decoder_matches_pytorch(B, h, w):
     assert float(d.float().mean()) < 0.6 and frac_bad < 0.01
 
 
+def test_hip_flux_vae_geometry_matches_pytorch():
+    """FLUX VAE: 16 latent channels, no post_quant_conv, z = latents / scaling + shift."""
+    from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
+
+    torch.manual_seed(2)
+    ref = AutoencoderKLDecoderOnly.flux().float().eval()
+    with torch.no_grad():
+        for n, p_ in ref.named_parameters():
+            if "norm" in n and n.endswith("weight"):
+                p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+            if "norm" in n and n.endswith("bias"):
+                p_.copy_(0.1 * torch.randn_like(p_))
+    hip = HipVaeDecoder.from_torch(ref)
+    assert hip.config.latent_channels == 16 and not hip.config.use_post_quant_conv
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(2, 16, 16, 24, generator=g) * 0.3611
+    img = ref.decode(lat / 0.3611 + 0.1159)[0].float()
+    exp = ((img / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    got = hip.decode_to_uint8(lat.cuda()).cpu()
+    d = (got.int() - exp.int()).abs()
+    frac_bad = float((d > 2).float().mean())
+    print(f"FLUX VAE uint8: mean |diff| {float(d.float().mean()):.3f}, max {int(d.max())}, >2 levels: {100 * frac_bad:.3f} %, dynamic range {int(exp.min())}..{int(exp.max())}")
+    assert int(exp.max()) - int(exp.min()) > 60
+    assert float(d.float().mean()) < 0.6 and frac_bad < 0.01
+    with pytest.raises(ValueError):
+        hip.decode_to_uint8(torch.randn(1, 4, 16, 16).cuda())
+
+
 def test_hip_vae_rejects_missing_weights():
     from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
 

@@ -8,8 +8,13 @@
 // (half the LDS traffic of two sequential rounds), the score strip covers 64 keys at a time (32 VGPRs for both fragments), and
 // the V tile row stride is 144 elements (288 B = 8 banks mod 64: the 8 rows x 32 B of a 32-lane transposed read tile the 64
 // banks exactly).  Also instantiated for the PixArt head dim 72 (engine.hip), where it replaced the two-sequential-rounds kernel
-// of attention.h: self-attention 9.1 -> 7.1 ms per alpha-256 batch, 256 -> 185 ms per Sigma-1024 batch.  Measured null: skipping
-// the accumulator rescale when no running maximum moved (ballot + branch cost what the 72 multiplies did).
+// of attention.h: self-attention 9.1 -> 7.1 ms per alpha-256 batch, 256 -> 185 ms per Sigma-1024 batch.  Ablation on the FLUX shape (scripts/bench_flux_attn.py, 795 us): without the staging + barriers 508 us, without the K fragment reads 575,
+// without the V reads 704, without the PV MFMAs 737, without the exp2s 787 -- the waves run the S / softmax / PV phases in lockstep
+// behind the per-chunk barriers, so LDS, MFMA and VALU time add up instead of overlapping.  Measured null or negative on top of this
+// kernel: skipping the accumulator rescale when no running maximum moved (+-0); K/V chunks by LDS-DMA into a double-buffered,
+// source-swizzled tile with one barrier per chunk and an all-ones MFMA for the denominator (-1 %: kept out of the tree); handing
+// each XCD a contiguous run of work items so the 18 query blocks of a (sample, head) share one L2 (+9 % time on FLUX, +13 % on
+// Sigma-1024: the CUs of an XCD then request the same K/V lines at the same moment).
 #pragma once
 #include "attention.h"
 #include "common.h"

@@ -271,3 +271,33 @@ def test_flux_errors():
         eng.begin_image_batch(enc.bfloat16().cuda(), pooled.bfloat16().cuda(), 4, 4)
     with pytest.raises(ValueError):
         eng.load_state_dict({"not.a.weight": torch.zeros(1)})
+
+
+def test_full_width_geometry_matches_oracle():
+    """FLUX.1-dev width and token counts (D = 3072 = 24 x 128, N = 4096 image + T = 512 text tokens, batch 2: the BASELINE config-5
+    shapes every kernel is tuned for -- 256-wide tiles, S = 4608 attention without a tail, 1.06 M-row adaLN matrix per 57 blocks
+    scaled down to 1 joint + 2 single blocks so the fp32 CPU oracle finishes in about a minute).  Step 1 mixes recomputed and
+    cached components."""
+    cfg = flux_ref.FluxConfig(num_layers=1, num_single_layers=2)
+    B, T, gh, gw = 2, 512, 64, 64
+    bf = np.array([[[1, 1, 1]], [[0, 1, 0]]], dtype=bool)
+    bs = np.array([[[1, 1, 1], [1, 1, 1]], [[1, 0, 1], [0, 0, 0]]], dtype=bool)
+    dtype = torch.bfloat16
+    w = flux_ref.make_weights(cfg, seed=2)
+    eng = make_engine(cfg, dtype, max_batch=B, max_n=gh * gw, max_t=T)
+    eng.load_state_dict(w)
+    eng.set_schedule(bf, bs)
+    ref = flux_ref.FluxOracle(cfg, w, round_dtype=dtype)
+    ref.round_dtype = None
+    lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, B, gh, gw, T)
+    enc_d, pooled_d = enc.to(dtype), pooled.to(dtype)
+    eng.begin_image_batch(enc_d.cuda(), pooled_d.cuda(), gh, gw)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    for s, t in enumerate((1000.0, 948.0)):
+        x = (lat * (1.0 - 0.1 * s)).to(dtype)
+        got = eng.step(s, x.cuda(), t, 4992.0)
+        torch.cuda.synchronize()
+        want = ref.forward(x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), 4992.0), ids, s, bf[s], bs[s])
+        err = rel_l2(got.float(), want)
+        print(f"flux full-width step {s}: rel-L2 {err:.2e}")
+        assert err <= 4e-2

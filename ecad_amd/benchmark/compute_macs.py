@@ -1,4 +1,4 @@
-"""Closed-form MAC accounting for PixArt cache schedules.
+"""Closed-form MAC accounting for PixArt and FLUX cache schedules.
 
 Replaces the reference's per-schedule calflops pass (``ecad/benchmark/compute_macs.py:255-303``: build zero inputs at
 batch 2, hook every nn.Linear/nn.Conv, run 20 forwards) with the closed form that reproduces every per-step value in
@@ -42,14 +42,36 @@ def total_macs_T(bits: np.ndarray, **kw) -> float:
     return float(macs_per_step(bits, **kw).sum()) / 1e12
 
 
+def flux_macs_per_step(bits_full: np.ndarray, bits_single: np.ndarray, tokens: int, dim: int = 3072, text_tokens: int = 512, in_channels: int = 64,
+                       joint_attention_dim: int = 4096, pooled_dim: int = 768, guidance_embeds: bool = True, batch: int = BATCH_SIZE) -> np.ndarray:
+    """FLUX (6 component kinds; flux_cache_schedule.py:51-60): reproduces the per-step MACs of all 38 FLUX schedule JSONs of the
+    reference that carry metrics (tests/test_cpu_flux.py).  tokens = (height / 16) * (width / 16)."""
+    n, t, d = tokens, text_tokens, dim
+    s = n + t
+    nb, ns = bits_full.shape[1], bits_single.shape[1]
+    cost_full = np.array([4 * s * d * d, 8 * n * d * d, 8 * t * d * d], dtype=np.int64)
+    cost_single = np.array([3 * s * d * d, 4 * s * d * d, 5 * s * d * d], dtype=np.int64)
+    overhead = (n * in_channels * d + t * joint_attention_dim * d + (2 if guidance_embeds else 1) * (256 * d + d * d) + (pooled_dim * d + d * d)
+                + nb * 12 * d * d + ns * 3 * d * d + 2 * d * d + n * d * in_channels)
+    ef, es = executed_components(bits_full).astype(np.int64), executed_components(bits_single).astype(np.int64)
+    return batch * (overhead + (ef * cost_full[None, None, :]).sum(axis=(1, 2)) + (es * cost_single[None, None, :]).sum(axis=(1, 2)))
+
+
 def annotate_schedule_file(path: Path, recompute_existing: bool = False) -> bool:
     with open(path) as f:
         data = json.load(f)
     metrics = data.get("metrics", {}) or {}
     if not recompute_existing and metrics.get("total_macs_T") is not None:
         return False
-    sched = PixArtCacheSchedule.from_json(path)
-    per_step = macs_per_step(sched.to_numpy())
+    if "num_single_blocks" in data.get("cache_schedule", {}):
+        from ecad_amd.schedulers.cache_scheduler.flux_cache_schedule import FluxCacheSchedule
+
+        fs = FluxCacheSchedule.from_json(path)
+        cfg = fs.top_level_config or {}
+        per_step = flux_macs_per_step(*fs.to_device_bits(), tokens=(cfg.get("height", 256) // 16) * (cfg.get("width", 256) // 16))
+    else:
+        sched = PixArtCacheSchedule.from_json(path)
+        per_step = macs_per_step(sched.to_numpy())
     metrics["by_inference_step"] = {f"{s:03}": {"macs": int(m)} for s, m in enumerate(per_step)}
     metrics["total_macs"] = int(per_step.sum())
     metrics["total_macs_T"] = float(per_step.sum()) / 1e12

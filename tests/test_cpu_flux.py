@@ -133,3 +133,18 @@ def test_flux_oracle_properties():
     assert sig.shape == (21,) and sig[-1] == 0 and (np.diff(sig) < 0).all() and abs(sig[0] - 1.0) < 1e-6
     tm, gm = flux_ref.model_scalars(sig, 5.0, torch.bfloat16)
     assert float(gm[0]) == 4992.0 and tm.shape == (20,)  # 5 * 1000 in bf16
+
+
+def test_compute_macs_cli_annotates_flux_schedules(tmp_path):
+    from ecad_amd.benchmark.compute_macs import annotate_schedule_file
+
+    src = REPO / "schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json"
+    d = json.load(open(src))
+    want = d["metrics"]["total_macs"], d["metrics"]["by_inference_step"]["002"]["macs"]
+    d["metrics"] = {}
+    p = tmp_path / "f.json"
+    json.dump(d, open(p, "w"))
+    assert annotate_schedule_file(p)
+    m = json.load(open(p))["metrics"]
+    assert (m["total_macs"], m["by_inference_step"]["002"]["macs"]) == want
+    assert not annotate_schedule_file(p)  # already annotated

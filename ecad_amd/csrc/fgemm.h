@@ -20,7 +20,12 @@
 
 namespace ecad {
 
-enum FGemmEpi { FEPI_BIAS = 0, FEPI_BIAS_GELU = 1, FEPI_BIAS_GATE_RESID = 2, FEPI_BIAS_SILU = 3 };
+// FEPI_QKV_ROPE: bias, then per-head RMSNorm * weight + RoPE on the columns < rope_cols (the q and k thirds of a fused QKV output;
+//   FluxAttnProcessor2_0 [ext]: norm_q / norm_k, apply_rope) -- a 128-column head never straddles a tile, so the epilogue's row pass does
+//   it on 16-lane groups (one (row, head) each) and the separate in-place pass over the QKV buffer disappears.
+// FEPI_QKV_ROPE_MLP: the single-stream block's to_q/k/v and proj_mlp share their input (cached_flux_transformer_block.py:108-118):
+//   one GEMM over the stacked [3D + 4D, D] weight; columns < n_split as FEPI_QKV_ROPE into C, columns >= n_split bias + GELU into C2.
+enum FGemmEpi { FEPI_BIAS = 0, FEPI_BIAS_GELU = 1, FEPI_BIAS_GATE_RESID = 2, FEPI_BIAS_SILU = 3, FEPI_QKV_ROPE = 4, FEPI_QKV_ROPE_MLP = 5 };
 
 template <typename T> struct FGemmArgs {
   const T* A;
@@ -35,6 +40,17 @@ template <typename T> struct FGemmArgs {
   int M, N, K;
   int k_split;        // in elements (multiple of 64); >= K when A2 is null
   int lda, lda2, ldw, ldc, ldr;
+  // FEPI_QKV_ROPE / FEPI_QKV_ROPE_MLP
+  const float* rope;    // [S][64][2] (cos, sin) by sequence position
+  const float* nq;      // [128] RMSNorm weights of q / k; *_txt (may be null) for the text rows of a joint block
+  const float* nk;
+  const float* nq_txt;
+  const float* nk_txt;
+  int rope_cols;        // 2 * D
+  int pos_T;            // sequence position of image token j is pos_T + j; of text token j it is j
+  float rope_eps;
+  T* C2;                // FEPI_QKV_ROPE_MLP: gelu(mlp) output
+  int ldc2, n_split;
 };
 
 ECAD_DEV int seg_batch(int m, int seg0, int rpb0, int rpb1) { return m < seg0 ? m / rpb0 : (m - seg0) / rpb1; }
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[r];
-        if (EPI == FEPI_BIAS_GELU) v = gelu_tanh(v);
+        if (EPI == FEPI_BIAS_GELU || (EPI == FEPI_QKV_ROPE_MLP && n0 >= p.n_split)) v = gelu_tanh(v);
         if (EPI == FEPI_BIAS_SILU) v = silu(v);
         float_to_elem4<T>(o, r, v);
       }
@@ -215,6 +231,40 @@ __global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
         for (int e = 0; e < 8; ++e) h[e] += o[e];
       }
       gstore16(rp, pack8<T>(h));
+    } else if (EPI == FEPI_QKV_ROPE || EPI == FEPI_QKV_ROPE_MLP) {
+      if (EPI == FEPI_QKV_ROPE_MLP && n >= p.n_split) {
+        gstore16(p.C2 + (size_t)m * p.ldc2 + (n - p.n_split), v);
+      } else {
+        if (n < p.rope_cols) {  // 16 consecutive lanes hold the 128 columns of one (row, head)
+          const int hc = cchunk & 15;
+          float x[8];
+          unpack8<T>(v, x);
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+          const float rr = rsqrtf(ss * (1.0f / 128.0f) + p.rope_eps);
+          const bool isk = n >= (p.rope_cols >> 1), txt = m < p.seg0;
+          const float* w = isk ? (txt && p.nk_txt ? p.nk_txt : p.nk) : (txt && p.nq_txt ? p.nq_txt : p.nq);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + hc * 8), w1 = *reinterpret_cast<const f32x4*>(w + hc * 8 + 4);
+          const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = round_elem<T>(round_elem<T>(x[e] * rr) * wv[e]);
+          const int pos = txt ? m % p.rows_per_batch0 : p.pos_T + (m - p.seg0) % p.rows_per_batch1;
+          const float* cs = p.rope + ((size_t)pos * 64 + hc * 4) * 2;
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);
+          const float cosv[4] = {c0[0], c0[2], c1[0], c1[2]}, sinv[4] = {c0[1], c0[3], c1[1], c1[3]};
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[2 * j] = cosv[j] * x[2 * j] - sinv[j] * x[2 * j + 1];
+            o[2 * j + 1] = sinv[j] * x[2 * j] + cosv[j] * x[2 * j + 1];
+          }
+          v = pack8<T>(o);
+        }
+        gstore16(p.C + (size_t)m * p.ldc + n, v);
+      }
     } else {
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }

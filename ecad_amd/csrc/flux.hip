@@ -180,6 +180,7 @@ template <typename T> class FluxT : public FluxBase {
   int64_t prof_launch[FC_COUNT];
   int num_cus = 256;
   int bn_force = 0;  // env ECAD_FLUX_BN=128|256 forces one tile width wherever it divides N (A/B)
+  bool fuse_rope = true;      // env ECAD_FLUX_FUSE=0: separate qk_norm_rope pass and separate single-block QKV / proj_mlp GEMMs (A/B)
   bool attn_generic = false;  // env ECAD_FLUX_ATTN=generic: the d_h-templated kernel of attention.h (A/B)
   const void* call_in = nullptr;
   void* call_out = nullptr;
@@ -253,8 +254,8 @@ template <typename T> class FluxT : public FluxBase {
     }
     for (int i = 0; i < NS; ++i) {
       SBlk& b = sb[i];
-      b.w_qkv = walloc<T>(3 * d * d); b.b_qkv = walloc<float>(3 * d);
-      b.w_mlp = walloc<T>(4 * d * d); b.b_mlp = walloc<float>(4 * d);
+      b.w_qkv = walloc<T>(3 * d * d); b.w_mlp = walloc<T>(4 * d * d);  // contiguous: one [7D, D] matrix for the fused QKV + proj_mlp GEMM
+      b.b_qkv = walloc<float>(3 * d); b.b_mlp = walloc<float>(4 * d);  // contiguous likewise (3D and 4D floats are multiples of 256 B)
       b.w_out = walloc<T>(5 * d * d); b.b_out = walloc<float>(d);
       b.nq = walloc<float>(DH); b.nk = walloc<float>(DH);
       const std::string p = "single_transformer_blocks." + std::to_string(i) + ".";
@@ -303,6 +304,7 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     { hipDeviceProp_t pr; FHIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     if (const char* e = getenv("ECAD_FLUX_BN")) bn_force = atoi(e) == 128 ? 128 : atoi(e) == 256 ? 256 : 0;
+    if (const char* e = getenv("ECAD_FLUX_FUSE")) fuse_rope = atoi(e) != 0;
     if (const char* e = getenv("ECAD_FLUX_ATTN")) attn_generic = strcmp(e, "generic") == 0;
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
 
@@ -347,6 +349,7 @@ template <typename T> class FluxT : public FluxBase {
 #define FATTR(BN, E) FHIPCHK(hipFuncSetAttribute((const void*)fgemm_kernel<T, BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<BN>()))
     FATTR(128, FEPI_BIAS); FATTR(128, FEPI_BIAS_GELU); FATTR(128, FEPI_BIAS_GATE_RESID); FATTR(128, FEPI_BIAS_SILU);
     FATTR(256, FEPI_BIAS); FATTR(256, FEPI_BIAS_GELU); FATTR(256, FEPI_BIAS_GATE_RESID); FATTR(256, FEPI_BIAS_SILU);
+    FATTR(128, FEPI_QKV_ROPE); FATTR(256, FEPI_QKV_ROPE); FATTR(128, FEPI_QKV_ROPE_MLP); FATTR(256, FEPI_QKV_ROPE_MLP);
 #undef FATTR
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
@@ -475,6 +478,11 @@ template <typename T> class FluxT : public FluxBase {
     o.g.seg0 = r.seg0; o.g.rows_per_batch0 = r.rpb0; o.g.rows_per_batch1 = r.rpb1;
     o.bytes += (double)o.g.M * D * sizeof(T) * (cache_slot ? 3 : 2);
   }
+  void set_rope(FOp<T>& o, const Range& r, const float* wq, const float* wk) {
+    o.epi = FEPI_QKV_ROPE;
+    o.g.rope = rope; o.g.nq = wq; o.g.nk = wk; o.g.nq_txt = nullptr; o.g.nk_txt = nullptr; o.g.rope_cols = 2 * D; o.g.pos_T = Tt; o.g.rope_eps = cfg.norm_eps;
+    o.g.seg0 = r.seg0; o.g.rows_per_batch0 = r.rpb0; o.g.rows_per_batch1 = r.rpb1;
+  }
   typedef std::vector<FluxSrc> Pend;
   void fill_rows(FOp<T>& o, const Range& r, Pend& pend, size_t src_row_shift) {
     o.f = FluxRowArgs{};
@@ -510,10 +518,12 @@ template <typename T> class FluxT : public FluxBase {
     ops.push_back(o);
   }
   void emit_attention(std::vector<FOp<T>>& ops, const float* wq, const float* wk, const float* wqt, const float* wkt, T* out) {
-    FOp<T> ro;
-    ro.kind = FOp<T>::ROPE; ro.cls = FC_ROPE; ro.w[0] = wq; ro.w[1] = wk; ro.w[2] = wqt; ro.w[3] = wkt;
-    ro.bytes = (double)B * (Tt + N) * 2 * D * sizeof(T) * 2;
-    ops.push_back(ro);
+    if (!fuse_rope) {
+      FOp<T> ro;
+      ro.kind = FOp<T>::ROPE; ro.cls = FC_ROPE; ro.w[0] = wq; ro.w[1] = wk; ro.w[2] = wqt; ro.w[3] = wkt;
+      ro.bytes = (double)B * (Tt + N) * 2 * D * sizeof(T) * 2;
+      ops.push_back(ro);
+    }
     FOp<T> ao;
     ao.kind = FOp<T>::ATTN; ao.cls = FC_ATTN;
     AttnArgs& a = ao.a;
@@ -572,8 +582,11 @@ template <typename T> class FluxT : public FluxBase {
       if (exf(s, i, 0)) {
         emit_ln(ops, RI, pend_img, m(0), m(1));
         emit_ln(ops, RT, pend_txt, m(6), m(7));
-        ops.push_back(mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RI.xn, D, b.w_qkv_i, b.b_qkv_i, qkv + BT * 3 * D, 3 * D, BNr, 3 * D, D));
-        ops.push_back(mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RT.xn, D, b.w_qkv_t, b.b_qkv_t, qkv, 3 * D, (int)BT, 3 * D, D));
+        FOp<T> qi = mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RI.xn, D, b.w_qkv_i, b.b_qkv_i, qkv + BT * 3 * D, 3 * D, BNr, 3 * D, D);
+        FOp<T> qt = mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RT.xn, D, b.w_qkv_t, b.b_qkv_t, qkv, 3 * D, (int)BT, 3 * D, D);
+        if (fuse_rope) { set_rope(qi, RI, b.nq, b.nk); set_rope(qt, RT, b.naq, b.nak); }
+        ops.push_back(qi);
+        ops.push_back(qt);
         emit_attention(ops, b.nq, b.nk, b.naq, b.nak, attn_o);
         const bool wl = wlive_f(s, i, 0);
         FOp<T> oi = mk_gemm(FC_GEMM_ATTN_OUT, 0, attn_o + BT * D, D, b.w_out_i, b.b_out_i, nullptr, D, BNr, D, D);
@@ -613,10 +626,21 @@ template <typename T> class FluxT : public FluxBase {
       auto m = [&](int k) { return mod_ptr(s, mo_single(i, k)); };
       const bool la = live_sa[(size_t)s * NS + i] != 0, lm = live_sm[(size_t)s * NS + i] != 0, eo = exs_(s, i, 2);
       if (la || lm) emit_ln(ops, RA, pend_all, m(0), m(1));
-      if (lm) ops.push_back(mk_gemm(FC_GEMM_SMLP, FEPI_BIAS_GELU, xn, D, b.w_mlp, b.b_mlp, cs(i, 1), 4 * D, R, 4 * D, D));
-      if (la) {
-        ops.push_back(mk_gemm(FC_GEMM_SQKV, FEPI_BIAS, xn, D, b.w_qkv, b.b_qkv, qkv, 3 * D, R, 3 * D, D));
+      if (la && lm && fuse_rope) {  // one GEMM over the stacked [3D + 4D, D] weight: q, k (normed + roped), v -> qkv; gelu(mlp) -> its cache slot
+        FOp<T> o = mk_gemm(FC_GEMM_SQKV, FEPI_BIAS, xn, D, b.w_qkv, b.b_qkv, qkv, 3 * D, R, 7 * D, D);
+        set_rope(o, RA, b.nq, b.nk);
+        o.epi = FEPI_QKV_ROPE_MLP;
+        o.g.C2 = cs(i, 1); o.g.ldc2 = 4 * D; o.g.n_split = 3 * D;
+        ops.push_back(o);
         emit_attention(ops, b.nq, b.nk, nullptr, nullptr, cs(i, 0));
+      } else {
+        if (lm) ops.push_back(mk_gemm(FC_GEMM_SMLP, FEPI_BIAS_GELU, xn, D, b.w_mlp, b.b_mlp, cs(i, 1), 4 * D, R, 4 * D, D));
+        if (la) {
+          FOp<T> o = mk_gemm(FC_GEMM_SQKV, FEPI_BIAS, xn, D, b.w_qkv, b.b_qkv, qkv, 3 * D, R, 3 * D, D);
+          if (fuse_rope) set_rope(o, RA, b.nq, b.nk);
+          ops.push_back(o);
+          emit_attention(ops, b.nq, b.nk, nullptr, nullptr, cs(i, 0));
+        }
       }
       if (eo) {
         if (!(la || lm)) emit_flush(ops, RA, pend_all);
@@ -750,6 +774,8 @@ template <typename T> class FluxT : public FluxBase {
       case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(512), lds, s, g); break;
       case FEPI_BIAS_GATE_RESID: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS_GATE_RESID>), dim3(tiles), dim3(512), lds, s, g); break;
       case FEPI_BIAS_SILU: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS_SILU>), dim3(tiles), dim3(512), lds, s, g); break;
+      case FEPI_QKV_ROPE: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_QKV_ROPE>), dim3(tiles), dim3(512), lds, s, g); break;
+      case FEPI_QKV_ROPE_MLP: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_QKV_ROPE_MLP>), dim3(tiles), dim3(512), lds, s, g); break;
       default: return fail(ECAD_E_INVALID, "bad epilogue %d", epi);
     }
     return ECAD_OK;

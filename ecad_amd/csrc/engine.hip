@@ -194,6 +194,7 @@ template <typename T> class EngineT : public EngineBase {
     gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = 0;
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
+    if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
     if (const char* at = getenv("ECAD_ATTN")) attn_shared = strcmp(at, "generic") != 0;
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
@@ -718,10 +719,16 @@ template <typename T> class EngineT : public EngineBase {
     if (masked || a.Nk % 128) return launch_attn_t<128, true>(a, 0, 1, s);
     return launch_attn_t<128, false>(a, 1, 1, s);
   }
+  int ln16 = 1;  // 16 lanes per row (D = 1152: 9 chunks per lane), ln16 rows per lane group: 16.2 -> 15.3 us per launch at 1 row, 18.3 at 2, 25.7 at 4
+                 // (the pass is bound by the number of loads in flight, not by bandwidth); env ECAD_LN16=0: one wave per row
   int launch_ln(const FlushArgs& f, hipStream_t s) {
     const int cpr = f.D / 8;
     const int grid = (f.M + 3) / 4;
     if (f.D % 8) return fail(ECAD_E_INVALID, "D %% 8 != 0");
+    if (ln16 && f.D == 1152) {  // 16 lanes per row, 9 chunks per lane
+      hipLaunchKernelGGL((ln_modulate16_kernel<T, 9>), dim3(((f.M + 15) / 16 + ln16 - 1) / ln16), dim3(256), 0, s, f);  // ln16 rows per 16-lane group
+      return ECAD_OK;
+    }
     if (cpr <= 64 * 3) hipLaunchKernelGGL((ln_modulate_kernel<T, 3>), dim3(grid), dim3(256), 0, s, f);
     else if (cpr <= 64 * 6) hipLaunchKernelGGL((ln_modulate_kernel<T, 6>), dim3(grid), dim3(256), 0, s, f);
     else return fail(ECAD_E_UNSUPPORTED, "D=%d too wide for ln kernel", f.D);

@@ -14,7 +14,8 @@
 // kernel: skipping the accumulator rescale when no running maximum moved (+-0); K/V chunks by LDS-DMA into a double-buffered,
 // source-swizzled tile with one barrier per chunk and an all-ones MFMA for the denominator (-1 %: kept out of the tree); handing
 // each XCD a contiguous run of work items so the 18 query blocks of a (sample, head) share one L2 (+9 % time on FLUX, +13 % on
-// Sigma-1024: the CUs of an XCD then request the same K/V lines at the same moment).
+// Sigma-1024: the CUs of an XCD then request the same K/V lines at the same moment); 4-wave workgroups on 128-query items, two per
+// CU (33 -> 52 us per alpha-256 self-attention launch: twice the K/V staging per query row outweighs the decoupled barriers).
 #pragma once
 #include "attention.h"
 #include "common.h"

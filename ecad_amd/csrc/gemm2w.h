@@ -5,6 +5,9 @@
 // through L2->LDS instead of 0.0109 (-32 %), and 8 waves laid out 4 (M) x 2 (N) own 64x144 each, so the LDS fragment
 // reads drop from 0.61 to 0.36 per MFMA.  Price: only a 2-deep stage ring fits (2 x 69.6 KiB), i.e. one K-step of
 // prefetch (a step is 144 MFMAs per SIMD, ~1.2 us, enough for L2-resident operands), and N % 288 == 0.
+// Measured negative: a persistent walk over the 2 tiles per CU of FF1 with the next tile's first K-step issued under the current tile's
+// last step and the epilogue written straight from the accumulators (8-byte stores, no LDS round trip, ring left free for the DMA):
+// 95.8 -> 102.6 us per launch -- the 32-byte row segments of the direct stores cost more than the overlap returns.
 #pragma once
 #include "common.h"
 #include "gemm.h"

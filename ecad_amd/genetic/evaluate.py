@@ -24,15 +24,21 @@ def latent_fidelity_score(latents, reference_latents) -> float:
     return -float((latents.float() - reference_latents.float()).norm() / reference_latents.float().norm().clamp_min(1e-12))
 
 
-def evaluate_population(X: np.ndarray, score_fn: Callable[[int, np.ndarray], float], steps: int = 20, blocks: int = 28) -> np.ndarray:
-    """F[pop, 2] = [1 - score, TMACs] for the whole population, computed cooperatively by all ranks."""
+def evaluate_population(X: np.ndarray, score_fn: Callable[[int, np.ndarray], float], steps: int = 20, blocks: int = 28,
+                        macs_fn: Callable[[np.ndarray], float] | None = None) -> np.ndarray:
+    """F[pop, 2] = [1 - score, TMACs] for the whole population, computed cooperatively by all ranks.  ``macs_fn`` (flat bit vector ->
+    TMACs) overrides the PixArt closed form (FLUX: ``FluxPopulationIOManager._macs_T``)."""
     rank, world = D._world()
     n = len(X)
     mine = D.shard_range(n, world, rank)
     local = np.zeros((len(mine), 2), dtype=np.float64)
     for k, c in enumerate(mine):
-        bits = np.asarray(X[c], dtype=np.bool_).reshape(steps, blocks, 3)
-        local[k] = [1.0 - score_fn(c, bits), total_macs_T(bits)]
+        if macs_fn is None:
+            bits = np.asarray(X[c], dtype=np.bool_).reshape(steps, blocks, 3)
+            local[k] = [1.0 - score_fn(c, bits), total_macs_T(bits)]
+        else:
+            bits = np.asarray(X[c], dtype=np.bool_)
+            local[k] = [1.0 - score_fn(c, bits), macs_fn(bits)]
     return D.gather_fitness(local, n)
 
 
@@ -45,5 +51,25 @@ def engine_score_fn(engine, enc, mask, latents, timesteps, coefs, guidance: floa
     def score(_idx: int, bits: np.ndarray) -> float:
         engine.set_schedule(bits)
         return latent_fidelity_score(engine.run_schedule(enc, mask, latents, timesteps, coefs, guidance), ref)
+
+    return score
+
+
+def flux_engine_score_fn(engine, enc, pooled, latents, grid_h: int, grid_w: int, timesteps_x1000, guidance_x1000: float, sigmas, num_blocks: int, num_single_blocks: int):
+    """score_fn for FLUX candidates (flat ``FluxCacheSchedule.to_numpy`` vectors) on this rank's ``EcadFluxEngine``."""
+    steps = len(timesteps_x1000)
+
+    def split(bits):
+        v = np.asarray(bits, dtype=np.bool_).reshape(steps, (num_blocks + num_single_blocks) * 3)
+        return v[:, : num_blocks * 3].reshape(steps, num_blocks, 3), v[:, num_blocks * 3:].reshape(steps, num_single_blocks, 3)
+
+    def run(bits):
+        engine.set_schedule(*split(bits))
+        return engine.run_schedule(latents.clone(), enc, pooled, grid_h, grid_w, timesteps_x1000, guidance_x1000, sigmas)
+
+    ref = run(np.ones(steps * (num_blocks + num_single_blocks) * 3, dtype=np.bool_))
+
+    def score(_idx: int, bits: np.ndarray) -> float:
+        return latent_fidelity_score(run(bits), ref)
 
     return score

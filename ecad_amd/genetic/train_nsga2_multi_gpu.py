@@ -22,6 +22,68 @@ from ecad_amd.genetic.nsga2 import NSGA2
 from ecad_amd.genetic.population_io_manager import PixArtPopulationIOManager
 
 
+def main_flux(args, rank, world, local_rank):
+    """FLUX search: population default 24 (reference flux_population_io_manager.py:38), candidates are flat FluxCacheSchedule vectors."""
+    from types import SimpleNamespace
+
+    from ecad_amd.flux_engine import EcadFluxEngine
+    from ecad_amd.genetic.evaluate import flux_engine_score_fn
+    from ecad_amd.genetic.population_io_manager import FluxPopulationIOManager
+    from ecad_amd.pipelines.flow_match import flow_match_sigmas, model_scalars
+    from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import synthetic_state_dict
+
+    nb, ns, heads = (int(v) for v in args.flux_geometry.split(","))
+    full = heads == 24
+    jd, pd = (4096, 768) if full else (128, 64)
+    steps, gh, gw, T, B = 20, args.height // 16, args.width // 16, 512 if full else 32, args.images
+    n_var = steps * (nb + ns) * 3
+    eng = EcadFluxEngine(num_layers=nb, num_single_layers=ns, num_heads=heads, joint_attention_dim=jd, pooled_projection_dim=pd, max_batch=B, max_image_tokens=gh * gw,
+                         max_text_tokens=T, dtype=torch.bfloat16, device=local_rank)
+    cfg = SimpleNamespace(num_layers=nb, num_single_layers=ns, num_attention_heads=heads, attention_head_dim=128, in_channels=64, joint_attention_dim=jd,
+                          pooled_projection_dim=pd, guidance_embeds=True)
+    eng.load_state_dict(synthetic_state_dict(cfg, 0, device=f"cuda:{local_rank}" if full else "cpu", dtype=torch.bfloat16 if full else torch.float32))
+    g = torch.Generator().manual_seed(1)
+    dev = torch.device("cuda", local_rank)
+    enc = (torch.randn(B, T, jd, generator=g) * 0.1).bfloat16().to(dev)
+    pooled = (torch.randn(B, pd, generator=g) * 0.5).bfloat16().to(dev)
+    lat = torch.randn(B, gh * gw, 64, generator=g).to(dev)
+    sig = flow_match_sigmas(steps, gh * gw)
+    tm, gm = model_scalars(sig, 5.0, torch.bfloat16)
+    score_fn = flux_engine_score_fn(eng, enc, pooled, lat, gh, gw, tm, gm, sig, nb, ns)
+
+    pop = args.population_size
+    mgr = algo = None
+    if rank == 0:
+        mgr = FluxPopulationIOManager(args.name, args.populations_dir, args.benchmarks_dir, generation_num=1, population_size=pop, num_blocks=nb, num_single_blocks=ns,
+                                      height=args.height, width=args.width)
+        algo = NSGA2(pop_size=pop, n_var=n_var, seed=0)
+        algo.setup(None)
+    # every rank needs the closed-form MAC objective; a manager without directories would do, the formula only needs the geometry
+    from ecad_amd.benchmark.compute_macs import flux_macs_per_step
+
+    def macs_fn(bits):
+        v = np.asarray(bits, dtype=np.bool_).reshape(steps, (nb + ns) * 3)
+        return float(flux_macs_per_step(v[:, : nb * 3].reshape(steps, nb, 3), v[:, nb * 3:].reshape(steps, ns, 3), tokens=gh * gw, dim=heads * 128,
+                                        text_tokens=T, joint_attention_dim=jd, pooled_dim=pd).sum()) / 1e12
+
+    for gen in range(1, args.generations + 1):
+        X = None
+        if rank == 0:
+            X = algo.ask()
+            mgr.generation_num = gen
+            mgr.save_population(X, gen)
+        X = D.broadcast_population(X, (pop, n_var))
+        F = evaluate_population(X, score_fn, macs_fn=macs_fn)
+        if rank == 0:
+            for i in range(len(X)):
+                mgr.write_evaluation(i, 1.0 - F[i, 0], X[i], gen)
+            Xd, Fd, Gd = mgr.ask()
+            algo.tell(Xd, Fd, Gd)
+            mgr.to_json()
+            print(f"generation {gen}: best (1-score) {Fd[:, 0].min():.4f}, min TMACs {Fd[:, 1].min():.3f}, evaluated on {world} rank(s)")
+    D.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--name", default="nsga2_multi_gpu")
@@ -32,9 +94,15 @@ def main():
     ap.add_argument("--generations", type=int, default=1)
     ap.add_argument("--images", type=int, default=4, help="prompts per candidate evaluation (synthetic embeddings)")
     ap.add_argument("--num-layers", type=int, default=28)
+    ap.add_argument("--model", default="pixart", choices=["pixart", "flux"], help="flux: FluxPopulationIOManager contract (reference train_nsga2_base.py / flux_problem.py)")
+    ap.add_argument("--flux-geometry", default="19,38,24", help="joint blocks, single blocks, heads (reduce for smoke runs, e.g. 2,3,2)")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=256)
     args = ap.parse_args()
 
     rank, world, local_rank = D.init()
+    if args.model == "flux":
+        return main_flux(args, rank, world, local_rank)
     from ecad_amd.engine import EcadEngine
     from ecad_amd.pipelines.dpm_solver import DPMSolverMultistepScheduler
     from ecad_amd.transformer_2d_models.pixart_transformer_2d_edited import synthetic_state_dict

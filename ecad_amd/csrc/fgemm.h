@@ -12,6 +12,11 @@
 //   BN = 128: 3-stage ring (144 KiB), counted vmcnt                       -- N = 3072 on 8192 image rows = 768 tiles = 3.0 rounds
 // Split A: K-steps >= k_split read A2 (lda2) instead of A -- the single-stream block's proj_out consumes
 // cat([attn, gelu(mlp)]) straight from the two cache slots (cached_flux_transformer_block.py:120-127) without a concat copy.
+// Measured negative: stream-K (persistent workgroups over contiguous (tile, K-step) ranges, fp32 partials + per-tile arrival counter,
+// last arriver sums the parts in workgroup order and runs the epilogue; built to recover the partially filled last round -- 432 tiles
+// on 256 CUs, the joint blocks' text-row GEMMs at 37-75 % of one round).  Bit-exact and parity-green, but the agent-scope
+// release / acquire around the counter is a whole-L2 write-back + invalidate on this multi-XCD part: single proj_out 842 -> 1255 us,
+// joint attn_out 125 -> 242 us.  Making it pay needs sc1 (write-through) partial traffic without the fences; not in the tree.
 // Row -> sample index is segment aware: rows [0, seg0) are text rows (rows_per_batch0 each), the rest image rows
 // (rows_per_batch1 each), the layout of the joint [text | image] hidden-state matrix (flux.hip).
 #pragma once

@@ -16,7 +16,10 @@
 // last arriver sums the parts in workgroup order and runs the epilogue; built to recover the partially filled last round -- 432 tiles
 // on 256 CUs, the joint blocks' text-row GEMMs at 37-75 % of one round).  Bit-exact and parity-green, but the agent-scope
 // release / acquire around the counter is a whole-L2 write-back + invalidate on this multi-XCD part: single proj_out 842 -> 1255 us,
-// joint attn_out 125 -> 242 us.  Making it pay needs sc1 (write-through) partial traffic without the fences; not in the tree.
+// joint attn_out 125 -> 242 us.  A fence-free variant (partials as agent-scope relaxed atomics = sc1 write-through stores / loads,
+// ordered against the relaxed counter add by s_waitcnt vmcnt(0)) is also exact but still loses: proj_out 850 -> 1107 us, joint QKV
+// +53 %; only the text-row FF2 gained (-5 %).  Workgroups at unrelated K offsets of neighbouring tiles no longer share A / W panels in
+// L2 at the same time, and 56 spilled VGPRs sit in the segment loop.  Not in the tree.
 // Row -> sample index is segment aware: rows [0, seg0) are text rows (rows_per_batch0 each), the rest image rows
 // (rows_per_batch1 each), the layout of the joint [text | image] hidden-state matrix (flux.hip).
 #pragma once

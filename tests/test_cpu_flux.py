@@ -148,3 +148,34 @@ def test_compute_macs_cli_annotates_flux_schedules(tmp_path):
     m = json.load(open(p))["metrics"]
     assert (m["total_macs"], m["by_inference_step"]["002"]["macs"]) == want
     assert not annotate_schedule_file(p)  # already annotated
+
+
+def test_flux_host_surface_without_gpu():
+    """Registries, latent packing, ids, flow-match constants: the host pieces that need no device."""
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+    from ecad_amd.pipelines.flow_match import calculate_shift, flow_match_sigmas, model_scalars
+    from ecad_amd.pipelines.flux import FluxPipeline
+    from ecad_amd.pipelines.load_pipeline import PipelineRegistry
+    from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import state_dict_shapes, synthetic_state_dict
+
+    assert PipelineRegistry.get("flux") is FluxPipeline
+    assert get_image_generator_type("FluxImageGenerator").__name__ == "FluxImageGenerator"
+    x = torch.randn(2, 16, 8, 12)
+    packed = FluxPipeline._pack_latents(x)
+    assert packed.shape == (2, 24, 64) and torch.equal(FluxPipeline._unpack_latents(packed, 64, 96), x)
+    assert torch.equal(FluxPipeline._prepare_latent_image_ids(4, 6, "cpu", torch.float32), flux_ref.latent_image_ids(4, 6))
+    assert abs(calculate_shift(256) - 0.5) < 1e-12 and abs(calculate_shift(4096) - 1.16) < 1e-12
+    sig = flow_match_sigmas(20, 4096)
+    assert np.array_equal(sig, flux_ref.flow_match_sigmas(20, 4096))
+    t, g = model_scalars(sig, 5.0, torch.bfloat16)
+    to, go = flux_ref.model_scalars(sig, 5.0, torch.bfloat16)
+    assert np.array_equal(t, to.numpy()) and g == float(go[0]) == 4992.0
+    cfg = flux_ref.FluxConfig(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=64)
+    assert state_dict_shapes(cfg) == flux_ref.weight_shapes(cfg)
+    a, b = synthetic_state_dict(cfg, 5), flux_ref.make_weights(cfg, 5)
+    assert all(torch.equal(a[k], b[k]) for k in b)
+    full = flux_ref.FluxConfig()
+    n = sum(int(np.prod(s)) for s in state_dict_shapes(full).values())
+    assert 11.8e9 < n < 12.0e9  # FLUX.1-dev: 11.9 B parameters
+    with pytest.raises(ValueError):
+        get_image_generator_type("FluxImageGenerator")()  # CUDA is required (same hard check as the reference)

@@ -116,8 +116,10 @@ def main_flux(args, world, rank, device):
     sched_path = "schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json"
     sched = FluxCacheSchedule.from_json(ROOT / sched_path)
     model = FluxTransformer2DEdited(guidance_embeds=True, max_batch=B, max_image_tokens=grid * grid, max_text_tokens=T, torch_dtype=torch.bfloat16, device=device.index)
-    model.load_state_dict(synthetic_state_dict(model.config, 0, device=str(device), dtype=torch.bfloat16))
     eng = model.engine
+    if args.fp8:
+        eng._chk(eng.lib.ecad_flux_set_fp8(eng._h, 1))
+    model.load_state_dict(synthetic_state_dict(model.config, 0, device=str(device), dtype=torch.bfloat16))
     eng.set_schedule(*sched.to_device_bits())
     log("flux engine ready")
     g = torch.Generator(device=device).manual_seed(1000 + rank)
@@ -158,7 +160,7 @@ def main_flux(args, world, rank, device):
         res = {
             "metric": "images/sec at fixed schedule (FLUX.1-dev 1024, 20-step, fast_256_to_1024) [secondary]", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8-e4m3 block GEMMs, bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
             "config": {
                 "workload": f"FLUX.1-dev geometry 1024x1024 (N=4096 + T=512 tokens, D=3072, 19+38 blocks), 20 steps, {sched_path}, batch=2 (no CFG; guidance 5 embedded), 1xMI355X per rank",
                 "batch_per_gpu": B, "timed_region": "context/pooled embedding hoist, all-step adaLN GEMM, 20 transformer steps with cache gate, flow-match Euler; packed latents out (no VAE/PIL)",
@@ -202,6 +204,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--decode-tail", action="store_true", help="also measure the secondary PNG-ready rate (HIP VAE decode + PIL)")
     ap.add_argument("--no-decode-tail", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fp8", action="store_true", help="flux1024 only: opt-in OCP e4m3 block GEMMs (BASELINE config 5 names fp8 MFMA); dtype then reads fp8")
     ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024", "flux1024"],
                     help="alpha256 = BASELINE metric config (default); sigma1024 / flux1024 = BASELINE configs 3 / 5 (secondary, not the headline)")
     args = ap.parse_args()

@@ -136,6 +136,7 @@ SIGNATURES = {
     "ecad_flux_last_error": (C.c_char_p, [_P]),
     "ecad_flux_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
     "ecad_flux_finalize_weights": (_I, [_P]),
+    "ecad_flux_set_fp8": (_I, [_P, _I]),
     "ecad_flux_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _I]),
     "ecad_flux_begin_image_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ecad_flux_step": (_I, [_P, _I, _P, _F, _F, _P, _P]),
@@ -145,6 +146,7 @@ SIGNATURES = {
     "ecad_flux_set_profiling": (_I, [_P, _I]),
     "ecad_flux_get_profile": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ecad_flux_op_gemm": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I64, _I, _I, _I, _P]),
+    "ecad_flux_op_gemm_fp8": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _P]),
     "ecad_flux_op_qk_norm_rope": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "ecad_flux_op_attention": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ecad_flux_op_ln_modulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I64, _P]),

@@ -70,40 +70,19 @@ template <int BN> constexpr int fgemm_lds_bytes() {
   return ring > ctile ? ring : ctile;
 }
 
-template <typename T, int BN, int EPI>
-__global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
+// the whole K loop of the tile at (m0, n0) into acc (zeroed here); ends with a barrier: the LDS ring may be reused right away
+template <typename T, int BN>
+ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, f32x4 (&acc)[4][BN / 32]) {
   constexpr int BM = 256, NW = 8, STAGES = fgemm_stages<BN>();
   constexpr int FM = 4, FN = BN / 32;  // wave tile 64 x BN/2
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
   constexpr int A_INST = BM / 8 / NW;  // 4
   constexpr int B_INST = BN / 8 / NW;  // 4 (BN 256) or 2 (BN 128)
   constexpr int CS = BN + 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;
   const int l15 = lane & 15, g = lane >> 4;
-  const int tiles_n = p.N / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {  // blocks b, b + 8 share an XCD: give each XCD a contiguous run of tile ids
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  if ((tiles_m & 3) == 0 && (tiles_n & 3) == 0) {  // 4 x 4 patches: the 16 resident tiles of a patch share 4 A panels and 4 W panels
-    const int patch = bid >> 4, within = bid & 15;
-    const int pn = tiles_n >> 2;
-    const int patch_m = patch / pn, patch_n = patch - patch_m * pn;
-    tm = patch_m * 4 + (within >> 2);
-    tn = patch_n * 4 + (within & 3);
-  } else {
-    tm = bid / tiles_n;
-    tn = bid - tm * tiles_n;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-
   const T* a_src[A_INST];
   const T* a2_src[A_INST];
   const T* b_src[B_INST];
@@ -149,7 +128,6 @@ __global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
     ++kissue;
   };
 
-  f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -188,7 +166,21 @@ __global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
     stage = stage + 1 >= STAGES ? 0 : stage + 1;
   }
   __syncthreads();
+}
 
+// bias / activation / rounding through the LDS C tile, then the row pass (plain store, gated residual, RoPE ...); shared with fgemm8.h
+template <typename T, int BN, int EPI>
+ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, f32x4 (&acc)[4][BN / 32]) {
+  constexpr int BM = 256, NW = 8, STAGES = fgemm_stages<BN>();
+  constexpr int FM = 4, FN = BN / 32;  // wave tile 64 x BN/2
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+  constexpr int A_INST = BM / 8 / NW;  // 4
+  constexpr int B_INST = BN / 8 / NW;  // 4 (BN 256) or 2 (BN 128)
+  constexpr int CS = BN + 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
   // ---- epilogue 1: wave's 64 x BN/2 block -> row-major C tile in LDS (bias, activation, rounding)
   T* ctile = reinterpret_cast<T*>(smem);
 #pragma unroll
@@ -277,6 +269,35 @@ __global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }
   }
+}
+
+// tile id -> (tm, tn): blocks b, b + 8 share an XCD, so each XCD gets a contiguous run of ids; 4 x 4 patches inside the run
+ECAD_DEV void fgemm_tile_of(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  if ((tiles_m & 3) == 0 && (tiles_n & 3) == 0) {  // the 16 resident tiles of a patch share 4 A panels and 4 W panels
+    const int patch = bid >> 4, within = bid & 15;
+    const int pn = tiles_n >> 2;
+    const int patch_m = patch / pn, patch_n = patch - patch_m * pn;
+    tm = patch_m * 4 + (within >> 2);
+    tn = patch_n * 4 + (within & 3);
+  } else {
+    tm = bid / tiles_n;
+    tn = bid - tm * tiles_n;
+  }
+}
+
+template <typename T, int BN, int EPI>
+__global__ __launch_bounds__(512) void fgemm_kernel(const FGemmArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  fgemm_tile_of(blockIdx.x, (p.M + 255) / 256, p.N / BN, tm, tn);
+  f32x4 acc[4][BN / 32];
+  fgemm_mainloop<T, BN>(p, smem, tm * 256, tn * BN, acc);
+  fgemm_epilogue<T, BN, EPI>(p, smem, tm * 256, tn * BN, acc);
 }
 
 }  // namespace ecad

@@ -32,6 +32,7 @@
 #include "common.h"
 #include "elementwise.h"
 #include "fgemm.h"
+#include "fgemm8.h"
 #include "flux_kernels.h"
 
 namespace ecad {
@@ -46,11 +47,11 @@ static std::string g_flux_create_error;
 
 enum FClass {
   FC_GEMM_QKV = 0, FC_GEMM_ATTN_OUT, FC_GEMM_FF1, FC_GEMM_FF2, FC_GEMM_SQKV, FC_GEMM_SMLP, FC_GEMM_SOUT, FC_GEMM_MOD, FC_GEMM_SMALL,
-  FC_ATTN, FC_ROPE, FC_LN, FC_REPLAY, FC_MISC, FC_COUNT
+  FC_ATTN, FC_ROPE, FC_LN, FC_REPLAY, FC_QUANT, FC_MISC, FC_COUNT
 };
 static const char* fclass_names[FC_COUNT] = {"gemm_joint_qkv", "gemm_joint_attn_out", "gemm_joint_ff1_gelu", "gemm_joint_ff2", "gemm_single_qkv",
                                              "gemm_single_mlp_gelu", "gemm_single_proj_out", "gemm_adaln_all_steps", "gemm_small", "attn_joint",
-                                             "qk_norm_rope", "ln_modulate", "cache_replay", "misc"};
+                                             "qk_norm_rope", "ln_modulate", "cache_replay", "fp8_quant_rows", "misc"};
 
 __global__ void flux_fill_kernel(float* p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,6 +94,7 @@ struct FluxBase {
   virtual int init() = 0;
   virtual int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
   virtual int finalize_weights() = 0;
+  virtual int set_fp8(int on) = 0;
   virtual int set_schedule(const uint8_t* bf, const uint8_t* bs, int steps) = 0;
   virtual int begin_batch(int B, int gh, int gw, const void* enc, const void* pooled, int T, hipStream_t s) = 0;
   virtual int step(int step_idx, const void* lat, float t, float g, void* out, hipStream_t s) = 0;
@@ -104,16 +106,19 @@ struct FluxBase {
   virtual int get_profile(int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) = 0;
   virtual int op_gemm(int epi, int bn, const void* A, const void* A2, int k_split, const void* W, const float* bias, void* out, int M, int N, int K, void* resid,
                       const void* gate, int64_t gate_stride, int seg0, int rpb0, int rpb1, hipStream_t s) = 0;
+  virtual int op_gemm_fp8(int epi, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int iters, float* avg_us, hipStream_t s) = 0;
   virtual int op_rope(void* qkv, int B, int T, int N, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* rope, hipStream_t s) = 0;
   virtual int op_attention(const void* qkv, void* out, int B, int T, int N, hipStream_t s) = 0;
   virtual int op_ln(const void* x, void* y, int B, int T, int N, const void* shift, const void* scale, int64_t mod_stride, hipStream_t s) = 0;
 };
 
 template <typename T> struct FOp {
-  enum Kind { GEMM, ATTN, ROPE, LN, REPLAY, COPY, SINUS, TEMB, EULER, UNPAD } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, ROPE, LN, REPLAY, COPY, SINUS, TEMB, EULER, UNPAD } kind;
   int cls = FC_MISC;
   int epi = 0, bn = 128;
   FGemmArgs<T> g{};
+  const uint8_t* w8 = nullptr;  // GEMM8: fp8 weight + per-channel scales (activations: the engine's a8 / sa8 buffers)
+  const float* sw8 = nullptr;
   AttnArgs a{};
   FluxRowArgs f{};
   int desc_off = -1, desc_n = 0;
@@ -180,6 +185,15 @@ template <typename T> class FluxT : public FluxBase {
   int64_t prof_launch[FC_COUNT];
   int num_cus = 256;
   int bn_force = 0;  // env ECAD_FLUX_BN=128|256 forces one tile width wherever it divides N (A/B)
+  bool fp8 = false;           // env ECAD_FLUX_FP8=1 (or cfg dtype flag): OCP e4m3 for the block GEMMs (fgemm8.h); bf16 everywhere else
+  struct W8 { uint8_t* w; float* s; };
+  std::map<const void*, W8> w8map;  // bf16 weight pointer -> fp8 copy + per-output-channel scales
+  std::vector<void*> w8allocs;
+  uint8_t* a8 = nullptr;      // [R][5D] activation rows quantised right before each fp8 GEMM
+  float* sa8 = nullptr;       // [R]
+  uint8_t* xn8 = nullptr;     // [R][D] LN output in e4m3 (row layout of xn) when its only consumers are fp8 GEMMs
+  float* sxn8 = nullptr;      // [R]
+  bool f8_engine_attr = false;
   bool fuse_rope = true;      // env ECAD_FLUX_FUSE=0: separate qk_norm_rope pass and separate single-block QKV / proj_mlp GEMMs (A/B)
   bool attn_generic = false;  // env ECAD_FLUX_ATTN=generic: the d_h-templated kernel of attention.h (A/B)
   const void* call_in = nullptr;
@@ -194,6 +208,11 @@ template <typename T> class FluxT : public FluxBase {
     if (warena) hipFree(warena);
     if (ws) hipFree(ws);
     if (desc_dev) hipFree(desc_dev);
+    for (void* q : w8allocs) hipFree(q);
+    if (a8) hipFree(a8);
+    if (sa8) hipFree(sa8);
+    if (xn8) hipFree(xn8);
+    if (sxn8) hipFree(sxn8);
   }
 
   template <typename U> U* walloc(size_t n) {
@@ -305,6 +324,8 @@ template <typename T> class FluxT : public FluxBase {
     { hipDeviceProp_t pr; FHIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     if (const char* e = getenv("ECAD_FLUX_BN")) bn_force = atoi(e) == 128 ? 128 : atoi(e) == 256 ? 256 : 0;
     if (const char* e = getenv("ECAD_FLUX_FUSE")) fuse_rope = atoi(e) != 0;
+    if (const char* e = getenv("ECAD_FLUX_FP8")) fp8 = atoi(e) != 0;
+    if (fp8 && D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
     if (const char* e = getenv("ECAD_FLUX_ATTN")) attn_generic = strcmp(e, "generic") == 0;
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
 
@@ -393,6 +414,58 @@ template <typename T> class FluxT : public FluxBase {
       if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "weight '%s' was never loaded", kv.first.c_str());
     finalized = true;
     plan_valid = false;
+    if (fp8) return build_fp8_weights();
+    return ECAD_OK;
+  }
+
+  int set_fp8(int on) override {
+    if (on && D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
+    if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; plan_valid = false; }
+    return ECAD_OK;
+  }
+  int quant_weight(const T* w, size_t rows, int K) {
+    W8 e{};
+    FHIPCHK(hipMalloc((void**)&e.w, rows * K));
+    FHIPCHK(hipMalloc((void**)&e.s, rows * sizeof(float)));
+    w8allocs.push_back(e.w); w8allocs.push_back(e.s);
+    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, 0, w, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, e.w, (int64_t)K, e.s, (int)rows);
+    w8map[w] = e;
+    return ECAD_OK;
+  }
+  int build_fp8_weights() {
+    for (void* q : w8allocs) hipFree(q);
+    w8allocs.clear(); w8map.clear();
+    const size_t d = D;
+    int rc;
+    for (auto& b : jb) {
+      if ((rc = quant_weight(b.w_qkv_i, 3 * d, D)) || (rc = quant_weight(b.w_qkv_t, 3 * d, D)) || (rc = quant_weight(b.w_out_i, d, D)) || (rc = quant_weight(b.w_out_t, d, D)) ||
+          (rc = quant_weight(b.w_ff1_i, 4 * d, D)) || (rc = quant_weight(b.w_ff1_t, 4 * d, D)) || (rc = quant_weight(b.w_ff2_i, d, 4 * D)) || (rc = quant_weight(b.w_ff2_t, d, 4 * D)))
+        return rc;
+    }
+    for (auto& b : sb) {
+      if ((rc = quant_weight(b.w_qkv, 7 * d, D)) || (rc = quant_weight(b.w_out, d, 5 * D))) return rc;  // [to_q | to_k | to_v | proj_mlp] rows are contiguous
+      const W8 e = w8map[b.w_qkv];
+      w8map[b.w_mlp] = W8{e.w + 3 * d * d, e.s + 3 * d};  // proj_mlp alone (its attention being cached): the tail of the stacked copy
+    }
+    FHIPCHK(hipDeviceSynchronize());
+    if (!a8) {
+      const size_t R = (size_t)cfg.max_batch * (cfg.max_image_tokens + cfg.max_text_tokens);
+      FHIPCHK(hipMalloc((void**)&a8, R * 5 * d));
+      FHIPCHK(hipMalloc((void**)&sa8, R * sizeof(float)));
+      FHIPCHK(hipMalloc((void**)&xn8, R * d));
+      FHIPCHK(hipMalloc((void**)&sxn8, R * sizeof(float)));
+    }
+    if (!f8_engine_attr) {
+#define F8ATTR(BN, E) FHIPCHK(hipFuncSetAttribute((const void*)fgemm8_kernel<T, BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<BN>()))
+      F8ATTR(128, FEPI_BIAS); F8ATTR(128, FEPI_BIAS_GELU); F8ATTR(128, FEPI_BIAS_GATE_RESID); F8ATTR(128, FEPI_QKV_ROPE); F8ATTR(128, FEPI_QKV_ROPE_MLP);
+      F8ATTR(256, FEPI_BIAS); F8ATTR(256, FEPI_BIAS_GELU); F8ATTR(256, FEPI_BIAS_GATE_RESID); F8ATTR(256, FEPI_QKV_ROPE); F8ATTR(256, FEPI_QKV_ROPE_MLP);
+#undef F8ATTR
+      f8_engine_attr = f8_attr = true;
+    }
+    int64_t extra = 0;
+    for (auto& b : jb) { (void)b; extra += (int64_t)(3 + 3 + 1 + 1 + 4 + 4 + 4 + 4) * d * d; }
+    extra += (int64_t)sb.size() * 12 * d * d;
+    st.weight_bytes = (int64_t)warena_used + extra;
     return ECAD_OK;
   }
 
@@ -483,6 +556,34 @@ template <typename T> class FluxT : public FluxBase {
     o.g.rope = rope; o.g.nq = wq; o.g.nk = wk; o.g.nq_txt = nullptr; o.g.nk_txt = nullptr; o.g.rope_cols = 2 * D; o.g.pos_T = Tt; o.g.rope_eps = cfg.norm_eps;
     o.g.seg0 = r.seg0; o.g.rows_per_batch0 = r.rpb0; o.g.rows_per_batch1 = r.rpb1;
   }
+  // append a block GEMM; in fp8 mode: quantise its A rows (per-row scale; both sources of a split-A GEMM in one pass), then the fp8 kernel
+  void push_gemm(std::vector<FOp<T>>& ops, FOp<T> o) {
+    auto it = fp8 ? w8map.find(o.g.W) : w8map.end();
+    if (it == w8map.end() || o.g.K % GEMM8_BK) { ops.push_back(o); return; }
+    const size_t Rrows = (size_t)B * (Tt + N);
+    if (!o.g.A2 && o.g.A >= xn && o.g.A < xn + Rrows * D && o.g.lda == D) {  // LN output: already e4m3 in xn8 (emit_ln)
+      const size_t row0 = (size_t)(o.g.A - xn) / D;
+      o.kind = FOp<T>::GEMM8;
+      o.w8 = it->second.w; o.sw8 = it->second.s;
+      o.p0 = xn8 + row0 * D; o.p1 = sxn8 + row0;
+      o.bytes = ((double)o.g.M * o.g.K + (double)o.g.N * o.g.K) + (double)o.g.M * o.g.N * sizeof(T);
+      ops.push_back(o);
+      return;
+    }
+    FOp<T> qo;
+    qo.kind = FOp<T>::QUANT; qo.cls = FC_QUANT;
+    qo.p0 = o.g.A; qo.i0 = o.g.lda; qo.i1 = o.g.A2 ? o.g.k_split : o.g.K;
+    qo.p1 = o.g.A2; qo.i2 = o.g.A2 ? o.g.lda2 : 0;
+    qo.n = (size_t)(o.g.A2 ? o.g.K - o.g.k_split : 0);
+    qo.g.M = o.g.M; qo.g.K = o.g.K;
+    qo.bytes = (double)o.g.M * o.g.K * (2 * sizeof(T) + 1);
+    ops.push_back(qo);
+    o.kind = FOp<T>::GEMM8;
+    o.w8 = it->second.w; o.sw8 = it->second.s;
+    o.g.A2 = nullptr; o.g.k_split = o.g.K;
+    o.bytes = ((double)o.g.M * o.g.K + (double)o.g.N * o.g.K) + (double)o.g.M * o.g.N * sizeof(T);
+    ops.push_back(o);
+  }
   typedef std::vector<FluxSrc> Pend;
   void fill_rows(FOp<T>& o, const Range& r, Pend& pend, size_t src_row_shift) {
     o.f = FluxRowArgs{};
@@ -499,12 +600,16 @@ template <typename T> class FluxT : public FluxBase {
     }
     pend.clear();
   }
-  void emit_ln(std::vector<FOp<T>>& ops, const Range& r, Pend& pend, const T* shift, const T* scale, size_t src_row_shift = 0) {
+  void emit_ln(std::vector<FOp<T>>& ops, const Range& r, Pend& pend, const T* shift, const T* scale, size_t src_row_shift = 0, bool bf16_out = false) {
     FOp<T> o;
     o.kind = FOp<T>::LN; o.cls = FC_LN;
     const int ns = (int)pend.size();
     fill_rows(o, r, pend, src_row_shift);
     o.f.shift = shift; o.f.scale = scale;
+    if (fp8 && !bf16_out) {  // the block GEMMs read this row range as e4m3: write it that way, with the row scales
+      o.f.y8 = xn8 + r.row0 * D;
+      o.f.y8_scale = sxn8 + r.row0;
+    }
     o.bytes = (double)r.M * D * sizeof(T) * (2 + ns + (ns ? 1 : 0));
     ops.push_back(o);
   }
@@ -585,35 +690,35 @@ template <typename T> class FluxT : public FluxBase {
         FOp<T> qi = mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RI.xn, D, b.w_qkv_i, b.b_qkv_i, qkv + BT * 3 * D, 3 * D, BNr, 3 * D, D);
         FOp<T> qt = mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RT.xn, D, b.w_qkv_t, b.b_qkv_t, qkv, 3 * D, (int)BT, 3 * D, D);
         if (fuse_rope) { set_rope(qi, RI, b.nq, b.nk); set_rope(qt, RT, b.naq, b.nak); }
-        ops.push_back(qi);
-        ops.push_back(qt);
+        push_gemm(ops, qi);
+        push_gemm(ops, qt);
         emit_attention(ops, b.nq, b.nk, b.naq, b.nak, attn_o);
         const bool wl = wlive_f(s, i, 0);
         FOp<T> oi = mk_gemm(FC_GEMM_ATTN_OUT, 0, attn_o + BT * D, D, b.w_out_i, b.b_out_i, nullptr, D, BNr, D, D);
         set_resid(oi, RI, wl ? cj(i, 0) + BT * D : nullptr, m(2));
-        ops.push_back(oi);
+        push_gemm(ops, oi);
         FOp<T> ot = mk_gemm(FC_GEMM_ATTN_OUT, 0, attn_o, D, b.w_out_t, b.b_out_t, nullptr, D, (int)BT, D, D);
         set_resid(ot, RT, wl ? cj(i, 0) : nullptr, m(8));
-        ops.push_back(ot);
+        push_gemm(ops, ot);
       } else {
         pend_img.push_back(FluxSrc{cj(i, 0) + BT * D, m(2)});
         pend_txt.push_back(FluxSrc{cj(i, 0), m(8)});
       }
       if (exf(s, i, 1)) {
         emit_ln(ops, RI, pend_img, m(3), m(4));
-        ops.push_back(mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RI.xn, D, b.w_ff1_i, b.b_ff1_i, ffmid + BT * 4 * D, 4 * D, BNr, 4 * D, D));
+        push_gemm(ops, mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RI.xn, D, b.w_ff1_i, b.b_ff1_i, ffmid + BT * 4 * D, 4 * D, BNr, 4 * D, D));
         FOp<T> o = mk_gemm(FC_GEMM_FF2, 0, ffmid + BT * 4 * D, 4 * D, b.w_ff2_i, b.b_ff2_i, nullptr, D, BNr, D, 4 * D);
         set_resid(o, RI, wlive_f(s, i, 1) ? cj(i, 1) : nullptr, m(5));
-        ops.push_back(o);
+        push_gemm(ops, o);
       } else {
         pend_img.push_back(FluxSrc{cj(i, 1), m(5)});
       }
       if (exf(s, i, 2)) {
         emit_ln(ops, RT, pend_txt, m(9), m(10));
-        ops.push_back(mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RT.xn, D, b.w_ff1_t, b.b_ff1_t, ffmid, 4 * D, (int)BT, 4 * D, D));
+        push_gemm(ops, mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RT.xn, D, b.w_ff1_t, b.b_ff1_t, ffmid, 4 * D, (int)BT, 4 * D, D));
         FOp<T> o = mk_gemm(FC_GEMM_FF2, 0, ffmid, 4 * D, b.w_ff2_t, b.b_ff2_t, nullptr, D, (int)BT, D, 4 * D);
         set_resid(o, RT, wlive_f(s, i, 2) ? cj(i, 2) : nullptr, m(11));
-        ops.push_back(o);
+        push_gemm(ops, o);
       } else {
         pend_txt.push_back(FluxSrc{cj(i, 2), m(11)});
       }
@@ -631,14 +736,14 @@ template <typename T> class FluxT : public FluxBase {
         set_rope(o, RA, b.nq, b.nk);
         o.epi = FEPI_QKV_ROPE_MLP;
         o.g.C2 = cs(i, 1); o.g.ldc2 = 4 * D; o.g.n_split = 3 * D;
-        ops.push_back(o);
+        push_gemm(ops, o);
         emit_attention(ops, b.nq, b.nk, nullptr, nullptr, cs(i, 0));
       } else {
-        if (lm) ops.push_back(mk_gemm(FC_GEMM_SMLP, FEPI_BIAS_GELU, xn, D, b.w_mlp, b.b_mlp, cs(i, 1), 4 * D, R, 4 * D, D));
+        if (lm) push_gemm(ops, mk_gemm(FC_GEMM_SMLP, FEPI_BIAS_GELU, xn, D, b.w_mlp, b.b_mlp, cs(i, 1), 4 * D, R, 4 * D, D));
         if (la) {
           FOp<T> o = mk_gemm(FC_GEMM_SQKV, FEPI_BIAS, xn, D, b.w_qkv, b.b_qkv, qkv, 3 * D, R, 3 * D, D);
           if (fuse_rope) set_rope(o, RA, b.nq, b.nk);
-          ops.push_back(o);
+          push_gemm(ops, o);
           emit_attention(ops, b.nq, b.nk, nullptr, nullptr, cs(i, 0));
         }
       }
@@ -649,13 +754,13 @@ template <typename T> class FluxT : public FluxBase {
         o.g.lda2 = 4 * D;
         o.g.k_split = D;
         set_resid(o, RA, wlive_s(s, i, 2) ? cs(i, 2) : nullptr, m(2));
-        ops.push_back(o);
+        push_gemm(ops, o);
       } else {
         pend_all.push_back(FluxSrc{cs(i, 2), m(2)});
       }
     }
     // hidden_states[:, T:] -> norm_out (AdaLayerNormContinuous: chunk order scale, shift) -> proj_out   (:301-304)
-    emit_ln(ops, RI, pend_all, mod_ptr(s, mo_out(1)), mod_ptr(s, mo_out(0)), BT);
+    emit_ln(ops, RI, pend_all, mod_ptr(s, mo_out(1)), mod_ptr(s, mo_out(0)), BT, true);  // feeds the (bf16) final projection
     FOp<T> po = mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, RI.xn, D, w_proj, b_proj, proj, PROJ_PAD, BNr, PROJ_PAD, D);
     ops.push_back(po);
   }
@@ -825,6 +930,15 @@ template <typename T> class FluxT : public FluxBase {
         if (o.bind_in) { FGemmArgs<T> g = o.g; g.A = (const T*)call_in; return launch_gemm(o.epi, o.bn, g, s); }
         return launch_gemm(o.epi, o.bn, o.g, s);
       }
+      case FOp<T>::QUANT:
+        hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((o.g.M + 3) / 4), dim3(256), 0, s, (const T*)o.p0, (int64_t)o.i0, o.i1, (const T*)o.p1, (int64_t)o.i2, (int)o.n, a8,
+                           (int64_t)o.g.K, sa8, o.g.M);
+        break;
+      case FOp<T>::GEMM8: {
+        FGemm8Args<T> q{};
+        q.A8 = o.p0 ? (const uint8_t*)o.p0 : a8; q.W8 = o.w8; q.sa = o.p0 ? (const float*)o.p1 : sa8; q.sw = o.sw8; q.lda8 = o.g.K; q.e = o.g;
+        return launch_gemm8(o.epi, o.bn, q, s);
+      }
       case FOp<T>::ATTN: return launch_attn(o.a, s);
       case FOp<T>::ROPE: return launch_rope(qkv, B * (Tt + N), o.w[0], o.w[1], o.w[2], o.w[3], rope, B * Tt, Tt, N, s);
       case FOp<T>::LN: return launch_ln(o.f, s);
@@ -980,6 +1094,69 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipGetLastError());
     return ECAD_OK;
   }
+  template <int BNT> void launch8(int epi, const FGemm8Args<T>& q, hipStream_t s) {
+    const int tiles = ((q.e.M + 255) / 256) * (q.e.N / BNT);
+    constexpr int lds = fgemm_lds_bytes<BNT>();
+    switch (epi) {
+      case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(512), lds, s, q); break;
+      default: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_BIAS>), dim3(tiles), dim3(512), lds, s, q); break;
+    }
+  }
+  bool f8_attr = false;
+  template <int BNT> int launch_gemm8_bn(int epi, const FGemm8Args<T>& q, hipStream_t s) {
+    const int tiles = ((q.e.M + 255) / 256) * (q.e.N / BNT);
+    constexpr int lds = fgemm_lds_bytes<BNT>();
+    switch (epi) {
+      case FEPI_BIAS: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_BIAS>), dim3(tiles), dim3(512), lds, s, q); break;
+      case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(512), lds, s, q); break;
+      case FEPI_BIAS_GATE_RESID: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_BIAS_GATE_RESID>), dim3(tiles), dim3(512), lds, s, q); break;
+      case FEPI_QKV_ROPE: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_QKV_ROPE>), dim3(tiles), dim3(512), lds, s, q); break;
+      case FEPI_QKV_ROPE_MLP: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_QKV_ROPE_MLP>), dim3(tiles), dim3(512), lds, s, q); break;
+      default: return fail(ECAD_E_INVALID, "no fp8 instantiation for epilogue %d", epi);
+    }
+    return ECAD_OK;
+  }
+  int launch_gemm8(int epi, int bn, const FGemm8Args<T>& q, hipStream_t s) {
+    if (q.e.K % GEMM8_BK || q.e.M < 1 || q.e.N % bn) return fail(ECAD_E_INVALID, "fp8 gemm shape M=%d N=%d K=%d unsupported", q.e.M, q.e.N, q.e.K);
+    return bn == 256 ? launch_gemm8_bn<256>(epi, q, s) : launch_gemm8_bn<128>(epi, q, s);
+  }
+  int op_gemm_fp8(int epi, int bn, const void* A, const void* W, const float* bias, void* out, int M, int Nn, int K, int iters, float* avg_us, hipStream_t s) override {
+    FHIPCHK(hipSetDevice(dev));
+    if ((bn != 128 && bn != 256) || Nn % bn || K % GEMM8_BK || M < 1) return fail(ECAD_E_INVALID, "fp8 gemm shape M=%d N=%d K=%d bn=%d unsupported (K %% 128, N %% bn)", M, Nn, K, bn);
+    if (epi != FEPI_BIAS && epi != FEPI_BIAS_GELU) return fail(ECAD_E_INVALID, "fp8 single-op entry supports epilogues 0 and 1");
+    if (!f8_attr) {
+      FHIPCHK(hipFuncSetAttribute((const void*)fgemm8_kernel<T, 128, FEPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<128>()));
+      FHIPCHK(hipFuncSetAttribute((const void*)fgemm8_kernel<T, 128, FEPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<128>()));
+      FHIPCHK(hipFuncSetAttribute((const void*)fgemm8_kernel<T, 256, FEPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<256>()));
+      FHIPCHK(hipFuncSetAttribute((const void*)fgemm8_kernel<T, 256, FEPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<256>()));
+      f8_attr = true;
+    }
+    uint8_t *a8 = nullptr, *w8 = nullptr;
+    float *sa = nullptr, *sw = nullptr;
+    FHIPCHK(hipMalloc((void**)&a8, (size_t)M * K));
+    FHIPCHK(hipMalloc((void**)&w8, (size_t)Nn * K));
+    FHIPCHK(hipMalloc((void**)&sa, (size_t)M * sizeof(float)));
+    FHIPCHK(hipMalloc((void**)&sw, (size_t)Nn * sizeof(float)));
+    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)A, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, a8, (int64_t)K, sa, M);
+    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((Nn + 3) / 4), dim3(256), 0, s, (const T*)W, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, w8, (int64_t)K, sw, Nn);
+    FGemm8Args<T> q{};
+    q.A8 = a8; q.W8 = w8; q.sa = sa; q.sw = sw; q.lda8 = K;
+    q.e.bias = bias; q.e.C = (T*)out; q.e.M = M; q.e.N = Nn; q.e.K = K; q.e.ldc = Nn; q.e.k_split = K;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    if (bn == 256) launch8<256>(epi, q, s); else launch8<128>(epi, q, s);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) { if (bn == 256) launch8<256>(epi, q, s); else launch8<128>(epi, q, s); }
+    hipEventRecord(e1, s);
+    hipError_t err = hipStreamSynchronize(s);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (avg_us) *avg_us = iters > 0 ? ms * 1e3f / iters : 0.f;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a8); hipFree(w8); hipFree(sa); hipFree(sw);
+    if (err != hipSuccess) return fail(ECAD_E_HIP, "fp8 gemm failed: %s", hipGetErrorString(err));
+    return ECAD_OK;
+  }
   int op_rope(void* buf, int B_, int T_, int N_, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* tab, hipStream_t s) override {
     FHIPCHK(hipSetDevice(dev));
     launch_rope((T*)buf, B_ * (T_ + N_), wq, wk, wqt, wkt, tab, B_ * T_, T_, N_, s);
@@ -1039,6 +1216,7 @@ const char* ecad_flux_last_error(const EcadFlux* e) { return e ? e->impl->err.c_
 
 int ecad_flux_load_weights(EcadFlux* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { FENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
 int ecad_flux_finalize_weights(EcadFlux* e) { FENG(e); return E->finalize_weights(); }
+int ecad_flux_set_fp8(EcadFlux* e, int on) { FENG(e); return E->set_fp8(on); }
 int ecad_flux_set_schedule(EcadFlux* e, const uint8_t* bf, const uint8_t* bs, int steps) { FENG(e); if (!bf || !bs) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bf, bs, steps); }
 int ecad_flux_begin_image_batch(EcadFlux* e, int B, int gh, int gw, const void* enc, const void* pooled, int T, void* stream) { FENG(e); return E->begin_batch(B, gh, gw, enc, pooled, T, (hipStream_t)stream); }
 int ecad_flux_step(EcadFlux* e, int step_idx, const void* lat, float t, float g, void* out, void* stream) { FENG(e); return E->step(step_idx, lat, t, g, out, (hipStream_t)stream); }
@@ -1051,6 +1229,9 @@ int ecad_flux_set_profiling(EcadFlux* e, int on) { FENG(e); return E->set_profil
 int ecad_flux_get_profile(EcadFlux* e, int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) { FENG(e); return E->get_profile(maxc, names, ms, launches, flops, bytes); }
 int ecad_flux_op_gemm(EcadFlux* e, int epi, int bn, const void* A, const void* A2, int k_split, const void* W, const float* bias, void* out, int M, int N, int K, void* resid, const void* gate, int64_t gate_stride, int seg0, int rpb0, int rpb1, void* stream) {
   FENG(e); return E->op_gemm(epi, bn, A, A2, k_split, W, bias, out, M, N, K, resid, gate, gate_stride, seg0, rpb0, rpb1, (hipStream_t)stream);
+}
+int ecad_flux_op_gemm_fp8(EcadFlux* e, int epi, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int iters, float* avg_us, void* stream) {
+  FENG(e); return E->op_gemm_fp8(epi, bn, A, W, bias, out, M, N, K, iters, avg_us, (hipStream_t)stream);
 }
 int ecad_flux_op_qk_norm_rope(EcadFlux* e, void* qkv, int B, int T, int N, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* rope, void* stream) {
   FENG(e); return E->op_rope(qkv, B, T, N, wq, wk, wqt, wkt, rope, (hipStream_t)stream);

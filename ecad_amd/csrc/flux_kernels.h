@@ -8,6 +8,7 @@
 #pragma once
 #include "common.h"
 #include "fgemm.h"
+#include "fgemm8.h"
 
 namespace ecad {
 
@@ -19,6 +20,8 @@ struct FluxSrc {
 struct FluxRowArgs {
   void* h;             // [M, D] hidden states (updated in place when n_src > 0)
   void* y;             // LN output (ln kernel only)
+  uint8_t* y8;         // fp8 mode: the LN output goes out as e4m3 rows (row stride D bytes) with one fp32 scale per row instead of y,
+  float* y8_scale;     //   so the consuming fp8 GEMM needs no separate quantisation pass (fgemm8.h)
   const FluxSrc* srcs; // device array
   int n_src;
   int M, D;
@@ -95,19 +98,42 @@ __global__ __launch_bounds__(256) void flux_ln_modulate_kernel(const FluxRowArgs
   for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
   const float rstd = rsqrtf(var / (float)p.D + p.eps);
 
-  T* yrow = reinterpret_cast<T*>(p.y) + (size_t)row * p.D;
   const T* msh = reinterpret_cast<const T*>(p.shift) + (size_t)b * p.mod_stride;
   const T* msc = reinterpret_cast<const T*>(p.scale) + (size_t)b * p.mod_stride;
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + 64 * i;
     if (c < cpr) {
-      float sh[8], sc[8], o[8];
+      float sh[8], sc[8];
       unpack8<T>(gload16(msh + c * 8), sh);
       unpack8<T>(gload16(msc + c * 8), sc);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (x[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
-      gstore16(yrow + c * 8, pack8<T>(o));
+      for (int e = 0; e < 8; ++e) {
+        x[i][e] = round_elem<T>((x[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e]);
+        amax = fmaxf(amax, fabsf(x[i][e]));
+      }
+    }
+  }
+  if (p.y8) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float scl = amax > 0.f ? amax / FP8_MAX : 1.0f;
+    const float inv = 1.0f / scl;
+    if (lane == 0) p.y8_scale[row] = scl;
+    u32x2* d = reinterpret_cast<u32x2*>(p.y8 + (size_t)row * p.D);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < cpr)
+        d[c] = (u32x2){pack_fp8x4(x[i][0] * inv, x[i][1] * inv, x[i][2] * inv, x[i][3] * inv), pack_fp8x4(x[i][4] * inv, x[i][5] * inv, x[i][6] * inv, x[i][7] * inv)};
+    }
+  } else {
+    T* yrow = reinterpret_cast<T*>(p.y) + (size_t)row * p.D;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < cpr) gstore16(yrow + c * 8, pack8<T>(x[i]));
     }
   }
 }

@@ -30,6 +30,7 @@ class EcadFluxEngine:
         dtype: torch.dtype = torch.bfloat16,
         norm_eps=1e-6,
         device: int = 0,
+        fp8: bool | None = None,
     ):
         self.lib = L.load()
         if dtype not in (torch.float16, torch.bfloat16):
@@ -49,6 +50,9 @@ class EcadFluxEngine:
             self._h = C.c_void_p()
             self._raise(rc, handle=None)
         self.steps = 0
+        if fp8 is not None:  # None: the library default (env ECAD_FLUX_FP8)
+            self._chk(self.lib.ecad_flux_set_fp8(self._h, int(fp8)))
+        self.fp8 = fp8
 
     def _raise(self, rc: int, handle="self"):
         msg = self.lib.ecad_flux_last_error(self._h if handle == "self" else None)
@@ -159,6 +163,15 @@ class EcadFluxEngine:
             self._h, epi, bn, A.data_ptr(), _ptr(A2), A.shape[1], W.data_ptr(), _ptr(bias), _ptr(out), M, N, K, _ptr(resid), _ptr(gate),
             gate.stride(0) if gate is not None else 0, seg0, rows_per_batch0, rows_per_batch1, _stream_ptr(stream)))
         return out
+
+    def op_gemm_fp8(self, epi: int, bn: int, A, W, bias=None, iters: int = 0, stream=None):
+        """(out, avg_us): the OCP-fp8 GEMM on device-quantised copies of A and W; avg_us over `iters` repeats of the GEMM alone."""
+        M, K = A.shape
+        N = W.shape[0]
+        out = torch.empty(M, N, dtype=self.dtype, device=A.device)
+        us = C.c_float(0.0)
+        self._chk(self.lib.ecad_flux_op_gemm_fp8(self._h, epi, bn, A.data_ptr(), W.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, iters, C.byref(us), _stream_ptr(stream)))
+        return out, us.value
 
     def op_qk_norm_rope(self, qkv, B, T, N, wq, wk, rope, wq_txt=None, wk_txt=None, stream=None):
         self._chk(self.lib.ecad_flux_op_qk_norm_rope(self._h, qkv.data_ptr(), B, T, N, wq.data_ptr(), wk.data_ptr(), _ptr(wq_txt), _ptr(wk_txt), rope.data_ptr(), _stream_ptr(stream)))

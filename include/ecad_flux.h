@@ -59,6 +59,10 @@ const char* ecad_flux_last_error(const EcadFlux* e); /* e may be NULL: last crea
  * ptr: host or device memory; the engine converts, fuses (QKV per stream, all adaLN linears into one matrix) and keeps its own copy. */
 int ecad_flux_load_weights(EcadFlux* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim);
 int ecad_flux_finalize_weights(EcadFlux* e);
+/* Opt-in OCP fp8 (e4m3) for the block GEMMs (QKV, attention out, FF, proj_mlp, proj_out): weights get an fp8 copy with per-output-channel
+ * scales at finalize, activations are quantised per row right before each GEMM (csrc/fgemm8.h).  Call before ecad_flux_finalize_weights
+ * (a later call requires finalizing again).  Default off: the reference computes in bf16.  Env ECAD_FLUX_FP8=1 sets the default. */
+int ecad_flux_set_fp8(EcadFlux* e, int on);
 
 /* Replaces the per-component FluxCacheSchedule.get_recompute lookups (ecad/schedulers/cache_scheduler/cache_schedule.py:68-73 via
  * cached_flux_transformer_block.py:53-55,76-78,168-170,205-207).  bits_full: [steps][num_layers][3] = (full_attn, full_ff,
@@ -95,6 +99,11 @@ int ecad_flux_get_profile(EcadFlux* e, int max_classes, const char** names, doub
  * rows_per_batch0 rows, the rest to samples of rows_per_batch1 rows. */
 int ecad_flux_op_gemm(EcadFlux* e, int epi, int bn, const void* A, const void* A2, int k_split, const void* W, const float* bias, void* out, int M, int N,
                       int K, void* resid, const void* gate, int64_t gate_stride, int seg0, int rows_per_batch0, int rows_per_batch1, void* stream);
+/* fp8 (OCP e4m3) variant of the plain GEMM, for parity / speed probes: A [M,K] and W [N,K] (engine dtype) are quantised on the device
+ * (per-row / per-output-channel amax scales), out = epi((A8 @ W8^T) * sa * sw + bias), epi 0 or 1.  The GEMM alone is then repeated
+ * `iters` times and its average duration returned in *avg_us (may be NULL). */
+int ecad_flux_op_gemm_fp8(EcadFlux* e, int epi, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int iters, float* avg_us,
+                          void* stream);
 /* In-place per-head RMSNorm + RoPE on the q and k thirds of qkv [B*(T+N), 3*heads*128] (text rows first); rope_f32 [T+N][64][2] (cos, sin). */
 int ecad_flux_op_qk_norm_rope(EcadFlux* e, void* qkv, int B, int T, int N, const float* wq, const float* wk, const float* wq_txt, const float* wk_txt,
                               const float* rope_f32, void* stream);

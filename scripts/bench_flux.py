@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--json", default=None, help="write the result + per-class profile here")
+    ap.add_argument("--fp8", action="store_true", help="opt-in OCP e4m3 block GEMMs (ecad_flux_set_fp8); also reports the distance of the final latents to the bf16 engine")
     ap.add_argument("--decode-tail", action="store_true", help="also time the 16-channel VAE decode + uint8 postprocess on the native decoder")
     a = ap.parse_args()
     t0 = time.time()
@@ -37,8 +38,11 @@ def main():
     bf, bs = bf[:, : a.layers], bs[:, : a.single]
     model = FluxTransformer2DEdited(num_layers=a.layers, num_single_layers=a.single, guidance_embeds=True, max_batch=a.batch, max_image_tokens=a.grid * a.grid,
                                     max_text_tokens=a.text, torch_dtype=torch.bfloat16)
-    model.load_state_dict(synthetic_state_dict(model.config, 0, device="cuda", dtype=torch.bfloat16))
+    weights = synthetic_state_dict(model.config, 0, device="cuda", dtype=torch.bfloat16)
     eng = model.engine
+    if a.fp8:
+        eng._chk(eng.lib.ecad_flux_set_fp8(eng._h, 1))
+    model.load_state_dict(weights)
     eng.set_schedule(bf, bs)
     print(f"[{time.time() - t0:5.1f}s] engine ready: {eng.stats()}", flush=True)
     B, N, T = a.batch, a.grid * a.grid, a.text
@@ -56,6 +60,22 @@ def main():
 
     x = run(True)
     torch.cuda.synchronize()
+    if a.fp8:  # same inputs through a bf16 engine: how far do 20 cached steps of e4m3 GEMMs move the final latents?
+        ref_model = FluxTransformer2DEdited(num_layers=a.layers, num_single_layers=a.single, guidance_embeds=True, max_batch=a.batch, max_image_tokens=a.grid * a.grid,
+                                            max_text_tokens=a.text, torch_dtype=torch.bfloat16)
+        ref_model.engine._chk(ref_model.engine.lib.ecad_flux_set_fp8(ref_model.engine._h, 0))
+        ref_model.load_state_dict(weights)
+        ref_model.engine.set_schedule(bf, bs)
+        g2 = torch.Generator(device="cuda").manual_seed(77)
+        x0 = torch.randn(B, N, 64, generator=g2, device="cuda")
+        xa = eng.run_schedule(x0.clone(), enc, pooled, a.grid, a.grid, tm, gm, sig, use_graph=False)
+        xb = ref_model.engine.run_schedule(x0.clone(), enc, pooled, a.grid, a.grid, tm, gm, sig, use_graph=False)
+        torch.cuda.synchronize()
+        d = float((xa.double() - xb.double()).norm() / xb.double().norm())
+        print(f"fp8 vs bf16 engine, final latents after {steps} steps: rel-L2 {d:.3e} (cosine {float(torch.nn.functional.cosine_similarity(xa.flatten(), xb.flatten(), dim=0)):.5f})")
+        del ref_model
+        torch.cuda.empty_cache()
+    del weights
     print(f"[{time.time() - t0:5.1f}s] warm; latents finite: {bool(torch.isfinite(x).all())}, std {float(x.std()):.3f}", flush=True)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -96,7 +116,7 @@ def main():
                 print(f"  {k:24s} {v['ms']:9.2f} ms {100 * v['ms'] / tot:5.1f} %  {v['launches']:5d} launches  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:7.0f} TFLOP/s  {v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:7.0f} GB/s")
         print(f"  sum {tot:.1f} ms")
         if a.json:
-            Path(a.json).write_text(json.dumps({"workload": f"flux {a.grid * 16}x{a.grid * 16} batch {B}, {a.schedule}", "ms_per_batch": ms, "images_per_s": B / ms * 1e3,
+            Path(a.json).write_text(json.dumps({"workload": f"flux {a.grid * 16}x{a.grid * 16} batch {B}, {a.schedule}" + (", fp8 e4m3 block GEMMs" if a.fp8 else ""), "ms_per_batch": ms, "images_per_s": B / ms * 1e3,
                                                 "reference_equivalent_tflop_per_image": tflop / B, "whole_job_tflops": tflop / ms * 1e3, "stats": st, "profile": prof}, indent=1))
 
 

@@ -273,18 +273,22 @@ def test_flux_errors():
         eng.load_state_dict({"not.a.weight": torch.zeros(1)})
 
 
-def test_full_width_geometry_matches_oracle():
+@pytest.mark.parametrize("fp8,tol", [(False, 4e-2), (True, 1.2e-1)])
+def test_full_width_geometry_matches_oracle(fp8, tol):
     """FLUX.1-dev width and token counts (D = 3072 = 24 x 128, N = 4096 image + T = 512 text tokens, batch 2: the BASELINE config-5
     shapes every kernel is tuned for -- 256-wide tiles, S = 4608 attention without a tail, 1.06 M-row adaLN matrix per 57 blocks
     scaled down to 1 joint + 2 single blocks so the fp32 CPU oracle finishes in about a minute).  Step 1 mixes recomputed and
-    cached components."""
+    cached components.  fp8=True: the opt-in e4m3 GEMM mode at the real K = 3072 / 12288 / 15360 (stated tolerance 1.2e-1 per forward;
+    measured ~6e-2 with these weights, against ~8e-3 in bf16)."""
     cfg = flux_ref.FluxConfig(num_layers=1, num_single_layers=2)
     B, T, gh, gw = 2, 512, 64, 64
     bf = np.array([[[1, 1, 1]], [[0, 1, 0]]], dtype=bool)
     bs = np.array([[[1, 1, 1], [1, 1, 1]], [[1, 0, 1], [0, 0, 0]]], dtype=bool)
     dtype = torch.bfloat16
     w = flux_ref.make_weights(cfg, seed=2)
-    eng = make_engine(cfg, dtype, max_batch=B, max_n=gh * gw, max_t=T)
+    from ecad_amd.flux_engine import EcadFluxEngine
+
+    eng = EcadFluxEngine(num_layers=1, num_single_layers=2, max_batch=B, max_image_tokens=gh * gw, max_text_tokens=T, dtype=dtype, fp8=fp8)
     eng.load_state_dict(w)
     eng.set_schedule(bf, bs)
     ref = flux_ref.FluxOracle(cfg, w, round_dtype=dtype)
@@ -299,5 +303,74 @@ def test_full_width_geometry_matches_oracle():
         torch.cuda.synchronize()
         want = ref.forward(x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), 4992.0), ids, s, bf[s], bs[s])
         err = rel_l2(got.float(), want)
-        print(f"flux full-width step {s}: rel-L2 {err:.2e}")
-        assert err <= 4e-2
+        print(f"flux full-width step {s} (fp8={fp8}): rel-L2 {err:.2e}")
+        assert err <= tol
+
+
+@pytest.mark.parametrize("bn", [128, 256])
+def test_fp8_gemm_matches_fp32_within_e4m3_noise(op_engine, bn):
+    """fgemm8.h: per-row / per-channel scaled OCP e4m3 operands, fp32 accumulate.  e4m3 keeps 3 mantissa bits (relative step 2^-3,
+    rms rounding error ~3.6 % per operand); the errors of the K products are independent, so the GEMM output sits ~4 % rel-L2 from
+    the fp32 result whatever K is.  Stated tolerance: 6e-2."""
+    eng = op_engine[torch.bfloat16]
+    g = torch.Generator().manual_seed(bn)
+    M, N, K = 520, 768, 1280
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    A[7] = 0  # an all-zero row must not divide by zero
+    A[:, 5] *= 30.0  # an outlier column stretches every row scale
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = A.float() @ W.float().T + bias
+    out, _ = eng.op_gemm_fp8(0, bn, A, W, bias)
+    out_gelu, _ = eng.op_gemm_fp8(1, bn, A, W, bias)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    err = rel_l2(out.float(), ref)
+    print(f"fp8 gemm bn {bn}: rel-L2 {err:.3e}")
+    assert err <= 6e-2
+    assert rel_l2(out_gelu.float(), torch.nn.functional.gelu(ref, approximate="tanh")) <= 6e-2
+    assert rel_l2(out[7].float(), bias) <= 1e-2
+
+
+def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle():
+    """Opt-in fp8 mode (ecad_flux_set_fp8): same schedule, same inputs.  Stated tolerance per forward against the fp32 oracle: 1.5e-1
+    rel-L2 (every block GEMM carries ~4 % e4m3 noise; the bf16 engine sits at 5e-3), and the fp8 run must stay bit-reproducible
+    between hipGraph replay and eager launches."""
+    cfg = tiny_cfg(2, 3)
+    steps, B, T, gh, gw = 5, 2, 32, 8, 8
+    bf, bs = rand_bits(steps, cfg.num_layers, 0.5, 31), rand_bits(steps, cfg.num_single_layers, 0.5, 32)
+    w = flux_ref.make_weights(cfg, seed=0)
+    from ecad_amd.flux_engine import EcadFluxEngine
+
+    eng = EcadFluxEngine(num_layers=2, num_single_layers=3, num_heads=2, joint_attention_dim=128, pooled_projection_dim=64, max_batch=B, max_image_tokens=gh * gw,
+                         max_text_tokens=T, dtype=torch.bfloat16, fp8=True)
+    eng.load_state_dict(w)
+    eng.set_schedule(bf, bs)
+    plain = make_engine(cfg, torch.bfloat16)
+    plain.load_state_dict(w)
+    assert eng.stats()["weight_bytes"] > plain.stats()["weight_bytes"]  # the e4m3 weight copies exist: the fp8 path is the one running
+    ref = flux_ref.FluxOracle(cfg, w, round_dtype=torch.bfloat16)
+    ref.round_dtype = None
+    lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, B, gh, gw, T)
+    enc_d, pooled_d = enc.bfloat16(), pooled.bfloat16()
+    eng.begin_image_batch(enc_d.cuda(), pooled_d.cuda(), gh, gw)
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    for s in range(steps):
+        x = torch.randn(B, gh * gw, 64, generator=g).bfloat16()
+        t = 900.0 - 150 * s
+        got = eng.step(s, x.cuda(), t, 4992.0)
+        torch.cuda.synchronize()
+        want = ref.forward(x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), 4992.0), ids, s, bf[s], bs[s])
+        worst = max(worst, rel_l2(got.float(), want))
+    print(f"flux fp8 step parity: worst rel-L2 {worst:.2e}")
+    assert worst <= 1.5e-1
+    sig = flux_ref.flow_match_sigmas(steps, gh * gw)
+    tm, gm = flux_ref.model_scalars(sig, 5.0, torch.bfloat16)
+    outs = []
+    for use_graph in (False, True):
+        xx = lat.clone().cuda()
+        eng.run_schedule(xx, enc_d.cuda(), pooled_d.cuda(), gh, gw, tm.numpy(), float(gm[0]), sig, use_graph=use_graph)
+        torch.cuda.synchronize()
+        outs.append(xx.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()

@@ -332,7 +332,8 @@ def test_fp8_gemm_matches_fp32_within_e4m3_noise(op_engine, bn):
     assert rel_l2(out[7].float(), bias) <= 1e-2
 
 
-def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle(dtype):
     """Opt-in fp8 mode (ecad_flux_set_fp8): same schedule, same inputs.  Stated tolerance per forward against the fp32 oracle: 1.5e-1
     rel-L2 (every block GEMM carries ~4 % e4m3 noise; the bf16 engine sits at 5e-3), and the fp8 run must stay bit-reproducible
     between hipGraph replay and eager launches."""
@@ -343,21 +344,21 @@ def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle():
     from ecad_amd.flux_engine import EcadFluxEngine
 
     eng = EcadFluxEngine(num_layers=2, num_single_layers=3, num_heads=2, joint_attention_dim=128, pooled_projection_dim=64, max_batch=B, max_image_tokens=gh * gw,
-                         max_text_tokens=T, dtype=torch.bfloat16, fp8=True)
+                         max_text_tokens=T, dtype=dtype, fp8=True)
     eng.load_state_dict(w)
     eng.set_schedule(bf, bs)
-    plain = make_engine(cfg, torch.bfloat16)
+    plain = make_engine(cfg, dtype)
     plain.load_state_dict(w)
     assert eng.stats()["weight_bytes"] > plain.stats()["weight_bytes"]  # the e4m3 weight copies exist: the fp8 path is the one running
-    ref = flux_ref.FluxOracle(cfg, w, round_dtype=torch.bfloat16)
+    ref = flux_ref.FluxOracle(cfg, w, round_dtype=dtype)
     ref.round_dtype = None
     lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, B, gh, gw, T)
-    enc_d, pooled_d = enc.bfloat16(), pooled.bfloat16()
+    enc_d, pooled_d = enc.to(dtype), pooled.to(dtype)
     eng.begin_image_batch(enc_d.cuda(), pooled_d.cuda(), gh, gw)
     g = torch.Generator().manual_seed(5)
     worst = 0.0
     for s in range(steps):
-        x = torch.randn(B, gh * gw, 64, generator=g).bfloat16()
+        x = torch.randn(B, gh * gw, 64, generator=g).to(dtype)
         t = 900.0 - 150 * s
         got = eng.step(s, x.cuda(), t, 4992.0)
         torch.cuda.synchronize()
@@ -366,7 +367,7 @@ def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle():
     print(f"flux fp8 step parity: worst rel-L2 {worst:.2e}")
     assert worst <= 1.5e-1
     sig = flux_ref.flow_match_sigmas(steps, gh * gw)
-    tm, gm = flux_ref.model_scalars(sig, 5.0, torch.bfloat16)
+    tm, gm = flux_ref.model_scalars(sig, 5.0, dtype)
     outs = []
     for use_graph in (False, True):
         xx = lat.clone().cuda()

@@ -113,7 +113,8 @@ struct FluxBase {
 };
 
 template <typename T> struct FOp {
-  enum Kind { GEMM, GEMM8, QUANT, ATTN, ROPE, LN, REPLAY, COPY, SINUS, TEMB, EULER, UNPAD } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, ROPE, LN, REPLAY, COPY, SINUS, TEMB, EULER, UNPAD, FORK, JOIN } kind;
+  int lane = 0;  // 0: main stream; 1: the text rows of a joint block, on the side stream (FORK: side waits for main, JOIN: main waits for side)
   int cls = FC_MISC;
   int epi = 0, bn = 128;
   FGemmArgs<T> g{};
@@ -185,6 +186,11 @@ template <typename T> class FluxT : public FluxBase {
   int64_t prof_launch[FC_COUNT];
   int num_cus = 256;
   int bn_force = 0;  // env ECAD_FLUX_BN=128|256 forces one tile width wherever it divides N (A/B)
+  int lanes = 2;              // env ECAD_FLUX_LANES=1: everything on one stream (A/B)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  uint8_t* a8_side = nullptr;  // the side lane's own quantisation scratch ([B*T][4D])
+  float* sa8_side = nullptr;
   bool fp8 = false;           // env ECAD_FLUX_FP8=1 (or cfg dtype flag): OCP e4m3 for the block GEMMs (fgemm8.h); bf16 everywhere else
   struct W8 { uint8_t* w; float* s; };
   std::map<const void*, W8> w8map;  // bf16 weight pointer -> fp8 copy + per-output-channel scales
@@ -204,6 +210,11 @@ template <typename T> class FluxT : public FluxBase {
     if (graph_exec) hipGraphExecDestroy(graph_exec);
     if (graph) hipGraphDestroy(graph);
     if (cap_stream) hipStreamDestroy(cap_stream);
+    if (side_stream) hipStreamDestroy(side_stream);
+    if (ev_fork) hipEventDestroy(ev_fork);
+    if (ev_join) hipEventDestroy(ev_join);
+    if (a8_side) hipFree(a8_side);
+    if (sa8_side) hipFree(sa8_side);
     for (auto e : ev_pool) hipEventDestroy(e);
     if (warena) hipFree(warena);
     if (ws) hipFree(ws);
@@ -325,6 +336,10 @@ template <typename T> class FluxT : public FluxBase {
     if (const char* e = getenv("ECAD_FLUX_BN")) bn_force = atoi(e) == 128 ? 128 : atoi(e) == 256 ? 256 : 0;
     if (const char* e = getenv("ECAD_FLUX_FUSE")) fuse_rope = atoi(e) != 0;
     if (const char* e = getenv("ECAD_FLUX_FP8")) fp8 = atoi(e) != 0;
+    if (const char* e = getenv("ECAD_FLUX_LANES")) lanes = atoi(e) == 1 ? 1 : 2;
+    FHIPCHK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    FHIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    FHIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     if (fp8 && D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
     if (const char* e = getenv("ECAD_FLUX_ATTN")) attn_generic = strcmp(e, "generic") == 0;
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
@@ -452,6 +467,8 @@ template <typename T> class FluxT : public FluxBase {
       const size_t R = (size_t)cfg.max_batch * (cfg.max_image_tokens + cfg.max_text_tokens);
       FHIPCHK(hipMalloc((void**)&a8, R * 5 * d));
       FHIPCHK(hipMalloc((void**)&sa8, R * sizeof(float)));
+      FHIPCHK(hipMalloc((void**)&a8_side, (size_t)cfg.max_batch * cfg.max_text_tokens * 4 * d));
+      FHIPCHK(hipMalloc((void**)&sa8_side, (size_t)cfg.max_batch * cfg.max_text_tokens * sizeof(float)));
       FHIPCHK(hipMalloc((void**)&xn8, R * d));
       FHIPCHK(hipMalloc((void**)&sxn8, R * sizeof(float)));
     }
@@ -670,11 +687,20 @@ template <typename T> class FluxT : public FluxBase {
     ops.push_back(mk_gemm(FC_GEMM_MOD, FEPI_BIAS, temb_silu + r0 * D, D, w_mod, b_mod, mod_all + r0 * MODW, (int)MODW, rows, (int)MODW, D));
   }
 
+  static void tag_lane(std::vector<FOp<T>>& ops, size_t from, int lane) {
+    for (size_t k = from; k < ops.size(); ++k) ops[k].lane = lane;
+  }
+  static void emit_sync(std::vector<FOp<T>>& ops, typename FOp<T>::Kind kind) {
+    FOp<T> o; o.kind = kind; o.cls = FC_MISC; ops.push_back(o);
+  }
   void emit_step(std::vector<FOp<T>>& ops, int s, bool bind) {
     const size_t BT = (size_t)B * Tt;
     const int BNr = B * N, R = B * (Tt + N);
+    // Joint blocks: the text-row chain (small GEMMs: 48-192 tiles on 256 CUs) runs on the side stream next to the image-row chain and
+    // the two only meet at the joint attention (JOIN before it, FORK after it) and at the end of the joint phase.
+    emit_sync(ops, FOp<T>::FORK);
     {  // residual streams: text <- hoisted context embedding, image <- x_embedder(latents)
-      FOp<T> c; c.kind = FOp<T>::COPY; c.p0 = ctx0; c.p3 = hs; c.n = BT * D * sizeof(T); c.bytes = 2.0 * c.n; ops.push_back(c);
+      FOp<T> c; c.kind = FOp<T>::COPY; c.p0 = ctx0; c.p3 = hs; c.n = BT * D * sizeof(T); c.bytes = 2.0 * c.n; c.lane = 1; ops.push_back(c);
       FOp<T> x = mk_gemm(FC_GEMM_SMALL, FEPI_BIAS, model_in, CIN, w_x, b_x, hs + BT * D, D, BNr, D, CIN);
       x.bind_in = bind;
       ops.push_back(x);
@@ -684,22 +710,30 @@ template <typename T> class FluxT : public FluxBase {
     for (int i = 0; i < NL; ++i) {
       const JBlk& b = jb[i];
       auto m = [&](int k) { return mod_ptr(s, mo_joint(i, k)); };
+      size_t mark;
       if (exf(s, i, 0)) {
         emit_ln(ops, RI, pend_img, m(0), m(1));
-        emit_ln(ops, RT, pend_txt, m(6), m(7));
         FOp<T> qi = mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RI.xn, D, b.w_qkv_i, b.b_qkv_i, qkv + BT * 3 * D, 3 * D, BNr, 3 * D, D);
-        FOp<T> qt = mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RT.xn, D, b.w_qkv_t, b.b_qkv_t, qkv, 3 * D, (int)BT, 3 * D, D);
-        if (fuse_rope) { set_rope(qi, RI, b.nq, b.nk); set_rope(qt, RT, b.naq, b.nak); }
+        if (fuse_rope) set_rope(qi, RI, b.nq, b.nk);
         push_gemm(ops, qi);
+        mark = ops.size();
+        emit_ln(ops, RT, pend_txt, m(6), m(7));
+        FOp<T> qt = mk_gemm(FC_GEMM_QKV, FEPI_BIAS, RT.xn, D, b.w_qkv_t, b.b_qkv_t, qkv, 3 * D, (int)BT, 3 * D, D);
+        if (fuse_rope) set_rope(qt, RT, b.naq, b.nak);
         push_gemm(ops, qt);
+        tag_lane(ops, mark, 1);
+        emit_sync(ops, FOp<T>::JOIN);
         emit_attention(ops, b.nq, b.nk, b.naq, b.nak, attn_o);
+        emit_sync(ops, FOp<T>::FORK);
         const bool wl = wlive_f(s, i, 0);
         FOp<T> oi = mk_gemm(FC_GEMM_ATTN_OUT, 0, attn_o + BT * D, D, b.w_out_i, b.b_out_i, nullptr, D, BNr, D, D);
         set_resid(oi, RI, wl ? cj(i, 0) + BT * D : nullptr, m(2));
         push_gemm(ops, oi);
+        mark = ops.size();
         FOp<T> ot = mk_gemm(FC_GEMM_ATTN_OUT, 0, attn_o, D, b.w_out_t, b.b_out_t, nullptr, D, (int)BT, D, D);
         set_resid(ot, RT, wl ? cj(i, 0) : nullptr, m(8));
         push_gemm(ops, ot);
+        tag_lane(ops, mark, 1);
       } else {
         pend_img.push_back(FluxSrc{cj(i, 0) + BT * D, m(2)});
         pend_txt.push_back(FluxSrc{cj(i, 0), m(8)});
@@ -714,18 +748,25 @@ template <typename T> class FluxT : public FluxBase {
         pend_img.push_back(FluxSrc{cj(i, 1), m(5)});
       }
       if (exf(s, i, 2)) {
+        mark = ops.size();
         emit_ln(ops, RT, pend_txt, m(9), m(10));
         push_gemm(ops, mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RT.xn, D, b.w_ff1_t, b.b_ff1_t, ffmid, 4 * D, (int)BT, 4 * D, D));
         FOp<T> o = mk_gemm(FC_GEMM_FF2, 0, ffmid, 4 * D, b.w_ff2_t, b.b_ff2_t, nullptr, D, (int)BT, D, 4 * D);
         set_resid(o, RT, wlive_f(s, i, 2) ? cj(i, 2) : nullptr, m(11));
         push_gemm(ops, o);
+        tag_lane(ops, mark, 1);
       } else {
         pend_txt.push_back(FluxSrc{cj(i, 2), m(11)});
       }
     }
     // cat([text, image]) is the layout itself; pending per-stream replays are flushed before the rows are treated as one matrix
     emit_flush(ops, RI, pend_img);
-    emit_flush(ops, RT, pend_txt);
+    {
+      const size_t mark = ops.size();
+      emit_flush(ops, RT, pend_txt);
+      tag_lane(ops, mark, 1);
+    }
+    emit_sync(ops, FOp<T>::JOIN);
     for (int i = 0; i < NS; ++i) {
       const SBlk& b = sb[i];
       auto m = [&](int k) { return mod_ptr(s, mo_single(i, k)); };
@@ -930,13 +971,15 @@ template <typename T> class FluxT : public FluxBase {
         if (o.bind_in) { FGemmArgs<T> g = o.g; g.A = (const T*)call_in; return launch_gemm(o.epi, o.bn, g, s); }
         return launch_gemm(o.epi, o.bn, o.g, s);
       }
+      case FOp<T>::FORK:
+      case FOp<T>::JOIN: break;
       case FOp<T>::QUANT:
-        hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((o.g.M + 3) / 4), dim3(256), 0, s, (const T*)o.p0, (int64_t)o.i0, o.i1, (const T*)o.p1, (int64_t)o.i2, (int)o.n, a8,
-                           (int64_t)o.g.K, sa8, o.g.M);
+        hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((o.g.M + 3) / 4), dim3(256), 0, s, (const T*)o.p0, (int64_t)o.i0, o.i1, (const T*)o.p1, (int64_t)o.i2, (int)o.n,
+                           o.lane ? a8_side : a8, (int64_t)o.g.K, o.lane ? sa8_side : sa8, o.g.M);
         break;
       case FOp<T>::GEMM8: {
         FGemm8Args<T> q{};
-        q.A8 = o.p0 ? (const uint8_t*)o.p0 : a8; q.W8 = o.w8; q.sa = o.p0 ? (const float*)o.p1 : sa8; q.sw = o.sw8; q.lda8 = o.g.K; q.e = o.g;
+        q.A8 = o.p0 ? (const uint8_t*)o.p0 : (o.lane ? a8_side : a8); q.W8 = o.w8; q.sa = o.p0 ? (const float*)o.p1 : (o.lane ? sa8_side : sa8); q.sw = o.sw8; q.lda8 = o.g.K; q.e = o.g;
         return launch_gemm8(o.epi, o.bn, q, s);
       }
       case FOp<T>::ATTN: return launch_attn(o.a, s);
@@ -967,12 +1010,22 @@ template <typename T> class FluxT : public FluxBase {
 
   int run_ops(const std::vector<FOp<T>>& ops, hipStream_t s, bool allow_profile) {
     const bool prof = profiling && allow_profile;
+    const bool two = lanes == 2 && !prof;  // profiling brackets every launch with events on ONE stream
+    hipStream_t st[2] = {s, two ? side_stream : s};
     if (prof)
       while (ev_pool.size() < 2 * ops.size()) { hipEvent_t e; FHIPCHK(hipEventCreate(&e)); ev_pool.push_back(e); }
     size_t k = 0;
     for (const auto& o : ops) {
+      if (o.kind == FOp<T>::FORK || o.kind == FOp<T>::JOIN) {
+        if (two) {
+          if (o.kind == FOp<T>::FORK) { FHIPCHK(hipEventRecord(ev_fork, st[0])); FHIPCHK(hipStreamWaitEvent(st[1], ev_fork, 0)); }
+          else { FHIPCHK(hipEventRecord(ev_join, st[1])); FHIPCHK(hipStreamWaitEvent(st[0], ev_join, 0)); }
+        }
+        ++k;
+        continue;
+      }
       if (prof) FHIPCHK(hipEventRecord(ev_pool[2 * k], s));
-      int rc = launch_op(o, s);
+      int rc = launch_op(o, st[o.lane]);
       if (rc) return rc;
       if (prof) FHIPCHK(hipEventRecord(ev_pool[2 * k + 1], s));
       ++k;
@@ -981,6 +1034,7 @@ template <typename T> class FluxT : public FluxBase {
     if (prof) {
       FHIPCHK(hipStreamSynchronize(s));
       for (size_t i = 0; i < ops.size(); ++i) {
+        if (ops[i].kind == FOp<T>::FORK || ops[i].kind == FOp<T>::JOIN) continue;
         float ms = 0;
         FHIPCHK(hipEventElapsedTime(&ms, ev_pool[2 * i], ev_pool[2 * i + 1]));
         const int c = ops[i].cls;

@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--decode-tail", action="store_true", help="also measure the secondary PNG-ready rate (HIP VAE decode + PIL)")
     ap.add_argument("--no-decode-tail", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--fp8", action="store_true", help="flux1024 only: opt-in OCP e4m3 block GEMMs (BASELINE config 5 names fp8 MFMA); dtype then reads fp8")
+    ap.add_argument("--fp8", action="store_true", help="opt-in OCP e4m3 block GEMMs (north_star / BASELINE config 5 name fp8 MFMA); secondary: dtype then reads fp8, the headline stays f16 / bf16")
     ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024", "flux1024"],
                     help="alpha256 = BASELINE metric config (default); sigma1024 / flux1024 = BASELINE configs 3 / 5 (secondary, not the headline)")
     args = ap.parse_args()
@@ -238,7 +238,7 @@ def main():
     sched = PixArtCacheSchedule.from_json(SCHEDULE)
     bits = sched.to_numpy()
     eng = EcadEngine(num_layers=28, max_batch=2 * BATCH, max_tokens=(side // 2) ** 2, max_text_tokens=text_tokens, sample_size=sample_size,
-                     interpolation_scale=interp, dtype=torch.float16, device=local_rank)
+                     interpolation_scale=interp, dtype=torch.float16, device=local_rank, fp8=True if args.fp8 else None)
     weights = device_weights(type("C", (), dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2,
                                                 num_layers=28, caption_channels=4096)), seed=0, device=device)
     log('weights generated')
@@ -294,7 +294,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "fp8-e4m3 block GEMMs, f16 elsewhere [opt-in, not the headline precision]" if args.fp8 else "f16",
             "data": "synthetic",
             "config": {
                 "workload": ("PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch=16 (CFG batch 32), 1xMI355X per rank"

@@ -110,6 +110,7 @@ SIGNATURES = {
     "ecad_last_error": (C.c_char_p, [_P]),
     "ecad_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
     "ecad_finalize_weights": (_I, [_P]),
+    "ecad_set_fp8": (_I, [_P, _I]),
     "ecad_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),
     "ecad_begin_image_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ecad_step": (_I, [_P, _I, _P, _P, _P, _P]),

@@ -6,6 +6,7 @@
 // Reference call sites are cited per kernel.
 #pragma once
 #include "common.h"
+#include "fgemm8.h"
 
 namespace ecad {
 
@@ -33,6 +34,8 @@ struct FlushArgs {
   const void* mod_shift;
   const void* mod_scale;
   float eps;
+  uint8_t* y8;      // opt-in fp8 mode: the LN output leaves as e4m3 rows (stride D bytes) + one fp32 scale per row instead of y
+  float* y8_scale;  //   (its consumers are fp8 GEMMs: gemm3s8.h), saving the separate row-quantiser pass
 };
 
 // ---- cache replay, flat: each thread owns one 16-byte chunk of the hidden states across all sources.
@@ -258,19 +261,36 @@ __global__ __launch_bounds__(256) void ln_modulate16_kernel(const FlushArgs p) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = rsqrtf(var / (float)p.D + p.eps);
-    T* yrow = reinterpret_cast<T*>(p.y) + (size_t)row * p.D;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       const int c = l16 + 16 * i;
-      float sh[8], sc[8], o[8];
+      float sh[8], sc[8];
       unpack8<T>(gload16(msh + c * 8), sh);
       unpack8<T>(gload16(msc + c * 8), sc);
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.table_scale + c * 8), t1 = *reinterpret_cast<const f32x4*>(p.table_scale + c * 8 + 4);
       const f32x4 u0 = *reinterpret_cast<const f32x4*>(p.table_shift + c * 8), u1 = *reinterpret_cast<const f32x4*>(p.table_shift + c * 8 + 4);
       const float tsc[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]}, tsh[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (x[i][e] - mean) * rstd * (1.0f + tsc[e] + sc[e]) + (tsh[e] + sh[e]);
-      gstore16(yrow + c * 8, pack8<T>(o));
+      for (int e = 0; e < 8; ++e) {
+        x[i][e] = round_elem<T>((x[i][e] - mean) * rstd * (1.0f + tsc[e] + sc[e]) + (tsh[e] + sh[e]));
+        amax = fmaxf(amax, fabsf(x[i][e]));
+      }
+    }
+    if (p.y8) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+      const float scl = amax > 0.f ? amax / FP8_MAX : 1.0f;
+      const float inv = 1.0f / scl;
+      if (l16 == 0) p.y8_scale[row] = scl;
+      u32x2* d = reinterpret_cast<u32x2*>(p.y8 + (size_t)row * p.D);
+#pragma unroll
+      for (int i = 0; i < CPL; ++i)
+        d[l16 + 16 * i] = (u32x2){pack_fp8x4(x[i][0] * inv, x[i][1] * inv, x[i][2] * inv, x[i][3] * inv), pack_fp8x4(x[i][4] * inv, x[i][5] * inv, x[i][6] * inv, x[i][7] * inv)};
+    } else {
+      T* yrow = reinterpret_cast<T*>(p.y) + (size_t)row * p.D;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) gstore16(yrow + (l16 + 16 * i) * 8, pack8<T>(x[i]));
     }
   }
 }

@@ -26,6 +26,7 @@
 #include "gemm.h"
 #include "gemm2w.h"
 #include "gemm3s.h"
+#include "gemm3s8.h"
 #include "pgemm.h"
 
 namespace ecad {
@@ -41,11 +42,11 @@ constexpr int PROJ_PAD = 144;  // proj_out rows padded to one GEMM tile column
 
 enum KClass {
   KC_GEMM_QKV = 0, KC_GEMM_OUT1, KC_GEMM_Q2, KC_GEMM_OUT2, KC_GEMM_FF1, KC_GEMM_FF2, KC_GEMM_TEXTKV, KC_GEMM_CAPTION,
-  KC_GEMM_SMALL, KC_GEMM_KV1, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_COUNT
+  KC_GEMM_SMALL, KC_GEMM_KV1, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_QUANT, KC_COUNT
 };
 static const char* kclass_names[KC_COUNT] = {
     "gemm_qkv", "gemm_attn1_out", "gemm_attn2_q", "gemm_attn2_out", "gemm_ff1_gelu", "gemm_ff2", "gemm_text_kv", "gemm_caption",
-    "gemm_small", "gemm_attn1_kv_wide", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc"};
+    "gemm_small", "gemm_attn1_kv_wide", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc", "fp8_quant_rows"};
 
 struct EngineBase {
   EcadModelCfg cfg;
@@ -64,6 +65,7 @@ struct EngineBase {
   virtual int init() = 0;
   virtual int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
   virtual int finalize_weights() = 0;
+  virtual int set_fp8(int on) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
   virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st) = 0;
   virtual int step(int step_idx, const void* latents, const float* timestep, void* out, hipStream_t st) = 0;
@@ -85,10 +87,12 @@ struct EngineBase {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Op {
-  enum Kind { GEMM, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP } kind;
   int cls = KC_MISC;
   int epi = 0;
   GemmArgs<T> g{};
+  const uint8_t* w8 = nullptr;  // GEMM8 (opt-in fp8 mode): e4m3 weight copy + per-output-channel scales
+  const float* sw8 = nullptr;
   AttnArgs a{};
   bool attn_masked = false;
   FlushArgs f{};
@@ -122,6 +126,15 @@ template <typename T> class EngineT : public EngineBase {
   float *b_kv2_all, *b_patch, *b_t1, *b_t2, *b_ada, *b_c1, *b_c2, *b_proj, *sst_out, *pos;
   bool finalized = false;
   int pos_grid = 0;
+  // ---- opt-in fp8 (e4m3) block GEMMs: gemm3s8.h; env ECAD_FP8=1 or ecad_set_fp8
+  bool fp8 = false;
+  struct W8 { uint8_t* w; float* s; };
+  std::map<const void*, W8> w8map;
+  std::vector<void*> w8allocs;
+  uint8_t* a8 = nullptr;  // [M][4D] activation rows quantised in front of each fp8 GEMM
+  float* sa8 = nullptr;
+  const void* a8_src = nullptr;  // plan construction: which tensor a8 currently holds (Q and K/V launches share one pass)
+  bool f8_attr = false;
   // ---- workspaces
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -167,6 +180,9 @@ template <typename T> class EngineT : public EngineBase {
     for (auto e : ev_pool) hipEventDestroy(e);
     if (warena) hipFree(warena);
     if (ws) hipFree(ws);
+    for (void* q : w8allocs) hipFree(q);
+    if (a8) hipFree(a8);
+    if (sa8) hipFree(sa8);
     if (desc_dev) hipFree(desc_dev);
   }
 
@@ -195,6 +211,7 @@ template <typename T> class EngineT : public EngineBase {
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
+    if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) attn_shared = strcmp(at, "generic") != 0;
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
@@ -355,7 +372,69 @@ template <typename T> class EngineT : public EngineBase {
       if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "weight '%s' was never loaded", kv.first.c_str());
     finalized = true;
     plan_valid = false;
+    if (fp8) return build_fp8_weights();
     return ECAD_OK;
+  }
+  int set_fp8(int on) override {
+    if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; plan_valid = false; }
+    return ECAD_OK;
+  }
+  int quant_weight(const T* w, size_t rows, int K) {
+    W8 e{};
+    HIPCHK(hipMalloc((void**)&e.w, rows * K));
+    HIPCHK(hipMalloc((void**)&e.s, rows * sizeof(float)));
+    w8allocs.push_back(e.w); w8allocs.push_back(e.s);
+    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, 0, w, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, e.w, (int64_t)K, e.s, (int)rows);
+    w8map[w] = e;
+    return ECAD_OK;
+  }
+  int build_fp8_weights() {
+    if (D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
+    for (void* q : w8allocs) hipFree(q);
+    w8allocs.clear(); w8map.clear();
+    const size_t d = D;
+    int rc;
+    for (auto& b : blk) {
+      if ((rc = quant_weight(b.w_qkv, 3 * d, D)) || (rc = quant_weight(b.w_o1, d, D)) || (rc = quant_weight(b.w_q2, d, D)) || (rc = quant_weight(b.w_o2, d, D)) ||
+          (rc = quant_weight(b.w_ff1, 4 * d, D)) || (rc = quant_weight(b.w_ff2, d, 4 * D)))
+        return rc;
+      const W8 e = w8map[b.w_qkv];
+      w8map[b.w_qkv + d * d] = W8{e.w + d * d, e.s + d};  // the K,V rows of the fused weight (split QKV launch)
+    }
+    HIPCHK(hipDeviceSynchronize());
+    if (!a8) {
+      const size_t Mmax = (size_t)cfg.max_batch * cfg.max_tokens;
+      HIPCHK(hipMalloc((void**)&a8, Mmax * 4 * d));
+      HIPCHK(hipMalloc((void**)&sa8, Mmax * sizeof(float)));
+    }
+    if (!f8_attr) {
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS_CACHE_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+      f8_attr = true;
+    }
+    st.weight_bytes = (int64_t)warena_used + (int64_t)blk.size() * 14 * (int64_t)d * d;
+    return ECAD_OK;
+  }
+  // append a block GEMM; fp8 mode: one row-quantiser pass over its A operand (skipped when a8 already holds that tensor), then gemm3s8
+  void push_gemm(std::vector<Op<T>>& ops, Op<T> o, bool share_prev = false) {
+    auto it = fp8 ? w8map.find(o.g.W) : w8map.end();
+    if (it == w8map.end() || o.g.K % GEMM8_BK || o.g.N % G3_BN || (o.epi != EPI_BIAS && o.epi != EPI_BIAS_GELU && o.epi != EPI_BIAS_CACHE_RESID)) {
+      ops.push_back(o);
+      a8_src = nullptr;  // a bf16 GEMM may have rewritten the tensor a8 mirrors (e.g. the residual stream)
+      return;
+    }
+    if (!(share_prev && a8_src == o.g.A)) {  // share_prev: the previous push quantised the same, untouched tensor (Q then K,V of one LN output)
+      Op<T> qo;
+      qo.kind = Op<T>::QUANT; qo.cls = KC_QUANT; qo.p0 = o.g.A; qo.i0 = o.g.lda; qo.g.M = o.g.M; qo.g.K = o.g.K;
+      qo.bytes = (double)o.g.M * o.g.K * (2 * sizeof(T) + 1);
+      ops.push_back(qo);
+    }
+    a8_src = o.epi == EPI_BIAS_CACHE_RESID ? nullptr : o.g.A;  // the residual epilogue rewrites h, which a8 may mirror
+    o.kind = Op<T>::GEMM8;
+    o.w8 = it->second.w; o.sw8 = it->second.s;
+    o.bytes = ((double)o.g.M * o.g.K + (double)o.g.N * o.g.K) + (double)o.g.M * o.g.N * sizeof(T);
+    ops.push_back(o);
   }
 
   // 2-D sincos table exactly as diffusers' PatchEmbed builds it [ext]: first half of the channels encodes the column.
@@ -428,7 +507,8 @@ template <typename T> class EngineT : public EngineBase {
   // step): nothing reads it before it is overwritten / dropped.  30 % of ours_fast's writes are dead.
   bool cache_write_live(int s, int b, int c) const { return s + 1 < steps && !executed[((size_t)(s + 1) * L + b) * 3 + c]; }
 
-  void emit_ln(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, const float* tsh, const float* tsc, const T* msh, const T* msc, int64_t ln_stride, int64_t mstride) {
+  void emit_ln(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, const float* tsh, const float* tsc, const T* msh, const T* msc, int64_t ln_stride, int64_t mstride,
+               bool feeds_fp8 = false) {
     if (pend.size() > 6) emit_replay(ops, pend, M, mstride);
     Op<T> o;
     o.kind = Op<T>::LN; o.cls = KC_LN;
@@ -437,6 +517,12 @@ template <typename T> class EngineT : public EngineBase {
     if (!pend.empty()) {
       o.desc_off = (int)desc_host.size();
       for (auto& p : pend) desc_host.push_back(SrcDesc{p.cache, p.gate_table, p.gate_mod});
+    }
+    if (feeds_fp8 && fp8 && ln16 && D == 1152) {  // the consumers are fp8 GEMMs: the kernel writes e4m3 + row scales straight into a8 / sa8
+      o.f.y8 = a8; o.f.y8_scale = sa8;
+      a8_src = xn;
+    } else {
+      a8_src = nullptr;
     }
     o.bytes = (2.0 + pend.size() + (pend.empty() ? 0 : 1)) * M * (double)D * sizeof(T);
     st.cache_bytes_read += (int64_t)pend.size() * M * D * (int64_t)sizeof(T);
@@ -474,21 +560,21 @@ template <typename T> class EngineT : public EngineBase {
       T* c2 = cache + ((size_t)b * 3 + 2) * slot;
       // --- attn1
       if (ex[0]) {
-        emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride);
+        emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, true);
         if (split_qkv && (2 * D) % G2_BN == 0) {
           // Q columns on 256x144 tiles (256 tiles) + K,V columns on 256x288 tiles (256 tiles): the wide tiles move 32 % fewer
           // L2->LDS bytes per flop, and both launches fill the chip exactly once
-          ops.push_back(mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, D, D, D, 3 * D));
-          ops.push_back(mk_gemm(KC_GEMM_KV1, EPI_BIAS, xn, B.w_qkv + (size_t)D * D, B.b_qkv + D, qkv + D, M, 2 * D, D, D, 3 * D));
+          push_gemm(ops, mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, D, D, D, 3 * D), true);
+          push_gemm(ops, mk_gemm(KC_GEMM_KV1, EPI_BIAS, xn, B.w_qkv + (size_t)D * D, B.b_qkv + D, qkv + D, M, 2 * D, D, D, 3 * D), true);
         } else {
-          ops.push_back(mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D));
+          push_gemm(ops, mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D), true);
         }
         Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0;
         a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = 4.0 * Bt * (double)NH * N * (double)N * DH; a.bytes = 4.0 * M * (double)D * sizeof(T);
         ops.push_back(a);
-        ops.push_back(mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, cache_write_live(s, b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
+        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, cache_write_live(s, b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
         if (cache_write_live(s, b, 0)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 4ll * M * D * D; st.linear_macs_executed += 4ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)N * D;
       } else {
@@ -497,14 +583,14 @@ template <typename T> class EngineT : public EngineBase {
       // --- attn2 (no norm for ada_norm_single, cached_transformer_block.py:264-267; no gate, :289)
       if (ex[1]) {
         emit_replay(ops, pend, M, mstride);
-        ops.push_back(mk_gemm(KC_GEMM_Q2, EPI_BIAS, h, B.w_q2, B.b_q2, qc, M, D, D, D, D));
+        push_gemm(ops, mk_gemm(KC_GEMM_Q2, EPI_BIAS, h, B.w_q2, B.b_q2, qc, M, D, D, D, D));
         Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_CROSS; a.attn_masked = true;
         a.a.q = qc; a.a.k = kv2 + (size_t)b * 2 * D; a.a.v = kv2 + (size_t)b * 2 * D + D; a.a.out = attn_o; a.a.bias = bias_buf;
         a.a.ldq = D; a.a.ldk = a.a.ldv = ldkv; a.a.ldo = D; a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = Tt; a.a.dh = DH;
         a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = 4.0 * Bt * (double)NH * N * (double)Tt * DH; a.bytes = (2.0 * M + 2.0 * Mt) * D * sizeof(T);
         ops.push_back(a);
-        ops.push_back(mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, cache_write_live(s, b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
+        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, cache_write_live(s, b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
         if (cache_write_live(s, b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
       } else {
@@ -512,9 +598,9 @@ template <typename T> class EngineT : public EngineBase {
       }
       // --- ff
       if (ex[2]) {
-        emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride);
-        ops.push_back(mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D));
-        ops.push_back(mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, cache_write_live(s, b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
+        emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride, true);
+        push_gemm(ops, mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D), true);
+        push_gemm(ops, mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, cache_write_live(s, b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
         if (cache_write_live(s, b, 2)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 8ll * M * D * D; st.linear_macs_executed += 8ll * M * D * D;
       } else {
@@ -745,6 +831,19 @@ template <typename T> class EngineT : public EngineBase {
     const int M = Bt * N;
     switch (o.kind) {
       case Op<T>::GEMM: return launch_gemm(o.epi, o.cls, o.g, s);
+      case Op<T>::QUANT:
+        hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((o.g.M + 3) / 4), dim3(256), 0, s, (const T*)o.p0, (int64_t)o.i0, o.g.K, (const T*)nullptr, (int64_t)0, 0, a8, (int64_t)o.g.K,
+                           sa8, o.g.M);
+        break;
+      case Op<T>::GEMM8: {
+        Gemm8Args<T> q{};
+        q.A8 = a8; q.W8 = o.w8; q.sa = sa8; q.sw = o.sw8; q.lda8 = o.g.K; q.e = o.g;
+        const int tiles = ((o.g.M + G3_BM - 1) / G3_BM) * (o.g.N / G3_BN);
+        if (o.epi == EPI_BIAS) hipLaunchKernelGGL((gemm3s8_kernel<T, EPI_BIAS>), dim3(tiles), dim3(G3_NW * 64), G3_LDS_BYTES, s, q);
+        else if (o.epi == EPI_BIAS_GELU) hipLaunchKernelGGL((gemm3s8_kernel<T, EPI_BIAS_GELU>), dim3(tiles), dim3(G3_NW * 64), G3_LDS_BYTES, s, q);
+        else hipLaunchKernelGGL((gemm3s8_kernel<T, EPI_BIAS_CACHE_RESID>), dim3(tiles), dim3(G3_NW * 64), G3_LDS_BYTES, s, q);
+        break;
+      }
       case Op<T>::ATTN: return launch_attn(o.a, o.attn_masked, s);
       case Op<T>::LN: return launch_ln(o.f, s);
       case Op<T>::REPLAY: launch_replay(o.f, s); break;
@@ -988,6 +1087,7 @@ const char* ecad_last_error(const EcadEngine* e) { return e ? e->impl->err.c_str
 
 int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { ENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
 int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights(); }
+int ecad_set_fp8(EcadEngine* e, int on) { ENG(e); return E->set_fp8(on); }
 int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks) { ENG(e); if (!bits) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bits, steps, blocks); }
 int ecad_begin_image_batch(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, void* stream) { ENG(e); return E->begin_batch(Bt, H, W, enc, mask, T, (hipStream_t)stream); }
 int ecad_step(EcadEngine* e, int step_idx, const void* lat, const float* ts, void* out, void* stream) { ENG(e); return E->step(step_idx, lat, ts, out, (hipStream_t)stream); }

@@ -1,0 +1,209 @@
+// gemm3s8.h -- OCP fp8 (e4m3) variant of gemm3s.h for the PixArt block GEMMs (opt-in: ecad_set_fp8; the reference computes in fp16 and
+// fp16 stays the precision of record).  Same 256 x 144 tile (every N of the model is a multiple of 144 and M = 8192 gives whole rounds
+// of 256 tiles), 8 waves x (32 rows x 144 columns), 3-stage LDS-DMA ring with counted vmcnt, same epilogues -- including the cache
+// write + gated residual (cached_transformer_block.py:243-246,289,317-320) -- but a K-step is 128 e4m3 elements (the same 128-byte
+// LDS rows) fed to v_mfma_scale_f32_16x16x128_f8f6f4 with all block scales 2^0; the per-row activation scale sa[m] (written by the
+// LN+modulate kernel or the row quantiser) and the per-output-channel weight scale sw[n] multiply the accumulators before the
+// epilogue.  See fgemm8.h for the instruction notes.
+#pragma once
+#include "common.h"
+#include "fgemm8.h"
+#include "gemm.h"
+#include "gemm3s.h"
+
+namespace ecad {
+
+template <typename T> struct Gemm8Args {
+  const uint8_t* A8;  // [M][K] e4m3 (row stride lda8 bytes)
+  const uint8_t* W8;  // [N][K] e4m3
+  const float* sa;    // [M]
+  const float* sw;    // [N]
+  int lda8;
+  GemmArgs<T> e;      // M, N, K, bias, C, resid, gate fields ... (A / W / lda / ldw unused)
+};
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> q) {
+  constexpr int BM = G3_BM, BN = G3_BN, NWAVES = G3_NW;
+  constexpr int WTM = BM / NWAVES;
+  constexpr int FM = WTM / 16, FN = BN / 16;  // 2 x 9
+  constexpr int A_BYTES = BM * 128;
+  constexpr int STAGE_BYTES = G3_STAGE_BYTES;
+  constexpr int A_INST = BM / 8 / NWAVES;
+  constexpr int B_INST_TOTAL = BN / 8;
+  constexpr int B_INST_MAX = (B_INST_TOTAL + NWAVES - 1) / NWAVES;
+  constexpr int CS = BN + 8;
+  const GemmArgs<T>& p = q.e;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+  }
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint8_t* a_src[A_INST];
+  const uint8_t* b_src[B_INST_MAX];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int row = m0 + r;
+    row = row < p.M ? row : p.M - 1;
+    a_src[i] = q.A8 + (size_t)row * q.lda8 + c * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INST_MAX; ++i) {
+    int inst = wave + i * NWAVES;
+    inst = inst < B_INST_TOTAL ? inst : B_INST_TOTAL - 1;
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = q.W8 + (size_t)(n0 + r) * p.K + c * 16;
+  }
+  auto issue = [&](int stage) {
+    char* abase = smem + stage * STAGE_BYTES;
+    char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      glds16(a_src[i], abase + (wave * A_INST + i) * 1024);
+      a_src[i] += GEMM8_BK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST_MAX; ++i) {
+      const int inst = wave + i * NWAVES;
+      if (inst < B_INST_TOTAL) glds16(b_src[i], bbase + inst * 1024);
+      b_src[i] += GEMM8_BK;
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wave * WTM + l15) * 128;
+  const int b_row_off = l15 * 128;
+  const int c0 = ((2 * g) ^ swz) * 16, c1 = ((2 * g + 1) ^ swz) * 16;
+  const int nk = p.K / GEMM8_BK;
+  issue(0);
+  if (nk > 1) issue(1);
+  // EPI_BIAS_CACHE_RESID: fetch the hidden-state chunks of the epilogue now (see gemm3s.h)
+  constexpr int CPR = BN / 8;
+  constexpr int CHUNKS = WTM * CPR;
+  constexpr int NCH = (CHUNKS + 63) / 64;
+  Pack8 hpre[EPI == EPI_BIAS_CACHE_RESID ? NCH : 1];
+  if (EPI == EPI_BIAS_CACHE_RESID) {
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int id = lane + it * 64;
+      const int rl = id / CPR, cchunk = id - rl * CPR;
+      const int m = m0 + wave * WTM + rl;
+      hpre[it].u = (u32x4){0, 0, 0, 0};
+      if (id < CHUNKS && m < p.M) hpre[it] = gload16(p.resid + (size_t)m * p.ldr + n0 + cchunk * 8);
+    }
+  }
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      int ns = stage + 2;
+      ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+      issue(ns);
+    }
+    const char* abase = smem + stage * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+    i32x8 af[FM], wf[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const Pack8 lo = lds_read16(abase + a_row_off + i * 2048 + c0), hi = lds_read16(abase + a_row_off + i * 2048 + c1);
+      af[i] = (i32x8){(int)lo.u[0], (int)lo.u[1], (int)lo.u[2], (int)lo.u[3], (int)hi.u[0], (int)hi.u[1], (int)hi.u[2], (int)hi.u[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const Pack8 lo = lds_read16(bbase + b_row_off + j * 2048 + c0), hi = lds_read16(bbase + b_row_off + j * 2048 + c1);
+      wf[j] = (i32x8){(int)lo.u[0], (int)lo.u[1], (int)lo.u[2], (int)lo.u[3], (int)hi.u[0], (int)hi.u[1], (int)hi.u[2], (int)hi.u[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
+  }
+  __syncthreads();
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int mi = m0 + wave * WTM + 16 * i + l15;
+    const float sam = q.sa[mi < p.M ? mi : p.M - 1];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nl = 16 * j + 4 * g;
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(q.sw + n0 + nl);
+      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+      const int ml = wave * WTM + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] * (sam * sv[r]) + bv[r];
+        if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+        if (EPI == EPI_BIAS_SILU) v = silu(v);
+        float_to_elem4<T>(o, r, v);
+      }
+      *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int id = lane + it * 64;
+    const int rl = id / CPR, cchunk = id - rl * CPR;
+    const int ml = wave * WTM + rl;
+    const int m = m0 + ml;
+    if (id >= CHUNKS || m >= p.M) continue;
+    const int n = n0 + cchunk * 8;
+    Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+    if (EPI == EPI_BIAS_CACHE_RESID) {
+      if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);
+      T* rp = p.resid + (size_t)m * p.ldr + n;
+      float o[8], h[8];
+      unpack8<T>(v, o);
+      unpack8<T>(hpre[it], h);
+      if (p.gate_table) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
+        float gt[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if (p.gate_mod) {
+          float gm[8];
+          const int b = m / p.rows_per_batch;
+          unpack8<T>(gload16(p.gate_mod + (size_t)b * p.gate_mod_stride + n), gm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gt[e] += gm[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += gt[e] * o[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += o[e];
+      }
+      gstore16(rp, pack8<T>(h));
+    } else {
+      gstore16(p.C + (size_t)m * p.ldc + n, v);
+    }
+  }
+}
+
+}  // namespace ecad

@@ -45,6 +45,7 @@ class EcadEngine:
         norm_eps=1e-6,
         interpolation_scale=None,
         device: int = 0,
+        fp8: bool | None = None,
     ):
         self.lib = L.load()
         if dtype not in (torch.float16, torch.bfloat16):
@@ -63,6 +64,9 @@ class EcadEngine:
             self._h = C.c_void_p()
             self._raise(rc, handle=None)
         self.steps = 0
+        if fp8 is not None:  # None: the library default (env ECAD_FP8)
+            self._chk(self.lib.ecad_set_fp8(self._h, int(fp8)))
+        self.fp8 = fp8
 
     # -- errors ---------------------------------------------------------------------------
     def _raise(self, rc: int, handle="self"):

@@ -83,6 +83,11 @@ int ecad_abi_version(void);
 int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim);
 /* Call once after the last ecad_load_weights: checks completeness, builds fused layouts. */
 int ecad_finalize_weights(EcadEngine* e);
+/* Opt-in OCP fp8 (e4m3) for the block GEMMs (QKV, attention out-projections, cross-attention Q, FF1, FF2): e4m3 weight copies with
+ * per-output-channel scales at finalize, activations quantised per row in front of each GEMM (csrc/gemm3s8.h).  Call before
+ * ecad_finalize_weights.  Default off (env ECAD_FP8=1 sets the default): the reference computes in fp16, which stays the precision of
+ * the headline metric; DESIGN.md states the measured accuracy of this mode. */
+int ecad_set_fp8(EcadEngine* e, int on);
 
 /* ---- schedule --------------------------------------------------------------------------- */
 

@@ -135,6 +135,7 @@ template <typename T> class EngineT : public EngineBase {
   float* sa8 = nullptr;
   const void* a8_src = nullptr;  // plan construction: which tensor a8 currently holds (Q and K/V launches share one pass)
   bool f8_attr = false;
+  bool fp8_wide = true;  // env ECAD_FP8_WIDE=0: 256 x 144 tiles everywhere (A/B)
   // ---- workspaces
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -212,6 +213,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) attn_shared = strcmp(at, "generic") != 0;
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
@@ -411,6 +413,8 @@ template <typename T> class EngineT : public EngineBase {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS_CACHE_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm2w8_kernel<T, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm2w8_kernel<T, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
       f8_attr = true;
     }
     st.weight_bytes = (int64_t)warena_used + (int64_t)blk.size() * 14 * (int64_t)d * d;
@@ -838,6 +842,12 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::GEMM8: {
         Gemm8Args<T> q{};
         q.A8 = a8; q.W8 = o.w8; q.sa = sa8; q.sw = o.sw8; q.lda8 = o.g.K; q.e = o.g;
+        if (fp8_wide && o.epi != EPI_BIAS_CACHE_RESID && o.g.N % G2_BN == 0 && ((o.g.M + G2_BM - 1) / G2_BM) * (o.g.N / G2_BN) >= num_cus) {  // 256 x 288 tiles, 4 x 2 waves
+          const int tiles2 = ((o.g.M + G2_BM - 1) / G2_BM) * (o.g.N / G2_BN);
+          if (o.epi == EPI_BIAS) hipLaunchKernelGGL((gemm2w8_kernel<T, EPI_BIAS>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, q);
+          else hipLaunchKernelGGL((gemm2w8_kernel<T, EPI_BIAS_GELU>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, q);
+          break;
+        }
         const int tiles = ((o.g.M + G3_BM - 1) / G3_BM) * (o.g.N / G3_BN);
         if (o.epi == EPI_BIAS) hipLaunchKernelGGL((gemm3s8_kernel<T, EPI_BIAS>), dim3(tiles), dim3(G3_NW * 64), G3_LDS_BYTES, s, q);
         else if (o.epi == EPI_BIAS_GELU) hipLaunchKernelGGL((gemm3s8_kernel<T, EPI_BIAS_GELU>), dim3(tiles), dim3(G3_NW * 64), G3_LDS_BYTES, s, q);

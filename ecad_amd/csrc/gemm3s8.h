@@ -9,6 +9,7 @@
 #include "common.h"
 #include "fgemm8.h"
 #include "gemm.h"
+#include "gemm2w.h"
 #include "gemm3s.h"
 
 namespace ecad {
@@ -203,6 +204,135 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
     } else {
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }
+  }
+}
+
+// ---- wide tile for the plain-store GEMMs with N % 288 == 0 (FF1, K/V, fused QKV): gemm2w.h's 256 x 288 tile, 8 waves laid out 4 (M) x 2 (N)
+// with 64 x 144 each.  With 32 x 144 per wave (above) a wave reads 22 fragments from LDS per 18 fp8 MFMAs and the tile is LDS-read-bound
+// (FF1 gained only 1.19x over fp16); here it is 26 reads per 36 MFMAs.  2-stage ring (2 x 69.6 KiB).
+template <typename T, int EPI>
+__global__ __launch_bounds__(G2_NW * 64) void gemm2w8_kernel(const Gemm8Args<T> q) {
+  static_assert(EPI != EPI_BIAS_CACHE_RESID, "plain-store epilogues only");
+  constexpr int FM = 4, FN = 9;
+  constexpr int A_INST = G2_BM / 8 / G2_NW;
+  constexpr int B_TOTAL = G2_BN / 8;
+  const GemmArgs<T>& p = q.e;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int tiles_n = p.N / G2_BN;
+  const int tiles_m = (p.M + G2_BM - 1) / G2_BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+  }
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+  const uint8_t* a_src[A_INST];
+  const uint8_t* b_src[5];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int row = m0 + r;
+    row = row < p.M ? row : p.M - 1;
+    a_src[i] = q.A8 + (size_t)row * q.lda8 + c * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int inst = wave + i * G2_NW;
+    inst = inst < B_TOTAL ? inst : B_TOTAL - 1;
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = q.W8 + (size_t)(n0 + r) * p.K + c * 16;
+  }
+  auto issue = [&](int stage) {
+    char* abase = smem + stage * G2_STAGE_BYTES;
+    char* bbase = abase + G2_A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      glds16(a_src[i], abase + (wave * A_INST + i) * 1024);
+      a_src[i] += GEMM8_BK;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int inst = wave + i * G2_NW;
+      if (inst < B_TOTAL) glds16(b_src[i], bbase + inst * 1024);
+      b_src[i] += GEMM8_BK;
+    }
+  };
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wm * 64 + l15) * 128;
+  const int b_row_off = (wn * 144 + l15) * 128;
+  const int c0 = ((2 * g) ^ swz) * 16, c1 = ((2 * g + 1) ^ swz) * 16;
+  const int nk = p.K / GEMM8_BK;
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(stage ^ 1);
+    const char* abase = smem + stage * G2_STAGE_BYTES;
+    const char* bbase = abase + G2_A_BYTES;
+    i32x8 af[FM], wf[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const Pack8 lo = lds_read16(abase + a_row_off + i * 2048 + c0), hi = lds_read16(abase + a_row_off + i * 2048 + c1);
+      af[i] = (i32x8){(int)lo.u[0], (int)lo.u[1], (int)lo.u[2], (int)lo.u[3], (int)hi.u[0], (int)hi.u[1], (int)hi.u[2], (int)hi.u[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const Pack8 lo = lds_read16(bbase + b_row_off + j * 2048 + c0), hi = lds_read16(bbase + b_row_off + j * 2048 + c1);
+      wf[j] = (i32x8){(int)lo.u[0], (int)lo.u[1], (int)lo.u[2], (int)lo.u[3], (int)hi.u[0], (int)hi.u[1], (int)hi.u[2], (int)hi.u[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+  }
+  __syncthreads();
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int ml = wm * 64 + 16 * i + l15;
+    const float sam = q.sa[m0 + ml < p.M ? m0 + ml : p.M - 1];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nl = wn * 144 + 16 * j + 4 * g;
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(q.sw + n0 + nl);
+      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] * (sam * sv[r]) + bv[r];
+        if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+        if (EPI == EPI_BIAS_SILU) v = silu(v);
+        float_to_elem4<T>(o, r, v);
+      }
+      *reinterpret_cast<u32x2*>(ctile + ml * G2_CS + nl) = o.u;
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = G2_BN / 8;
+  constexpr int CHUNKS = 32 * CPR;
+  for (int id = lane; id < CHUNKS; id += 64) {
+    const int rl = id / CPR, cchunk = id - rl * CPR;
+    const int ml = wave * 32 + rl;
+    const int m = m0 + ml;
+    if (m >= p.M) continue;
+    gstore16(p.C + (size_t)m * p.ldc + n0 + cchunk * 8, lds_read16(ctile + ml * G2_CS + cchunk * 8));
   }
 }
 

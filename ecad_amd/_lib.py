@@ -36,6 +36,7 @@ class EcadModelCfg(C.Structure):
         ("dtype", C.c_int32),
         ("norm_eps", C.c_float),
         ("interpolation_scale", C.c_float),
+        ("use_additional_conditions", C.c_int32),
     ]
 
 
@@ -111,6 +112,7 @@ SIGNATURES = {
     "ecad_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
     "ecad_finalize_weights": (_I, [_P]),
     "ecad_set_fp8": (_I, [_P, _I]),
+    "ecad_set_added_cond": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I]),
     "ecad_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),
     "ecad_begin_image_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ecad_step": (_I, [_P, _I, _P, _P, _P, _P]),

@@ -66,6 +66,7 @@ struct EngineBase {
   virtual int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
   virtual int finalize_weights() = 0;
   virtual int set_fp8(int on) = 0;
+  virtual int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
   virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st) = 0;
   virtual int step(int step_idx, const void* latents, const float* timestep, void* out, hipStream_t st) = 0;
@@ -87,7 +88,7 @@ struct EngineBase {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Op {
-  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE } kind;
   int cls = KC_MISC;
   int epi = 0;
   GemmArgs<T> g{};
@@ -123,6 +124,14 @@ template <typename T> class EngineT : public EngineBase {
   };
   std::vector<Blk> blk;
   T *w_kv2_all, *w_patch, *w_t1, *w_t2, *w_ada, *w_c1, *w_c2, *w_proj;
+  // micro-conditioning of the 1024-MS alpha checkpoints (use_additional_conditions): resolution / aspect-ratio embedders, E = D / 3 wide
+  T *w_sz1[2] = {nullptr, nullptr}, *w_sz2[2] = {nullptr, nullptr};
+  float *b_sz1[2] = {nullptr, nullptr}, *b_sz2[2] = {nullptr, nullptr};
+  float* cond_dev = nullptr;  // [max_batch][3] = (height, width, aspect ratio) per sample
+  T* size_emb = nullptr;      // [max_batch][D] = [res_h | res_w | aspect] embeddings, computed once per image batch
+  std::vector<float> cond_host;
+  int cond_bt = 0;
+  bool cond_uniform = true;
   float *b_kv2_all, *b_patch, *b_t1, *b_t2, *b_ada, *b_c1, *b_c2, *b_proj, *sst_out, *pos;
   bool finalized = false;
   int pos_grid = 0;
@@ -205,6 +214,7 @@ template <typename T> class EngineT : public EngineBase {
     if (P * P * COUT > PROJ_PAD) return fail(ECAD_E_UNSUPPORTED, "proj_out too wide");
     if (CAP % 64 != 0) return fail(ECAD_E_UNSUPPORTED, "caption_channels must be a multiple of 64");
     if (cfg.max_batch < 1 || cfg.max_tokens < 1 || cfg.max_text_tokens < 1) return fail(ECAD_E_INVALID, "max_batch/max_tokens/max_text_tokens must be positive");
+    if (cfg.use_additional_conditions && (D % 3 != 0 || (D / 3) % 4 != 0)) return fail(ECAD_E_UNSUPPORTED, "use_additional_conditions needs inner dim %d divisible by 12", D);
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
@@ -228,6 +238,8 @@ template <typename T> class EngineT : public EngineBase {
     size_t per_blk_f = 3 * d + d * 3 + 4 * d + d + 6 * d;
     size_t glob_T = (size_t)L * 2 * d * d + d * 16 + d * 256 + d * d + 6 * d * d + d * CAP + d * d + PROJ_PAD * d;
     size_t glob_f = (size_t)L * 2 * d + d + d + d + 6 * d + d + d + PROJ_PAD + 2 * d + (size_t)cfg.max_tokens * d;
+    const size_t E = d / 3;
+    if (cfg.use_additional_conditions) { glob_T += 2 * (E * 256 + E * E); glob_f += 4 * E; }
     warena_bytes = (per_blk_T * L + glob_T) * sizeof(T) + (per_blk_f * L + glob_f) * sizeof(float) + (size_t)(L * 16 + 64) * 256;
     HIPCHK(hipMalloc((void**)&warena, warena_bytes));
     HIPCHK(hipMemset(warena, 0, warena_bytes));
@@ -289,6 +301,19 @@ template <typename T> class EngineT : public EngineBase {
     reg("scale_shift_table", sst_out, true, 2, d, d);
     reg("proj_out.weight", w_proj, false, P * P * COUT, d, d);
     reg("proj_out.bias", b_proj, true, 1, P * P * COUT, P * P * COUT);
+    if (cfg.use_additional_conditions) {
+      // PixArtAlphaCombinedTimestepSizeEmbeddings [ext]: two TimestepEmbedding(256 -> D/3) MLPs
+      const char* nm[2] = {"resolution_embedder", "aspect_ratio_embedder"};
+      for (int k = 0; k < 2; ++k) {
+        w_sz1[k] = walloc<T>(E * 256); b_sz1[k] = walloc<float>(E);
+        w_sz2[k] = walloc<T>(E * E); b_sz2[k] = walloc<float>(E);
+        const std::string q = std::string("adaln_single.emb.") + nm[k] + ".";
+        reg(q + "linear_1.weight", w_sz1[k], false, E, 256, 256);
+        reg(q + "linear_1.bias", b_sz1[k], true, 1, E, E);
+        reg(q + "linear_2.weight", w_sz2[k], false, E, E, E);
+        reg(q + "linear_2.bias", b_sz2[k], true, 1, E, E);
+      }
+    }
     if (warena_used > warena_bytes) return fail(ECAD_E_INVALID, "internal: weight arena overflow");
     st.weight_bytes = (int64_t)warena_used;
 
@@ -310,6 +335,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t o_tes = take(trows * d * sizeof(T)), o_mod = take(trows * 6 * d * sizeof(T));
     const size_t o_bias = take(Mt * sizeof(float)), o_x0 = take(lat * sizeof(float)), o_lat = take(lat * sizeof(float));
     const size_t o_ts = take(trows * sizeof(float)), o_coef = take(max_steps * 8 * sizeof(float)), o_mask = take(Mt);
+    const size_t o_cond = take(Bm * 3 * sizeof(float)), o_szemb = take(Bm * d * sizeof(T));
     ws_bytes = off;
     HIPCHK(hipMalloc((void**)&ws, ws_bytes));
     HIPCHK(hipMemset(ws, 0, ws_bytes));
@@ -319,6 +345,7 @@ template <typename T> class EngineT : public EngineBase {
     tsin = (T*)(ws + o_tsin); temb1 = (T*)(ws + o_te1); temb = (T*)(ws + o_te); temb_silu = (T*)(ws + o_tes); mod_all = (T*)(ws + o_mod);
     bias_buf = (float*)(ws + o_bias); x0_prev = (float*)(ws + o_x0); lat_buf = (float*)(ws + o_lat); ts_dev = (float*)(ws + o_ts);
     coef_dev = (float*)(ws + o_coef); mask_buf = (uint8_t*)(ws + o_mask);
+    cond_dev = (float*)(ws + o_cond); size_emb = (T*)(ws + o_szemb);
     st.workspace_bytes = (int64_t)ws_bytes;
     st.cache_arena_bytes = (int64_t)((size_t)L * 3 * M * d * sizeof(T));
 
@@ -379,6 +406,23 @@ template <typename T> class EngineT : public EngineBase {
   }
   int set_fp8(int on) override {
     if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; plan_valid = false; }
+    return ECAD_OK;
+  }
+  // added_cond_kwargs of forward (pixart_transformer_2d_edited.py:208-211): host arrays, copied here; read by the size-embedding
+  // kernel at the start of every image batch (the captured graph reads the same device buffer)
+  int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt_) override {
+    if (!cfg.use_additional_conditions) return fail(ECAD_E_INVALID, "engine was created without use_additional_conditions");
+    if (!resolution || !aspect_ratio) return fail(ECAD_E_INVALID, "`added_cond_kwargs` cannot be None when using additional conditions for `adaln_single`.");
+    if (Bt_ < 1 || Bt_ > cfg.max_batch) return fail(ECAD_E_INVALID, "batch %d outside [1, max_batch=%d]", Bt_, cfg.max_batch);
+    HIPCHK(hipSetDevice(dev));
+    cond_host.resize((size_t)Bt_ * 3);
+    cond_uniform = true;
+    for (int b = 0; b < Bt_; ++b) {
+      cond_host[b * 3 + 0] = resolution[b * 2 + 0]; cond_host[b * 3 + 1] = resolution[b * 2 + 1]; cond_host[b * 3 + 2] = aspect_ratio[b];
+      for (int k = 0; k < 3; ++k) cond_uniform = cond_uniform && cond_host[b * 3 + k] == cond_host[k];
+    }
+    HIPCHK(hipMemcpy(cond_dev, cond_host.data(), cond_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    cond_bt = Bt_;
     return ECAD_OK;
   }
   int quant_weight(const T* w, size_t rows, int K) {
@@ -620,7 +664,7 @@ template <typename T> class EngineT : public EngineBase {
     }
     // per-step reference overhead the calflops model counts (patch conv, t-embed, caption, proj_out)
     const int64_t per_sample_over = (int64_t)Tt * ((int64_t)CAP * D + (int64_t)D * D) + (int64_t)N * 16 * D + (256ll * D + 7ll * D * D) + (int64_t)N * D * 32;
-    st.linear_macs_reference += per_sample_over * Bt;
+    st.linear_macs_reference += (per_sample_over + (cfg.use_additional_conditions ? size_embedder_macs() : 0)) * Bt;
     st.linear_macs_executed += ((int64_t)N * 16 * D + (int64_t)N * D * 32) * Bt;
   }
 
@@ -630,6 +674,10 @@ template <typename T> class EngineT : public EngineBase {
     ops.push_back(s);
     ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS_SILU, tsin + r0 * 256, w_t1, b_t1, temb1 + r0 * D, rows, D, 256, 256, D));
     ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, temb1 + r0 * D, w_t2, b_t2, temb + r0 * D, rows, D, D, D, D));
+    if (cfg.use_additional_conditions) {  // conditioning = timestep_emb + cat(resolution_emb, aspect_ratio_emb): per sample in a step plan, sample 0's in the run plan
+      Op<T> z; z.kind = Op<T>::ADDSIZE; z.cls = KC_MISC; z.p2 = temb + r0 * D; z.i0 = rows; z.i1 = bind_call ? Bt : 0;
+      ops.push_back(z);
+    }
     Op<T> a; a.kind = Op<T>::SILU; a.cls = KC_MISC; a.p0 = temb + r0 * D; a.p2 = temb_silu + r0 * D; a.n = (size_t)rows * D;
     ops.push_back(a);
     ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, temb_silu + r0 * D, w_ada, b_ada, mod_all + r0 * 6 * D, rows, 6 * D, D, D, 6 * D));
@@ -645,7 +693,13 @@ template <typename T> class EngineT : public EngineBase {
     // cross-attention K/V of the text for all blocks in ONE launch (weights stacked [L*2D, D])
     ops.push_back(mk_gemm(KC_GEMM_TEXTKV, EPI_BIAS, ctx, w_kv2_all, b_kv2_all, kv2, Mt, L * 2 * D, D, D, L * 2 * D));
     st.linear_macs_executed += (int64_t)Mt * ((int64_t)CAP * D + (int64_t)D * D) + (int64_t)Mt * L * 2 * D * D;
+    if (cfg.use_additional_conditions) {  // step-invariant as well: the reference re-evaluates both embedders at every step
+      Op<T> z; z.kind = Op<T>::SIZEEMB; z.cls = KC_MISC; z.i0 = Bt;
+      ops.push_back(z);
+      st.linear_macs_executed += (int64_t)Bt * size_embedder_macs();
+    }
   }
+  int64_t size_embedder_macs() const { const int64_t E = D / 3; return 3 * (256 * E + E * E); }
 
   int build_plans() {
     if (!finalized) return fail(ECAD_E_NOT_READY, "weights not finalized");
@@ -868,6 +922,11 @@ template <typename T> class EngineT : public EngineBase {
         break;
       }
       case Op<T>::SILU: hipLaunchKernelGGL((silu_kernel<T>), dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0, s, (const T*)o.p0, (T*)o.p2, o.n); break;
+      case Op<T>::SIZEEMB:
+        hipLaunchKernelGGL((size_embed_kernel<T>), dim3(o.i0 * 3), dim3(256), (256 + D / 3) * sizeof(float), s, cond_dev, w_sz1[0], b_sz1[0], w_sz2[0], b_sz2[0], w_sz1[1], b_sz1[1],
+                           w_sz2[1], b_sz2[1], size_emb, D / 3);
+        break;
+      case Op<T>::ADDSIZE: hipLaunchKernelGGL((add_size_emb_kernel<T>), dim3(o.i0), dim3(256), 0, s, (T*)o.p2, (const T*)size_emb, D, o.i1); break;
       case Op<T>::MASKBIAS: hipLaunchKernelGGL(mask_bias_kernel, dim3((o.i0 + 255) / 256), dim3(256), 0, s, (const uint8_t*)o.p0, (float*)o.p2, o.i0); break;
       case Op<T>::UNPATCH: {
         T* dst = o.call_out ? (T*)call_out : (T*)o.p2;
@@ -931,6 +990,8 @@ template <typename T> class EngineT : public EngineBase {
     if (!enc) return fail(ECAD_E_INVALID, "enc_dev is NULL");
     int rc = ensure_shapes(Bt_, H_, W_, T_);
     if (rc) return rc;
+    if (cfg.use_additional_conditions && cond_bt != Bt_)
+      return fail(ECAD_E_NOT_READY, "`added_cond_kwargs` cannot be None when using additional conditions for `adaln_single`: call ecad_set_added_cond for batch %d first", Bt_);
     rc = stage_inputs(enc, mask, s);
     if (rc) return rc;
     rc = run_ops(plan_begin, s, 0.f, true);
@@ -955,6 +1016,9 @@ template <typename T> class EngineT : public EngineBase {
     if (!enc || !latents || !ts || !coef) return fail(ECAD_E_INVALID, "NULL pointer argument");
     int rc = ensure_shapes(Bt_, H_, W_, T_);
     if (rc) return rc;
+    if (cfg.use_additional_conditions && (cond_bt != Bt_ || !cond_uniform))
+      return fail(cond_bt != Bt_ ? ECAD_E_NOT_READY : ECAD_E_INVALID,
+                  "ecad_run_schedule shares one adaLN table per step across the batch: call ecad_set_added_cond for batch %d with one (resolution, aspect_ratio) for all samples, as the pipeline does", Bt_);
     // per-schedule constants (timesteps, solver coefficients): uploaded synchronously, outside the graph
     std::vector<float> c8((size_t)steps * 8, 0.f), tsv(ts, ts + steps);
     for (int i = 0; i < steps; ++i) for (int j = 0; j < 5; ++j) c8[(size_t)i * 8 + j] = coef[i * 5 + j];
@@ -1098,6 +1162,7 @@ const char* ecad_last_error(const EcadEngine* e) { return e ? e->impl->err.c_str
 int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { ENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
 int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights(); }
 int ecad_set_fp8(EcadEngine* e, int on) { ENG(e); return E->set_fp8(on); }
+int ecad_set_added_cond(EcadEngine* e, const float* resolution, const float* aspect_ratio, int Bt) { ENG(e); return E->set_added_cond(resolution, aspect_ratio, Bt); }
 int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks) { ENG(e); if (!bits) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bits, steps, blocks); }
 int ecad_begin_image_batch(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, void* stream) { ENG(e); return E->begin_batch(Bt, H, W, enc, mask, T, (hipStream_t)stream); }
 int ecad_step(EcadEngine* e, int step_idx, const void* lat, const float* ts, void* out, void* stream) { ENG(e); return E->step(step_idx, lat, ts, out, (hipStream_t)stream); }

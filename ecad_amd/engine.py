@@ -46,6 +46,7 @@ class EcadEngine:
         interpolation_scale=None,
         device: int = 0,
         fp8: bool | None = None,
+        use_additional_conditions: bool = False,
     ):
         self.lib = L.load()
         if dtype not in (torch.float16, torch.bfloat16):
@@ -56,6 +57,7 @@ class EcadEngine:
         self.cfg = L.EcadModelCfg(
             num_layers, num_heads, head_dim, in_channels, out_channels, patch_size, sample_size, caption_channels,
             max_batch, max_tokens, max_text_tokens, _TORCH2ECAD[dtype], norm_eps, float(interpolation_scale or 0.0),
+            int(bool(use_additional_conditions)),
         )
         self.dim = num_heads * head_dim
         self._h = C.c_void_p()
@@ -110,6 +112,19 @@ class EcadEngine:
             raise ValueError(f"schedule bits must have shape (steps, blocks, 3), got {bits.shape}")
         self.steps = int(bits.shape[0])
         self._chk(self.lib.ecad_set_schedule(self._h, bits.ctypes.data_as(C.POINTER(C.c_uint8)), bits.shape[0], bits.shape[1]))
+
+    # -- micro-conditioning (1024-MS alpha checkpoints) ---------------------------------------
+    def set_added_cond(self, resolution, aspect_ratio) -> None:
+        """``added_cond_kwargs`` of the reference forward (pixart_transformer_2d_edited.py:208-211): resolution [Bt, 2] (height, width) and
+        aspect_ratio [Bt] or [Bt, 1]; must precede ``begin_image_batch`` / ``run_schedule`` for a batch of that size."""
+        if resolution is None or aspect_ratio is None:
+            raise ValueError("`added_cond_kwargs` cannot be None when using additional conditions for `adaln_single`.")
+        res = np.ascontiguousarray(torch.as_tensor(resolution).detach().float().cpu().numpy().reshape(-1, 2), dtype=np.float32)
+        ar = np.ascontiguousarray(torch.as_tensor(aspect_ratio).detach().float().cpu().numpy().reshape(-1), dtype=np.float32)
+        if res.shape[0] != ar.shape[0]:
+            raise ValueError(f"resolution has {res.shape[0]} rows but aspect_ratio has {ar.shape[0]}")
+        fp = C.POINTER(C.c_float)
+        self._chk(self.lib.ecad_set_added_cond(self._h, res.ctypes.data_as(fp), ar.ctypes.data_as(fp), res.shape[0]))
 
     # -- per batch ------------------------------------------------------------------------
     def _prep_enc(self, enc: torch.Tensor, mask: torch.Tensor | None):

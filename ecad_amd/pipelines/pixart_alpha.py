@@ -98,6 +98,14 @@ class PixArtAlphaPipeline:
         timesteps = self.scheduler.timesteps
         latents = self.prepare_latents(B, tr.config.in_channels, height, width, tr.dtype, device, generator, latents)
 
+        # micro-conditioning of the sample_size-128 alpha checkpoints (diffusers PixArtAlphaPipeline.__call__ step 6.1, mirrored at
+        # reference pass_through.py:268-290): one (height, width) / aspect ratio for the whole CFG-doubled batch
+        added_cond_kwargs = {"resolution": None, "aspect_ratio": None}
+        if getattr(tr, "use_additional_conditions", False):
+            added_cond_kwargs = {"resolution": torch.tensor([[float(height), float(width)]]).repeat(2 * B, 1),
+                                 "aspect_ratio": torch.tensor([[float(height / width)]]).repeat(2 * B, 1)}
+            tr.engine.set_added_cond(added_cond_kwargs["resolution"], added_cond_kwargs["aspect_ratio"])
+
         if self.native_loop:
             lat = tr.engine.run_schedule(enc, mask, latents.float(), timesteps.numpy().astype(np.float32), self.scheduler.coefficient_table(), guidance_scale, use_graph=True)
             latents = lat.to(tr.dtype)
@@ -110,7 +118,7 @@ class PixArtAlphaPipeline:
             for i, t in enumerate(timesteps):
                 x_in = torch.cat([latents] * 2)
                 tt = torch.full((x_in.shape[0],), float(t), device=device)
-                noise = tr(x_in, encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=tt, added_cond_kwargs=None, return_dict=False)[0]
+                noise = tr(x_in, encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=tt, added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
                 u, c = noise.chunk(2)
                 noise = u + guidance_scale * (c - u)
                 if tr.config.out_channels // 2 == tr.config.in_channels:

@@ -64,6 +64,12 @@ def state_dict_shapes(cfg) -> dict[str, tuple[int, ...]]:
         s[b + "ff.net.0.proj.bias"] = (4 * d,)
         s[b + "ff.net.2.weight"] = (d, 4 * d)
         s[b + "ff.net.2.bias"] = (d,)
+    if getattr(cfg, "use_additional_conditions", False):  # 1024-MS alpha: PixArtAlphaCombinedTimestepSizeEmbeddings [ext], size_emb_dim = D // 3
+        e = d // 3
+        for emb in ("resolution_embedder", "aspect_ratio_embedder"):
+            q = f"adaln_single.emb.{emb}."
+            s[q + "linear_1.weight"], s[q + "linear_1.bias"] = (e, 256), (e,)
+            s[q + "linear_2.weight"], s[q + "linear_2.bias"] = (e, e), (e,)
     return s
 
 
@@ -132,8 +138,6 @@ class PixArtTransformer2DEdited:
             norm_elementwise_affine=norm_elementwise_affine, norm_eps=norm_eps, interpolation_scale=interpolation_scale,
             use_additional_conditions=use_additional_conditions, caption_channels=caption_channels or 4096, attention_type=attention_type,
         )
-        if use_additional_conditions:
-            raise ValueError("micro-conditioned (1024-MS alpha) checkpoints are not supported yet: resolution/aspect-ratio embedders missing")
         self.inner_dim = num_attention_heads * attention_head_dim
         self.out_channels = out_channels
         self.norm_type = norm_type
@@ -146,6 +150,7 @@ class PixArtTransformer2DEdited:
             out_channels=out_channels, patch_size=patch_size, sample_size=sample_size, caption_channels=self.config.caption_channels,
             max_batch=max_batch, max_tokens=max_tokens or (sample_size // patch_size) ** 2, max_text_tokens=max_text_tokens,
             dtype=torch_dtype, norm_eps=norm_eps, interpolation_scale=interpolation_scale, device=dev,
+            use_additional_conditions=bool(use_additional_conditions),
         )
         self.dit_scheduler: DiTScheduler = dit_scheduler  # type: ignore
         self.cache_schedule: PixArtCacheSchedule | None = None
@@ -250,6 +255,8 @@ class PixArtTransformer2DEdited:
             raise ValueError("self-attention masks are not supported by the native engine (PixArt passes None)")
         if encoder_hidden_states is None or timestep is None:
             raise ValueError("encoder_hidden_states and timestep are required")
+        if self.use_additional_conditions and (added_cond_kwargs is None or added_cond_kwargs.get("resolution") is None or added_cond_kwargs.get("aspect_ratio") is None):
+            raise ValueError("`added_cond_kwargs` cannot be None when using additional conditions for `adaln_single`.")  # reference :208-211
         step = self.cache_schedule.curr_step
         enc_mask = encoder_attention_mask
         if enc_mask is not None and enc_mask.ndim == 3:  # already a bias [B,1,T]: 0 keep / -10000 discard
@@ -257,6 +264,8 @@ class PixArtTransformer2DEdited:
         key = (encoder_hidden_states.data_ptr(), tuple(encoder_hidden_states.shape), tuple(hidden_states.shape))
         if step == 0 or self._begun_key != key:
             # step-invariant work (caption projection, text K/V) is hoisted to the start of the batch
+            if self.use_additional_conditions:
+                self.engine.set_added_cond(added_cond_kwargs["resolution"], added_cond_kwargs["aspect_ratio"])
             self.engine.begin_image_batch(encoder_hidden_states, enc_mask, hidden_states.shape[-2], hidden_states.shape[-1])
             self._begun_key = key
         out = self.engine.step(step, hidden_states, timestep)

@@ -49,6 +49,7 @@ typedef struct EcadModelCfg {
   int32_t dtype;             /* ECAD_DTYPE_F16 (reference: .half(), :98) or ECAD_DTYPE_BF16 */
   float norm_eps;            /* 1e-6 */
   float interpolation_scale; /* <= 0: max(sample_size / 64, 1) as diffusers does */
+  int32_t use_additional_conditions; /* 1 for the 1024-MS alpha checkpoints: resolution / aspect-ratio embedders (pixart_transformer_2d_edited.py:43,69) */
 } EcadModelCfg;
 
 typedef struct EcadStats {
@@ -88,6 +89,13 @@ int ecad_finalize_weights(EcadEngine* e);
  * ecad_finalize_weights.  Default off (env ECAD_FP8=1 sets the default): the reference computes in fp16, which stays the precision of
  * the headline metric; DESIGN.md states the measured accuracy of this mode. */
 int ecad_set_fp8(EcadEngine* e, int on);
+/* Replaces the `added_cond_kwargs={"resolution", "aspect_ratio"}` argument of PixArtTransformer2DEdited.forward
+ * (pixart_transformer_2d_edited.py:169,208-211; filled by the pipeline at pass_through.py:268-290 for sample_size 128 checkpoints).
+ * Only for engines created with use_additional_conditions = 1, where it must precede ecad_begin_image_batch / ecad_run_schedule for a
+ * batch of that size (ECAD_E_NOT_READY otherwise -- the reference's ValueError).  resolution_host [Bt][2] = (height, width),
+ * aspect_ratio_host [Bt]: host arrays, copied.  ecad_step honours per-sample values; ecad_run_schedule requires one value for the
+ * whole batch (what the pipeline passes) and returns ECAD_E_INVALID otherwise. */
+int ecad_set_added_cond(EcadEngine* e, const float* resolution_host, const float* aspect_ratio_host, int Bt);
 
 /* ---- schedule --------------------------------------------------------------------------- */
 

@@ -67,7 +67,7 @@ def denoise(
     for i, t in enumerate(solver.timesteps):
         x_in = torch.cat([latents, latents], dim=0)
         tt = torch.full((x_in.shape[0],), float(t))
-        noise = model.forward(x_in, enc, mask, tt, counter.curr_step, bits[counter.curr_step])
+        noise = model.forward(x_in, enc, mask, tt, counter.curr_step, bits[counter.curr_step], added_cond=inputs.get("added_cond"))
         u, c = noise.chunk(2)
         eps = u + guidance_scale * (c - u)
         eps = model.q(eps[:, : model.cfg.in_channels])  # learned-sigma drop

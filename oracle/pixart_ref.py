@@ -44,6 +44,7 @@ class PixArtConfig:
     caption_channels: int = 4096
     norm_eps: float = 1e-6
     interpolation_scale: float | None = None
+    use_additional_conditions: bool = False  # True for PixArt-XL-2-1024-MS (sample_size 128)
 
     @property
     def dim(self) -> int:
@@ -83,6 +84,12 @@ def weight_shapes(cfg: PixArtConfig) -> dict[str, tuple[int, ...]]:
         s[b + "ff.net.0.proj.bias"] = (4 * d,)
         s[b + "ff.net.2.weight"] = (d, 4 * d)
         s[b + "ff.net.2.bias"] = (d,)
+    if getattr(cfg, "use_additional_conditions", False):  # 1024-MS alpha: PixArtAlphaCombinedTimestepSizeEmbeddings [ext], size_emb_dim = D // 3
+        e = d // 3
+        for emb in ("resolution_embedder", "aspect_ratio_embedder"):
+            q = f"adaln_single.emb.{emb}."
+            s[q + "linear_1.weight"], s[q + "linear_1.bias"] = (e, 256), (e,)
+            s[q + "linear_2.weight"], s[q + "linear_2.bias"] = (e, e), (e,)
     return s
 
 
@@ -179,12 +186,23 @@ class PixArtOracle:
         x = x.flatten(2).transpose(1, 2)  # [B, N, D], token = row*W + col
         return self.q(x + self.pos_embed[None])
 
-    def adaln_single(self, timestep: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-        p = "adaln_single.emb.timestep_embedder."
-        e = self.q(timestep_sinusoid(timestep))
-        e = self.lin(e, p + "linear_1")
-        e = self.q(F.silu(e))
-        embedded = self.lin(e, p + "linear_2")
+    def _timestep_mlp(self, values: torch.Tensor, prefix: str) -> torch.Tensor:
+        """TimestepEmbedding(256 -> width) on Timesteps(256) of ``values`` [ext]."""
+        e = self.q(timestep_sinusoid(values))
+        e = self.q(F.silu(self.lin(e, prefix + "linear_1")))
+        return self.lin(e, prefix + "linear_2")
+
+    def adaln_single(self, timestep: torch.Tensor, added_cond: dict | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        embedded = self._timestep_mlp(timestep, "adaln_single.emb.timestep_embedder.")
+        if self.cfg.use_additional_conditions:
+            # PixArtAlphaCombinedTimestepSizeEmbeddings.forward [ext]: resolution [B, 2] is flattened, embedded per scalar and reshaped to
+            # [B, 2E]; aspect_ratio [B, 1] -> [B, E]; conditioning = timestep_emb + cat(resolution_emb, aspect_ratio_emb)
+            if added_cond is None or added_cond.get("resolution") is None or added_cond.get("aspect_ratio") is None:
+                raise ValueError("`added_cond_kwargs` cannot be None when using additional conditions for `adaln_single`.")  # reference :208-211
+            b = timestep.shape[0]
+            res = self._timestep_mlp(added_cond["resolution"].float().reshape(-1), "adaln_single.emb.resolution_embedder.").reshape(b, -1)
+            ar = self._timestep_mlp(added_cond["aspect_ratio"].float().reshape(-1), "adaln_single.emb.aspect_ratio_embedder.").reshape(b, -1)
+            embedded = self.q(embedded + torch.cat([res, ar], dim=1))
         mod = self.lin(self.q(F.silu(embedded)), "adaln_single.linear")
         return mod, embedded  # [B, 6D], [B, D]
 
@@ -244,13 +262,13 @@ class PixArtOracle:
         return h
 
     # -- forward (pixart_transformer_2d_edited.py:160-253) -------------------
-    def forward(self, latents, enc, enc_mask, timestep, step: int, step_flags) -> torch.Tensor:
+    def forward(self, latents, enc, enc_mask, timestep, step: int, step_flags, added_cond: dict | None = None) -> torch.Tensor:
         """One noise prediction.  ``step_flags``: [blocks, 3] bools for this step."""
         cfg = self.cfg
         enc_bias = ((1 - enc_mask.float()) * -10000.0)[:, None, :]  # :255-291
         enc_bias = self.q(enc_bias)
         h = self.patch_embed(self.q(latents.float()))
-        mod, embedded = self.adaln_single(timestep)
+        mod, embedded = self.adaln_single(timestep, added_cond)
         ctx = self.caption_projection(self.q(enc.float()))
         for i in range(cfg.num_layers):
             h = self.block(i, step, step_flags[i], h, ctx, enc_bias, mod)

@@ -15,6 +15,8 @@ Outputs (data only -- inputs and expected outputs):
                                      with metrics.by_inference_step (bits via the
                                      reference's FluxCacheSchedule.to_numpy)
   tests/golden/flux_vectors.json     FluxCacheSchedule / FluxPopulationIOManager vectors
+  tests/golden/alpha1024_vectors.json  per-step MACs of the PixArt-alpha 1024-MS schedules (the micro-conditioned
+                                     checkpoint: N = 4096 and the resolution / aspect-ratio embedders)
 """
 import hashlib
 import json
@@ -264,7 +266,34 @@ def flux_golden():
     print("flux_vectors.json written")
 
 
+def alpha1024_golden():
+    """Known answers for the 1024-MS alpha weights (use_additional_conditions): non-TGATE schedules with measured per-step MACs."""
+    out = {}
+    for p in sorted((REF / "schedules" / "alpha_cache_schedules").rglob("*.json")):
+        with open(p) as f:
+            d = json.load(f)
+        cfg = d.get("config", {}) or {}
+        m = d.get("metrics", {}).get("by_inference_step")
+        if m is None or "1024" not in str(cfg.get("transformer_weights", "")) or cfg.get("pipeline", {}).get("name") == "tgate":
+            continue
+        sched = copy_schedule(str(p.relative_to(REF / "schedules")))  # the data file itself, for the generator-level test
+        bits = sched.to_numpy(flatten=True)
+        steps = sched.num_inference_steps
+        out[str(p.relative_to(REF / "schedules"))] = {
+            "transformer_weights": cfg["transformer_weights"], "height": cfg.get("height"), "width": cfg.get("width"),
+            "steps": steps, "bits_packed_hex": np.packbits(bits).tobytes().hex(), "bits_sum": int(bits.sum()),
+            "macs": [m[f"{s:03}"]["macs"] for s in range(steps)], "total_macs": d["metrics"].get("total_macs"),
+        }
+    with open(OUT / "alpha1024_vectors.json", "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"alpha1024_vectors.json: {len(out)} schedule(s)")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["alpha1024"]:
+        alpha1024_golden()
+        sys.exit(0)
     mac_kat()
     schedule_vectors()
     flux_golden()
+    alpha1024_golden()

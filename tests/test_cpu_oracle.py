@@ -148,3 +148,47 @@ def test_dpm_solver_timesteps_and_last_step():
 def test_weight_shapes_match_pixart_xl2():
     n = sum(int(np.prod(s)) for s in weight_shapes(PixArtConfig()).values())
     assert 600e6 < n < 615e6  # PixArt-XL/2 ~0.6B parameters
+
+
+# ---------------------------------------------------------------------------------------------
+# micro-conditioning of the 1024-MS alpha checkpoint (use_additional_conditions)
+# ---------------------------------------------------------------------------------------------
+def test_alpha_1024_ms_mac_kat_pins_the_size_embedders():
+    """The reference's measured per-step MACs for PixArt-XL-2-1024-MS (N = 4096, resolution + aspect-ratio embedders evaluated at every
+    step) = the closed-form model with the MACs of exactly the extra Linear layers the oracle adds for use_additional_conditions."""
+    vec = json.loads((GOLD / "alpha1024_vectors.json").read_text())
+    assert vec
+    extra = weight_shapes(PixArtConfig(use_additional_conditions=True)).keys() - weight_shapes(PixArtConfig()).keys()
+    shapes = weight_shapes(PixArtConfig(use_additional_conditions=True))
+    # resolution embedder runs on two scalars (height, width), aspect-ratio embedder on one
+    size_macs = sum(int(np.prod(shapes[k])) * (2 if "resolution" in k else 1) for k in extra if k.endswith("weight"))
+    assert size_macs == 737_280
+    for name, v in vec.items():
+        bits = np.unpackbits(np.frombuffer(bytes.fromhex(v["bits_packed_hex"]), dtype=np.uint8))[: v["steps"] * 84].reshape(v["steps"], 28, 3).astype(bool)
+        assert int(bits.sum()) == v["bits_sum"]
+        got = S.pixart_mac_model(S.resolve_executed(bits), tokens=(v["height"] // 16) * (v["width"] // 16), size_embedder_macs=size_macs)
+        assert got.tolist() == v["macs"] and int(got.sum()) == v["total_macs"], name
+
+
+def test_added_cond_kwargs_enter_the_conditioning():
+    cfg = PixArtConfig(num_layers=1, num_attention_heads=3, attention_head_dim=8, caption_channels=32, use_additional_conditions=True)
+    w = make_weights(cfg, seed=2)
+    # the extra keys are appended: the shared keys draw the same tensors as without them
+    w0 = make_weights(PixArtConfig(num_layers=1, num_attention_heads=3, attention_head_dim=8, caption_channels=32), seed=2)
+    assert all(torch.equal(w[k], v) for k, v in w0.items())
+    x, enc, mask = _inputs(cfg)
+    t = torch.tensor([500.0, 500.0])
+    flags = np.ones((1, 3), bool)
+    m = PixArtOracle(cfg, w)
+    with pytest.raises(ValueError, match="added_cond_kwargs"):
+        m.forward(x, enc, mask, t, 0, flags)
+    cond = {"resolution": torch.tensor([[1024.0, 1024.0], [512.0, 2048.0]]), "aspect_ratio": torch.tensor([[1.0], [0.25]])}
+    out = m.forward(x, enc, mask, t, 0, flags, added_cond=cond)
+    swapped = {"resolution": cond["resolution"].flip(0), "aspect_ratio": cond["aspect_ratio"].flip(0)}
+    out2 = PixArtOracle(cfg, w).forward(x, enc, mask, t, 0, flags, added_cond=swapped)
+    assert not torch.allclose(out, out2)
+    # sample 0 of `out` and sample 1 of a run with swapped conditions and swapped samples agree: conditions act per sample
+    out3 = PixArtOracle(cfg, w).forward(x.flip(0), enc.flip(0), mask.flip(0), t, 0, flags, added_cond=swapped)
+    assert torch.allclose(out, out3.flip(0), atol=1e-5)
+    mod, emb = m.adaln_single(t, cond)
+    assert mod.shape == (2, 6 * cfg.dim) and emb.shape == (2, cfg.dim)

@@ -89,10 +89,12 @@ class PixArtAlphaPipeline:
         device = tr.device
         B = prompt_embeds.shape[0]
         cfg_on = guidance_scale > 1.0
-        if not cfg_on:
-            raise ValueError("guidance_scale <= 1 (no CFG) is not wired into the native loop")
-        enc = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(device)
-        mask = torch.cat([negative_prompt_attention_mask, prompt_attention_mask], dim=0).to(device)
+        reps = 2 if cfg_on else 1  # guidance_scale <= 1: no unconditional half (diffusers do_classifier_free_guidance); per-step path only
+        if cfg_on:
+            enc = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(device)
+            mask = torch.cat([negative_prompt_attention_mask, prompt_attention_mask], dim=0).to(device)
+        else:
+            enc, mask = prompt_embeds.to(device), prompt_attention_mask.to(device)
 
         self.scheduler.set_timesteps(num_inference_steps, device=None)
         timesteps = self.scheduler.timesteps
@@ -102,11 +104,11 @@ class PixArtAlphaPipeline:
         # reference pass_through.py:268-290): one (height, width) / aspect ratio for the whole CFG-doubled batch
         added_cond_kwargs = {"resolution": None, "aspect_ratio": None}
         if getattr(tr, "use_additional_conditions", False):
-            added_cond_kwargs = {"resolution": torch.tensor([[float(height), float(width)]]).repeat(2 * B, 1),
-                                 "aspect_ratio": torch.tensor([[float(height / width)]]).repeat(2 * B, 1)}
+            added_cond_kwargs = {"resolution": torch.tensor([[float(height), float(width)]]).repeat(reps * B, 1),
+                                 "aspect_ratio": torch.tensor([[float(height / width)]]).repeat(reps * B, 1)}
             tr.engine.set_added_cond(added_cond_kwargs["resolution"], added_cond_kwargs["aspect_ratio"])
 
-        if self.native_loop:
+        if self.native_loop and cfg_on:
             lat = tr.engine.run_schedule(enc, mask, latents.float(), timesteps.numpy().astype(np.float32), self.scheduler.coefficient_table(), guidance_scale, use_graph=True)
             latents = lat.to(tr.dtype)
             if callback is not None:
@@ -116,11 +118,12 @@ class PixArtAlphaPipeline:
             tr._begun_key = None
         else:
             for i, t in enumerate(timesteps):
-                x_in = torch.cat([latents] * 2)
+                x_in = torch.cat([latents] * 2) if cfg_on else latents
                 tt = torch.full((x_in.shape[0],), float(t), device=device)
                 noise = tr(x_in, encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=tt, added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
-                u, c = noise.chunk(2)
-                noise = u + guidance_scale * (c - u)
+                if cfg_on:
+                    u, c = noise.chunk(2)
+                    noise = u + guidance_scale * (c - u)
                 if tr.config.out_channels // 2 == tr.config.in_channels:
                     noise = noise.chunk(2, dim=1)[0]
                 latents = self.scheduler.step(noise, t, latents)[0]

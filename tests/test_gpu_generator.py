@@ -113,3 +113,23 @@ def test_alpha_1024_ms_schedule_runs_micro_conditioned(embedding_dir):
     with pytest.raises(ValueError, match="added_cond_kwargs"):
         tr(torch.zeros(2, 4, 128, 128), encoder_hidden_states=torch.zeros(2, 120, 4096), timestep=torch.zeros(2), added_cond_kwargs=None)
     gen.free_diffusion_pipeline()
+
+
+def test_pipeline_without_classifier_free_guidance(embedding_dir):
+    """guidance_scale <= 1 (diffusers' do_classifier_free_guidance False): only the conditional half runs, through the per-step path.  With
+    guidance 1 the CFG formula u + 1 * (c - u) collapses to c, so the CFG-doubled run at guidance 1 + 1e-6 must give the same latents."""
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+
+    gen = get_image_generator_type("PixArtAlphaImageGenerator")(schedule_path=FAST, max_batch=4)
+    gen.create_diffusion_pipeline()
+    batch = next(iter(gen.load_and_batch_embeddings(embedding_dir, 2)))
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(3)).half()
+    kw = gen._pipeline_kwargs(batch, 256, 256, "latent")
+    a = gen.diffusion_pipeline(**{**kw, "guidance_scale": 1.0, "latents": lat.clone()})[0].float()
+    assert gen.cache_schedule.curr_step == 0  # counters were driven and reset
+    gen.diffusion_pipeline.native_loop = False
+    b = gen.diffusion_pipeline(**{**kw, "guidance_scale": 1.0 + 1e-6, "latents": lat.clone()})[0].float()
+    rel = float((a - b).norm() / b.norm())
+    print(f"no-CFG vs CFG at guidance 1: rel-L2 {rel:.2e}")
+    assert torch.isfinite(a).all() and rel < 3e-3
+    gen.free_diffusion_pipeline()

@@ -346,12 +346,20 @@ def main():
                 "launches_measured": d["launches"],
                 "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12,
             }
-            rep = prof.get("cache_replay")
+            # HBM regime: the pure cache-hit steps are one (3L + 2)-stream sweep each (class / kernel symbol "cache_hit_step":
+            # algorithmic bytes = (84 + 2) * Bt * N * D * 2 B at L = 28); the short mid-step replays are reported beside it.
+            rep = prof.get("cache_hit_step") if prof.get("cache_hit_step", {}).get("launches") else prof.get("cache_replay")
             if rep and rep["launches"]:
                 gbs = rep["bytes"] / (rep["ms"] * 1e-3) / 1e9
-                res["roofline_hbm"] = {"bound": "hbm", "kernel": "cache_replay", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": gbs / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": rep["bytes"] / rep["launches"],
-                                       "avg_launch_ms": rep["ms"] / rep["launches"]}
+                res["roofline_hbm"] = {"bound": "hbm", "kernel": "cache_hit_step" if rep is prof.get("cache_hit_step") else "cache_replay", "achieved": gbs,
+                                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                       "bytes_per_launch": rep["bytes"] / rep["launches"], "avg_launch_ms": rep["ms"] / rep["launches"],
+                                       "launches_measured": rep["launches"]}
+                mid = prof.get("cache_replay")
+                if mid and mid["launches"] and mid is not rep:
+                    res["roofline_hbm"]["mid_step_replays"] = {"achieved": mid["bytes"] / (mid["ms"] * 1e-3) / 1e9, "unit": "GB/s",
+                                                               "bytes_per_launch": mid["bytes"] / mid["launches"], "avg_launch_ms": mid["ms"] / mid["launches"],
+                                                               "launches_measured": mid["launches"]}
             tot = sum(v["ms"] for v in prof.values())
             res["time_breakdown_ms_per_batch"] = {k: round(v["ms"] / reps, 3) for k, v in prof.items() if v["launches"]}
             res["time_breakdown_ms_per_batch"]["_sum"] = round(tot / reps, 3)

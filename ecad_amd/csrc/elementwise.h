@@ -40,7 +40,8 @@ struct FlushArgs {
 
 // ---- cache replay, flat: each thread owns one 16-byte chunk of the hidden states across all sources.
 // Fully cached step: n_src = 84, one streaming pass over the cache arena.
-template <typename T>
+// TAG only separates the kernel symbols (0: mid-step replay, 1: whole cache-hit step) for rocprof's per-kernel statistics.
+template <typename T, int TAG = 0>
 __global__ __launch_bounds__(256) void cache_accumulate_kernel(const FlushArgs p) {
   const int cpr = p.D >> 3;
   const size_t total = (size_t)p.M * cpr;
@@ -95,6 +96,53 @@ __global__ __launch_bounds__(256) void cache_accumulate_kernel(const FlushArgs p
       }
     }
     gstore16(hp, pack8<T>(acc));
+  }
+}
+
+// ---- cache replay, R rows per thread: a thread owns chunk c of R consecutive rows of one sample, so the gate of (source, sample,
+// column) -- 48 bytes of L1/L2 traffic next to every 16-byte cache chunk in the flat kernel -- is fetched once per R chunks, and the
+// cache stream is read with non-temporal loads (each slot is read once per step; 1.6 GB never fits the Infinity Cache).
+// Probe (scripts/probe_hbm_read.hip): this access pattern without the gate traffic streams at 6.9 TB/s on one MI355X.
+template <typename T, int TAG, int R>
+__global__ __launch_bounds__(256) void cache_accumulate_rows_kernel(const FlushArgs p) {
+  const int cpr = p.D >> 3;
+  const unsigned total = (unsigned)(p.M / R) * cpr;
+  for (unsigned idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const unsigned g = idx / cpr, c = idx - g * cpr;
+    const unsigned row0 = g * R;
+    const int b = row0 / p.rows_per_batch;
+    const size_t off = (size_t)row0 * p.D + c * 8;
+    T* hp = reinterpret_cast<T*>(p.h) + off;
+    float acc[R][8];
+#pragma unroll
+    for (int j = 0; j < R; ++j) unpack8<T>(gload16(hp + (size_t)j * p.D), acc[j]);
+    for (int s = 0; s < p.n_src; ++s) {
+      const SrcDesc d = p.srcs[s];
+      const T* cp = reinterpret_cast<const T*>(d.cache) + off;
+      Pack8 cv[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) cv[j].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(cp + (size_t)j * p.D));
+      float gate[8];
+      if (d.gate_table) {
+        unpack8<T>(gload16(reinterpret_cast<const T*>(d.gate_mod) + (size_t)b * p.mod_stride + c * 8), gate);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(d.gate_table + c * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(d.gate_table + c * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gate[e] += t0[e]; gate[4 + e] += t1[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gate[e] = 1.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        float cf[8];
+        unpack8<T>(cv[j], cf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] += gate[e] * cf[e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) gstore16(hp + (size_t)j * p.D, pack8<T>(acc[j]));
   }
 }
 

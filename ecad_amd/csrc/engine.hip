@@ -42,11 +42,11 @@ constexpr int PROJ_PAD = 144;  // proj_out rows padded to one GEMM tile column
 
 enum KClass {
   KC_GEMM_QKV = 0, KC_GEMM_OUT1, KC_GEMM_Q2, KC_GEMM_OUT2, KC_GEMM_FF1, KC_GEMM_FF2, KC_GEMM_TEXTKV, KC_GEMM_CAPTION,
-  KC_GEMM_SMALL, KC_GEMM_KV1, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_QUANT, KC_COUNT
+  KC_GEMM_SMALL, KC_GEMM_KV1, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_QUANT, KC_CACHE_HIT_STEP, KC_COUNT
 };
 static const char* kclass_names[KC_COUNT] = {
     "gemm_qkv", "gemm_attn1_out", "gemm_attn2_q", "gemm_attn2_out", "gemm_ff1_gelu", "gemm_ff2", "gemm_text_kv", "gemm_caption",
-    "gemm_small", "gemm_attn1_kv_wide", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc", "fp8_quant_rows"};
+    "gemm_small", "gemm_attn1_kv_wide", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc", "fp8_quant_rows", "cache_hit_step"};
 
 struct EngineBase {
   EcadModelCfg cfg;
@@ -580,7 +580,9 @@ template <typename T> class EngineT : public EngineBase {
   void emit_replay(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, int64_t mstride) {
     if (pend.empty()) return;
     Op<T> o;
-    o.kind = Op<T>::REPLAY; o.cls = KC_CACHE_REPLAY;
+    // a pure cache-hit step (all 3L components replayed in one sweep, SURVEY 8d "algorithmic bytes on cache-hit steps") is its own class
+    // and kernel symbol so that its HBM rate is reported separately from the short mid-step replays
+    o.kind = Op<T>::REPLAY; o.cls = (int)pend.size() == 3 * L ? KC_CACHE_HIT_STEP : KC_CACHE_REPLAY;
     o.f.h = h; o.f.y = nullptr; o.f.n_src = (int)pend.size(); o.f.M = M; o.f.D = D; o.f.mod_stride = mstride; o.f.ln_mod_stride = 0; o.f.rows_per_batch = N;
     o.desc_off = (int)desc_host.size();
     for (auto& p : pend) desc_host.push_back(SrcDesc{p.cache, p.gate_table, p.gate_mod});
@@ -878,11 +880,23 @@ template <typename T> class EngineT : public EngineBase {
     else return fail(ECAD_E_UNSUPPORTED, "D=%d too wide for ln kernel", f.D);
     return ECAD_OK;
   }
-  void launch_replay(const FlushArgs& f, hipStream_t s) {
+  // Rows kernel (4 rows per thread, gate fetched once per 4 chunks, non-temporal cache reads) whenever the shapes allow: in-run A/B on the
+  // 84-source cache-hit step at Bt 32: 389 -> 258 us (4.17 -> 6.29 TB/s), mid-step replays 162 -> 105 us; 2 rows 340 us, 8 rows 276 us;
+  // capping the grid at 6 or 8 resident blocks per CU, or 8 sources in flight in the flat kernel: slower or equal.  ECAD_REPLAY=flat
+  // restores the one-chunk-per-thread kernel.
+  void launch_replay(const FlushArgs& f, hipStream_t s, bool hit_step = false) {
+    static const bool flat = getenv("ECAD_REPLAY") && strcmp(getenv("ECAD_REPLAY"), "flat") == 0;
+    if (!flat && f.M % 4 == 0 && f.rows_per_batch % 4 == 0) {
+      const size_t nb = ((size_t)(f.M / 4) * (f.D / 8) + 255) / 256;
+      if (hit_step) hipLaunchKernelGGL((cache_accumulate_rows_kernel<T, 1, 4>), dim3((unsigned)nb), dim3(256), 0, s, f);
+      else hipLaunchKernelGGL((cache_accumulate_rows_kernel<T, 0, 4>), dim3((unsigned)nb), dim3(256), 0, s, f);
+      return;
+    }
     const size_t total = (size_t)f.M * (f.D / 8);
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL((cache_accumulate_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, f);
+    if (hit_step) hipLaunchKernelGGL((cache_accumulate_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL((cache_accumulate_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, s, f);
   }
 
   int launch_op(const Op<T>& o, hipStream_t s, float guidance) {
@@ -910,7 +924,7 @@ template <typename T> class EngineT : public EngineBase {
       }
       case Op<T>::ATTN: return launch_attn(o.a, o.attn_masked, s);
       case Op<T>::LN: return launch_ln(o.f, s);
-      case Op<T>::REPLAY: launch_replay(o.f, s); break;
+      case Op<T>::REPLAY: launch_replay(o.f, s, o.cls == KC_CACHE_HIT_STEP); break;
       case Op<T>::PATCH: {
         const T* src = o.call_latents ? (const T*)call_latents : (const T*)o.p0;
         hipLaunchKernelGGL((patch_embed_kernel<T, 4, 2>), dim3(Hl / P, Bt), dim3(128), CIN * P * Wl * sizeof(float), s, src, w_patch, b_patch, pos, h, Hl, Wl, D);

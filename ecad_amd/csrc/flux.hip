@@ -959,6 +959,13 @@ template <typename T> class FluxT : public FluxBase {
     return ECAD_OK;
   }
   void launch_replay(const FluxRowArgs& f, hipStream_t s) {
+    static const bool flat = getenv("ECAD_REPLAY") && strcmp(getenv("ECAD_REPLAY"), "flat") == 0;
+    const int rpb1 = f.rows_per_batch1 > 0 ? f.rows_per_batch1 : 4;
+    if (!flat && f.M % 4 == 0 && f.seg0 % 4 == 0 && (f.seg0 == 0 || f.rows_per_batch0 % 4 == 0) && rpb1 % 4 == 0) {  // 4 rows per thread (flux_kernels.h)
+      const size_t nb = ((size_t)(f.M / 4) * (f.D / 8) + 255) / 256;
+      hipLaunchKernelGGL((flux_replay_rows_kernel<T, 4>), dim3((unsigned)nb), dim3(256), 0, s, f);
+      return;
+    }
     const size_t total = (size_t)f.M * (f.D / 8);
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

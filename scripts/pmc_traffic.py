@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch and per kernel class from two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+MI355X_MICROARCH.md "rocprofv3 PMC slots").
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline
+    python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_i_pmc_traffic.json
+
+Corrections exactly as the guide's HBM section prescribes: both counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide
+coalesced reads, so it is doubled; WRITE_SIZE is exact.  bench.py reads the newest profiles/r*_pmc_traffic.json for `roofline.traffic`.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+# kernel symbol (demangled or mangled substring) -> class name used by the engine's profiler / bench.py.  TAG template arguments make
+# every class its own symbol: gemm kernels <T, EPI, TAG> with TAG = the KClass index; replay <T, 0 | 1>.
+GEMM_TAGS = {0: "gemm_qkv", 1: "gemm_attn1_out", 2: "gemm_attn2_q", 3: "gemm_attn2_out", 4: "gemm_ff1_gelu", 5: "gemm_ff2", 6: "gemm_text_kv",
+             7: "gemm_caption", 8: "gemm_small", 9: "gemm_attn1_kv_wide"}
+
+
+def classify(name: str) -> str | None:
+    m = re.search(r"(gemm2w|gemm3s|pgemm)_kernel.*?Li(\d+)ELi(\d+)E", name) or re.search(r"(gemm2w|gemm3s|pgemm)_kernel<[^,]+, *(\d+), *(\d+)>", name)
+    if m:
+        return GEMM_TAGS.get(int(m.group(3)))
+    if "cache_accumulate" in name:  # cache_accumulate_kernel<T, TAG> / cache_accumulate_rows_kernel<T, TAG, R>
+        tag = re.search(r"cache_accumulate\w*kernel.*?Li(\d)E", name) or re.search(r"cache_accumulate\w*kernel<[^,]+, *(\d)", name)
+        return "cache_hit_step" if tag and tag.group(1) == "1" else "cache_replay"
+    if "ln_modulate" in name:
+        return "ln_modulate"
+    if "attn128_kernel" in name or "attn_kernel" in name:
+        masked = re.search(r"Lb([01])E", name) or re.search(r"(true|false)", name)
+        if masked is None:
+            return "attn"
+        return "attn_cross" if masked.group(1) in ("1", "true") else "attn_self"
+    if "patch_embed" in name:
+        return "patch_embed"
+    return None
+
+
+def read_pass(directory: Path, counter: str):
+    per = defaultdict(lambda: [0, 0.0, ""])  # class -> [launches, sum of counter values, symbol]
+    files = list(directory.rglob("*counter_collection.csv"))
+    if not files:
+        raise SystemExit(f"no *counter_collection.csv under {directory}")
+    for f in files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                cls = classify(row["Kernel_Name"])
+                if cls is None:
+                    continue
+                e = per[cls]
+                e[0] += 1
+                e[1] += float(row["Counter_Value"])
+                e[2] = row["Kernel_Name"]
+    return per
+
+
+def main():
+    fetch_dir, write_dir, out = Path(sys.argv[1]), Path(sys.argv[2]), Path(sys.argv[3])
+    fetch, write = read_pass(fetch_dir, "FETCH_SIZE"), read_pass(write_dir, "WRITE_SIZE")
+    res = {}
+    for cls in sorted(set(fetch) | set(write)):
+        nf, sf, sym = fetch.get(cls, [0, 0.0, ""])
+        nw, sw, sym2 = write.get(cls, [0, 0.0, ""])
+        fkb = sf / nf if nf else 0.0
+        wkb = sw / nw if nw else 0.0
+        res[cls] = {"kernel": sym or sym2, "launches": nf or nw, "fetch_size_kb_raw_per_launch": fkb, "write_size_kb_per_launch": wkb,
+                    "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0,
+                    "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM); WRITE_SIZE exact; separate --pmc passes, eager (no graph) run"}
+    out.write_text(json.dumps(res, indent=1))
+    for k, v in res.items():
+        print(f"{k:22s} launches {v['launches']:5d}  HBM {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB / launch")
+
+
+if __name__ == "__main__":
+    main()

@@ -351,8 +351,10 @@ def main():
             rep = prof.get("cache_hit_step") if prof.get("cache_hit_step", {}).get("launches") else prof.get("cache_replay")
             if rep and rep["launches"]:
                 gbs = rep["bytes"] / (rep["ms"] * 1e-3) / 1e9
-                res["roofline_hbm"] = {"bound": "hbm", "kernel": "cache_hit_step" if rep is prof.get("cache_hit_step") else "cache_replay", "achieved": gbs,
-                                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                hbm_kernel = "cache_hit_step" if rep is prof.get("cache_hit_step") else "cache_replay"
+                hbm_traffic = json.load(open(pmc[-1])).get(hbm_kernel, {}).get("hbm_bytes_per_launch") if pmc else None
+                res["roofline_hbm"] = {"bound": "hbm", "kernel": hbm_kernel, "achieved": gbs,
+                                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": hbm_traffic,
                                        "bytes_per_launch": rep["bytes"] / rep["launches"], "avg_launch_ms": rep["ms"] / rep["launches"],
                                        "launches_measured": rep["launches"]}
                 mid = prof.get("cache_replay")

@@ -1,0 +1,118 @@
+"""-m gpu: the checkpoint path a user of the reference takes -- ``from_pretrained(<local dir>, subfolder="transformer", ...)`` on a
+diffusers-layout directory (config.json + *.safetensors), as ``create_diffusion_pipeline`` does
+(ecad/image_generators/pixart_image_generator.py:64-88, flux_image_generator.py:136-163).  The directory is written here with seeded
+weights (no real checkpoint exists offline); the loaded model must equal, bit for bit, one fed the same tensors directly, config keys the
+engine does not know (diffusers bookkeeping) must be ignored, and missing / misnamed tensors must fail loudly."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_checkpoint(root, config: dict, state: dict, shards: int = 2):
+    from safetensors.torch import save_file
+
+    d = root / "transformer"
+    d.mkdir(parents=True)
+    (d / "config.json").write_text(json.dumps(config, indent=1))
+    keys = list(state)
+    per = (len(keys) + shards - 1) // shards
+    for i in range(shards):  # sharded like the real repositories (diffusion_pytorch_model-0000x-of-0000y.safetensors)
+        part = {k: state[k].contiguous() for k in keys[i * per:(i + 1) * per]}
+        if part:
+            save_file(part, str(d / f"diffusion_pytorch_model-{i + 1:05}-of-{shards:05}.safetensors"))
+    return root
+
+
+def test_pixart_checkpoint_directory(tmp_path):
+    from ecad_amd.schedulers.cache_scheduler.generators.pixart_schedule_generators import gen_default
+    from ecad_amd.schedulers.dit_scheduler.dit_scheduler import DiTScheduler, PixArtDiTSchedule
+    from ecad_amd.transformer_2d_models.pixart_transformer_2d_edited import PixArtTransformer2DEdited, synthetic_state_dict
+
+    layers, steps = 2, 3
+    config = {  # the keys of a diffusers 0.30 PixArtTransformer2DModel config.json, bookkeeping included
+        "_class_name": "PixArtTransformer2DModel", "_diffusers_version": "0.30.3", "activation_fn": "gelu-approximate", "attention_bias": True,
+        "attention_head_dim": 72, "attention_type": "default", "caption_channels": 4096, "cross_attention_dim": 1152, "dropout": 0.0, "in_channels": 4,
+        "interpolation_scale": None, "norm_elementwise_affine": False, "norm_eps": 1e-06, "norm_num_groups": 32, "norm_type": "ada_norm_single",
+        "num_attention_heads": 16, "num_embeds_ada_norm": 1000, "num_layers": layers, "out_channels": 8, "patch_size": 2, "sample_size": 32,
+        "upcast_attention": False, "use_additional_conditions": None, "double_self_attention": False, "only_cross_attention": False,
+    }
+    probe = PixArtTransformer2DEdited(num_layers=layers, sample_size=32, max_batch=2)
+    state = {k: v.half() for k, v in synthetic_state_dict(probe.config, seed=5).items()}
+    _write_checkpoint(tmp_path / "ckpt", config, state)
+
+    def schedules():
+        return DiTScheduler(PixArtDiTSchedule(layers, steps, "default")), next(gen_default(layers, steps))
+
+    dit, cache = schedules()
+    loaded = PixArtTransformer2DEdited.from_pretrained(tmp_path / "ckpt", subfolder="transformer", torch_dtype=torch.float16, dit_scheduler=dit,
+                                                       cache_schedule=cache, max_batch=2)
+    assert loaded.config.num_layers == layers and loaded.config.sample_size == 32 and not loaded.use_additional_conditions
+    probe.load_state_dict(state)
+    probe._post_init(*schedules())
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 32, 32, generator=g).half().cuda()
+    enc = (torch.randn(2, 120, 4096, generator=g) * 0.1).half().cuda()
+    mask = torch.ones(2, 120, dtype=torch.int64).cuda()
+    t = torch.tensor([999.0, 500.0]).cuda()
+    a = loaded(x, encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=t, return_dict=False)[0]
+    b = probe(x, encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=t, return_dict=False)[0]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+    # a checkpoint with a tensor missing, or with a tensor the model does not have, is an error -- never a silent partial load
+    broken = dict(state)
+    broken.pop("transformer_blocks.1.ff.net.2.weight")
+    _write_checkpoint(tmp_path / "missing", config, broken)
+    with pytest.raises(RuntimeError, match="never loaded"):
+        PixArtTransformer2DEdited.from_pretrained(tmp_path / "missing", subfolder="transformer", max_batch=2, dit_scheduler=dit, cache_schedule=cache)
+    extra = dict(state)
+    extra["transformer_blocks.0.attn1.to_qq.weight"] = torch.zeros(4, 4, dtype=torch.float16)
+    _write_checkpoint(tmp_path / "extra", config, extra)
+    with pytest.raises(ValueError, match="unknown weight name"):
+        PixArtTransformer2DEdited.from_pretrained(tmp_path / "extra", subfolder="transformer", max_batch=2, dit_scheduler=dit, cache_schedule=cache)
+    with pytest.raises(ValueError, match="neither a local checkpoint directory nor a known"):
+        PixArtTransformer2DEdited.from_pretrained(tmp_path / "nowhere", subfolder="transformer")
+
+
+def test_flux_checkpoint_directory(tmp_path):
+    from ecad_amd.schedulers.cache_scheduler.flux_cache_schedule import FluxCacheSchedule
+    from ecad_amd.schedulers.dit_scheduler.dit_scheduler import DiTScheduler, FluxDiTSchedule
+    from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import FluxTransformer2DEdited, synthetic_state_dict
+
+    steps = 2
+    config = {"_class_name": "FluxTransformer2DModel", "_diffusers_version": "0.30.3", "attention_head_dim": 128, "guidance_embeds": True, "in_channels": 64,
+              "joint_attention_dim": 128, "num_attention_heads": 2, "num_layers": 2, "num_single_layers": 2, "patch_size": 1, "pooled_projection_dim": 64,
+              "axes_dims_rope": [16, 56, 56]}
+    probe = FluxTransformer2DEdited(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64, guidance_embeds=True)
+    state = {k: v.bfloat16() for k, v in synthetic_state_dict(probe.config, seed=9).items()}
+    _write_checkpoint(tmp_path / "ckpt", config, state, shards=3)
+
+    def schedules():
+        bits = np.ones(steps * 4 * 3, dtype=bool)
+        return (DiTScheduler(FluxDiTSchedule(2, steps, "default", num_single_blocks=2)),
+                FluxCacheSchedule.from_numpy(bits, name="all", num_blocks=2, num_single_blocks=2, num_inference_steps=steps))
+
+    dit, cache = schedules()
+    loaded = FluxTransformer2DEdited.from_pretrained(tmp_path / "ckpt", subfolder="transformer", torch_dtype=torch.bfloat16, dit_scheduler=dit, cache_schedule=cache)
+    probe.load_state_dict(state)
+    probe._post_init(*schedules())
+    g = torch.Generator().manual_seed(1)
+    gh, gw, T = 4, 4, 16
+    lat = torch.randn(1, gh * gw, 64, generator=g).bfloat16().cuda()
+    enc = (torch.randn(1, T, 128, generator=g) * 0.1).bfloat16().cuda()
+    pooled = (torch.randn(1, 64, generator=g) * 0.5).bfloat16().cuda()
+    ids = torch.zeros(gh * gw, 3)
+    ids[:, 1] = torch.arange(gh).repeat_interleave(gw)
+    ids[:, 2] = torch.arange(gw).repeat(gh)
+    kw = dict(hidden_states=lat, encoder_hidden_states=enc, pooled_projections=pooled, timestep=torch.tensor([0.7]).cuda(), img_ids=ids.cuda(),
+              txt_ids=torch.zeros(T, 3).cuda(), guidance=torch.tensor([3.5]).cuda(), return_dict=False)
+    a, b = loaded(**kw)[0], probe(**kw)[0]
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    broken = dict(state)
+    broken.pop(next(k for k in state if k.startswith("single_transformer_blocks.1.")))
+    _write_checkpoint(tmp_path / "missing", config, broken)
+    with pytest.raises(RuntimeError, match="never loaded"):
+        FluxTransformer2DEdited.from_pretrained(tmp_path / "missing", subfolder="transformer", dit_scheduler=dit, cache_schedule=cache)

@@ -403,6 +403,9 @@ template <typename T> class FluxT : public FluxBase {
     int64_t numel = 1;
     for (int i = 0; i < ndim; ++i) numel *= shape[i];
     if (numel != d.rows * d.cols) return fail(ECAD_E_INVALID, "weight '%s': expected %lld elements, got %lld", name, (long long)(d.rows * d.cols), (long long)numel);
+    // a Linear weight must arrive as [out_features, in_features]: a transposed tensor has the right element count and the wrong meaning
+    if (ndim == 2 && d.rows > 1 && (shape[0] != d.rows || shape[1] != d.cols))
+      return fail(ECAD_E_INVALID, "weight '%s': expected shape [%lld, %lld], got [%lld, %lld]", name, (long long)d.rows, (long long)d.cols, (long long)shape[0], (long long)shape[1]);
     if (dtype != ECAD_DTYPE_F16 && dtype != ECAD_DTYPE_BF16 && dtype != ECAD_DTYPE_F32) return fail(ECAD_E_INVALID, "weight '%s': bad dtype %d", name, dtype);
     const size_t esz = dtype == ECAD_DTYPE_F32 ? 4 : 2;
     void* stage = nullptr;

@@ -73,6 +73,11 @@ def test_pixart_checkpoint_directory(tmp_path):
     _write_checkpoint(tmp_path / "extra", config, extra)
     with pytest.raises(ValueError, match="unknown weight name"):
         PixArtTransformer2DEdited.from_pretrained(tmp_path / "extra", subfolder="transformer", max_batch=2, dit_scheduler=dit, cache_schedule=cache)
+    transposed = dict(state)
+    transposed["transformer_blocks.0.ff.net.0.proj.weight"] = state["transformer_blocks.0.ff.net.0.proj.weight"].t().contiguous()  # [in, out]: same element count
+    _write_checkpoint(tmp_path / "transposed", config, transposed)
+    with pytest.raises(ValueError, match=r"expected shape \[4608, 1152\]"):
+        PixArtTransformer2DEdited.from_pretrained(tmp_path / "transposed", subfolder="transformer", max_batch=2, dit_scheduler=dit, cache_schedule=cache)
     with pytest.raises(ValueError, match="neither a local checkpoint directory nor a known"):
         PixArtTransformer2DEdited.from_pretrained(tmp_path / "nowhere", subfolder="transformer")
 

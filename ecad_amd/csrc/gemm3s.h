@@ -102,6 +102,30 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     }
   }
 #endif
+  // The gate (scale_shift_table row + adaLN modulation) depends on the column and the sample only.  When the tile lies inside one sample
+  // (always for N = 256 / 4096 tokens and 256-row tiles) lanes 0 .. CPR-1 fetch the 8 gate values of their column chunk NOW -- three small
+  // loads per wave instead of three per output chunk at the tail -- and the epilogue reads them back from LDS.
+  float gpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bool gate_lds = false;
+#ifndef G3_GATE_PER_CHUNK
+  if (EPI == EPI_BIAS_CACHE_RESID && p.gate_table) {
+    const int m_last = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
+    gate_lds = m0 / p.rows_per_batch == m_last / p.rows_per_batch;
+    if (gate_lds && lane < CPR) {
+      const int n = n0 + lane * 8;
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gpre[e] = t0[e]; gpre[4 + e] = t1[e]; }
+      if (p.gate_mod) {
+        float gm[8];
+        unpack8<T>(gload16(p.gate_mod + (size_t)(m0 / p.rows_per_batch) * p.gate_mod_stride + n), gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gpre[e] += gm[e];
+      }
+    }
+  }
+#endif
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A_INST(4) + 2: oldest stage retired for every wave
@@ -150,6 +174,11 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
       *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
     }
   }
+  float* gwave = reinterpret_cast<float*>(smem + BM * CS * sizeof(T)) + wave * BN;  // behind the C tile; one private copy per wave: no block barrier
+  if (gate_lds && lane < CPR) {
+    *reinterpret_cast<f32x4*>(gwave + lane * 8) = (f32x4){gpre[0], gpre[1], gpre[2], gpre[3]};
+    *reinterpret_cast<f32x4*>(gwave + lane * 8 + 4) = (f32x4){gpre[4], gpre[5], gpre[6], gpre[7]};
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int it = 0; it < NCH; ++it) {
@@ -171,7 +200,11 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
       float o[8], h[8];
       unpack8<T>(v, o);
       unpack8<T>(hv, h);
-      if (p.gate_table) {
+      if (gate_lds) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gwave + cchunk * 8), g1 = *reinterpret_cast<const f32x4*>(gwave + cchunk * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] += g0[e] * o[e]; h[4 + e] += g1[e] * o[4 + e]; }
+      } else if (p.gate_table) {
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
         float gt[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     const int n = n0 + cchunk * 8;
     Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
     if (EPI == EPI_BIAS_CACHE_RESID) {
-      if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);
+      if (p.C) gstore16_nt(p.C + (size_t)m * p.ldc + n, v);
       T* rp = p.resid + (size_t)m * p.ldr + n;
 #ifdef G3_NO_RESID_PREFETCH
       Pack8 hv = gload16(rp);

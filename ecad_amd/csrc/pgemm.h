@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GemmArgs<T> p) {
         if (m < p.M) {
           Pack8 v = lds_read16(slab + rl * PG_CS + cchunk * 8);
           if (EPI == EPI_BIAS_CACHE_RESID) {
-            if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);  // cache <- un-gated sub-layer output
+            if (p.C) gstore16_nt(p.C + (size_t)m * p.ldc + n, v);  // cache <- un-gated sub-layer output
             T* rp = p.resid + (size_t)m * p.ldr + n;
             Pack8 hv = gload16(rp);
             float o[8], h[8];

@@ -930,7 +930,9 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::REPLAY: launch_replay(o.f, s, o.cls == KC_CACHE_HIT_STEP); break;
       case Op<T>::PATCH: {
         const T* src = o.call_latents ? (const T*)call_latents : (const T*)o.p0;
-        hipLaunchKernelGGL((patch_embed_kernel<T, 4, 2>), dim3(Hl / P, Bt), dim3(128), CIN * P * Wl * sizeof(float), s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
+        static const bool rows = getenv("ECAD_PATCH") && strcmp(getenv("ECAD_PATCH"), "rows") == 0;  // the earlier row-of-patches kernel
+        if (rows) hipLaunchKernelGGL((patch_embed_kernel<T, 4, 2>), dim3(Hl / P, Bt), dim3(128), CIN * P * Wl * sizeof(float), s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
+        else hipLaunchKernelGGL((patch_embed_cols_kernel<T, 256>), dim3(D / 128, Bt * ((N + 255) / 256)), dim3(256), 0, s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
         break;
       }
       case Op<T>::SINUS: {

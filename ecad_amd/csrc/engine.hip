@@ -88,7 +88,7 @@ struct EngineBase {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Op {
-  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE, COMB } kind;
   int cls = KC_MISC;
   int epi = 0;
   GemmArgs<T> g{};
@@ -150,6 +150,9 @@ template <typename T> class EngineT : public EngineBase {
   size_t ws_bytes = 0;
   T *h, *xn, *qkv, *attn_o, *qc, *ffmid, *ctx_mid, *ctx, *kv2, *cache, *proj, *model_in, *noise, *enc_buf;
   T *tsin, *temb1, *temb, *temb_silu, *mod_all;
+  T* comb = nullptr;  // [max_steps][L][4][D]: LN shift / scale of every (step, block) of a shared-timestep plan (comb_mod_kernel)
+  bool comb_live = false;
+  bool use_comb = true;  // env ECAD_LN_COMB=0: LN reads table + modulation separately (fp32 sum), as the per-step plans do
   float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
   uint8_t* mask_buf;
   SrcDesc* desc_dev = nullptr;
@@ -222,6 +225,7 @@ template <typename T> class EngineT : public EngineBase {
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
+    if (const char* l = getenv("ECAD_LN_COMB")) use_comb = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) attn_shared = strcmp(at, "generic") != 0;
@@ -336,6 +340,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t o_bias = take(Mt * sizeof(float)), o_x0 = take(lat * sizeof(float)), o_lat = take(lat * sizeof(float));
     const size_t o_ts = take(trows * sizeof(float)), o_coef = take(max_steps * 8 * sizeof(float)), o_mask = take(Mt);
     const size_t o_cond = take(Bm * 3 * sizeof(float)), o_szemb = take(Bm * d * sizeof(T));
+    const size_t o_comb = take(max_steps * (size_t)L * 4 * d * sizeof(T));
     ws_bytes = off;
     HIPCHK(hipMalloc((void**)&ws, ws_bytes));
     HIPCHK(hipMemset(ws, 0, ws_bytes));
@@ -346,6 +351,7 @@ template <typename T> class EngineT : public EngineBase {
     bias_buf = (float*)(ws + o_bias); x0_prev = (float*)(ws + o_x0); lat_buf = (float*)(ws + o_lat); ts_dev = (float*)(ws + o_ts);
     coef_dev = (float*)(ws + o_coef); mask_buf = (uint8_t*)(ws + o_mask);
     cond_dev = (float*)(ws + o_cond); size_emb = (T*)(ws + o_szemb);
+    comb = (T*)(ws + o_comb);
     st.workspace_bytes = (int64_t)ws_bytes;
     st.cache_arena_bytes = (int64_t)((size_t)L * 3 * M * d * sizeof(T));
 
@@ -559,12 +565,13 @@ template <typename T> class EngineT : public EngineBase {
   bool cache_write_live(int s, int b, int c) const { return s + 1 < steps && !executed[((size_t)(s + 1) * L + b) * 3 + c]; }
 
   void emit_ln(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, const float* tsh, const float* tsc, const T* msh, const T* msc, int64_t ln_stride, int64_t mstride,
-               bool feeds_fp8 = false) {
+               bool feeds_fp8 = false, const T* csh = nullptr, const T* csc = nullptr) {
     if (pend.size() > 6) emit_replay(ops, pend, M, mstride);
     Op<T> o;
     o.kind = Op<T>::LN; o.cls = KC_LN;
     o.f.h = h; o.f.y = xn; o.f.srcs = nullptr; o.f.n_src = (int)pend.size(); o.f.M = M; o.f.D = D; o.f.mod_stride = mstride; o.f.ln_mod_stride = ln_stride;
     o.f.rows_per_batch = N; o.f.table_shift = tsh; o.f.table_scale = tsc; o.f.mod_shift = msh; o.f.mod_scale = msc; o.f.eps = cfg.norm_eps;
+    o.f.comb_shift = csh; o.f.comb_scale = csc;
     if (!pend.empty()) {
       o.desc_off = (int)desc_host.size();
       for (auto& p : pend) desc_host.push_back(SrcDesc{p.cache, p.gate_table, p.gate_mod});
@@ -608,12 +615,13 @@ template <typename T> class EngineT : public EngineBase {
     for (int b = 0; b < L; ++b) {
       const Blk& B = blk[b];
       const uint8_t* ex = &executed[((size_t)s * L + b) * 3];
+      const T* cb = comb_live && !bind_call ? comb + ((size_t)s * L + b) * 4 * D : nullptr;  // shared-timestep (run) plan only
       T* c0 = cache + ((size_t)b * 3 + 0) * slot;
       T* c1 = cache + ((size_t)b * 3 + 1) * slot;
       T* c2 = cache + ((size_t)b * 3 + 2) * slot;
       // --- attn1
       if (ex[0]) {
-        emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, true);
+        emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, true, cb ? cb + 0 * D : nullptr, cb ? cb + 1 * D : nullptr);
         if (split_qkv && (2 * D) % G2_BN == 0) {
           // Q columns on 256x144 tiles (256 tiles) + K,V columns on 256x288 tiles (256 tiles): the wide tiles move 32 % fewer
           // L2->LDS bytes per flop, and both launches fill the chip exactly once
@@ -651,7 +659,7 @@ template <typename T> class EngineT : public EngineBase {
       }
       // --- ff
       if (ex[2]) {
-        emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride, true);
+        emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride, true, cb ? cb + 2 * D : nullptr, cb ? cb + 3 * D : nullptr);
         push_gemm(ops, mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D), true);
         push_gemm(ops, mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, cache_write_live(s, b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
         if (cache_write_live(s, b, 2)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
@@ -720,6 +728,8 @@ template <typename T> class EngineT : public EngineBase {
     EcadStats keep = st;
     plan_run = plan_begin;
     emit_temb(plan_run, ts_dev, steps, 0, false);
+    comb_live = use_comb && ln16 && D == 1152 && (L < 2 || blk[1].sst - blk[0].sst == (blk[L - 1].sst - blk[0].sst) / (L - 1));
+    if (comb_live) { Op<T> c; c.kind = Op<T>::COMB; c.cls = KC_MISC; plan_run.push_back(c); }
     { Op<T> d; d.kind = Op<T>::DUP; d.cls = KC_MISC; plan_run.push_back(d); }
     for (int s = 0; s < steps; ++s) {
       emit_transformer(plan_run, s, mod_all + (size_t)s * 6 * D, 0, temb + (size_t)s * D, 0, false);
@@ -946,6 +956,9 @@ template <typename T> class EngineT : public EngineBase {
                            w_sz2[1], b_sz2[1], size_emb, D / 3);
         break;
       case Op<T>::ADDSIZE: hipLaunchKernelGGL((add_size_emb_kernel<T>), dim3(o.i0), dim3(256), 0, s, (T*)o.p2, (const T*)size_emb, D, o.i1); break;
+      case Op<T>::COMB:
+        hipLaunchKernelGGL((comb_mod_kernel<T>), dim3(steps, L), dim3(256), 0, s, blk[0].sst, (int64_t)(L > 1 ? blk[1].sst - blk[0].sst : 0), (const T*)mod_all, comb, L, D);
+        break;
       case Op<T>::MASKBIAS: hipLaunchKernelGGL(mask_bias_kernel, dim3((o.i0 + 255) / 256), dim3(256), 0, s, (const uint8_t*)o.p0, (float*)o.p2, o.i0); break;
       case Op<T>::UNPATCH: {
         T* dst = o.call_out ? (T*)call_out : (T*)o.p2;

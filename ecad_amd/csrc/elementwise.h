@@ -244,7 +244,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const FlushArgs p) {
 
 // ---- same operation, 16 lanes per row (CPL = D / 128 chunks of 16 bytes per lane, every lane busy: D = 1152 -> 9), so a wave carries 4
 // rows with CPL independent loads in flight per lane and the reductions are 4 shuffle steps instead of 6.
-template <typename T, int CPL>
+// COMB: shift / scale come pre-summed (FlushArgs::comb_*), 32 bytes of modulation per 16-byte chunk instead of 96 -- the loads are L1 / L2
+// hits, but the pass is bound by L1 traffic.  A template parameter, not a run-time branch: a branch inside the chunk loop keeps hipcc from
+// batching the loads of the 9 chunks (11.7 -> 19.9 us per launch when it was one).
+template <typename T, int CPL, bool COMB = false>
 __global__ __launch_bounds__(256) void ln_modulate16_kernel(const FlushArgs p) {
   const int l16 = threadIdx.x & 15;
   const int stride = gridDim.x * 16;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void ln_modulate16_kernel(const FlushArgs p) {
       const int c = l16 + 16 * i;
       float sh[8], sc[8];
       f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, u0 = t0, u1 = t0;
-      if (p.comb_shift) {  // 32 bytes of modulation per 16-byte chunk instead of 96 (the loads are L1 / L2 hits, but the LN pass is bound by L1 traffic)
+      if (COMB) {
         unpack8<T>(gload16(reinterpret_cast<const T*>(p.comb_shift) + c * 8), sh);
         unpack8<T>(gload16(reinterpret_cast<const T*>(p.comb_scale) + c * 8), sc);
       } else {

@@ -885,7 +885,9 @@ template <typename T> class EngineT : public EngineBase {
     const int grid = (f.M + 3) / 4;
     if (f.D % 8) return fail(ECAD_E_INVALID, "D %% 8 != 0");
     if (ln16 && f.D == 1152) {  // 16 lanes per row, 9 chunks per lane
-      hipLaunchKernelGGL((ln_modulate16_kernel<T, 9>), dim3(((f.M + 15) / 16 + ln16 - 1) / ln16), dim3(256), 0, s, f);  // ln16 rows per 16-lane group
+      const dim3 g16(((f.M + 15) / 16 + ln16 - 1) / ln16);  // ln16 rows per 16-lane group
+      if (f.comb_shift) hipLaunchKernelGGL((ln_modulate16_kernel<T, 9, true>), g16, dim3(256), 0, s, f);
+      else hipLaunchKernelGGL((ln_modulate16_kernel<T, 9, false>), g16, dim3(256), 0, s, f);
       return ECAD_OK;
     }
     if (cpr <= 64 * 3) hipLaunchKernelGGL((ln_modulate_kernel<T, 3>), dim3(grid), dim3(256), 0, s, f);

@@ -238,6 +238,29 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GemmArgs<T> p) {
     __builtin_amdgcn_s_barrier();
     // ---- epilogue: two 32-row halves through this wave's private slab of the stage just consumed
     T* slab = reinterpret_cast<T*>(smem + last_stage * PG_STAGE_BYTES) + wave * 32 * PG_CS;
+    // gate vector of a tile that lies inside one sample (always for 256 / 4096 tokens): fetched once per tile by lanes 0 .. 17 into this
+    // wave's private strip behind the four slabs, instead of three L1 loads next to every one of the 1152 output chunks of the wave
+    // (ablation: the per-chunk gate loads cost 0.8 ms of the 20.5 ms FF2 spends per alpha-256 batch)
+    float* gwave = reinterpret_cast<float*>(smem + last_stage * PG_STAGE_BYTES + 4 * 32 * PG_CS * sizeof(T)) + wave * PG_BN;
+    bool gate_lds = false;
+    if (EPI == EPI_BIAS_CACHE_RESID && p.gate_table) {
+      const int m_last = (m0 + PG_BM <= p.M ? m0 + PG_BM : p.M) - 1;
+      gate_lds = m0 / p.rows_per_batch == m_last / p.rows_per_batch;
+      if (gate_lds && lane < PG_BN / 8) {
+        const int n = n0 + lane * 8;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
+        float gs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if (p.gate_mod) {
+          float gm[8];
+          unpack8<T>(gload16(p.gate_mod + (size_t)(m0 / p.rows_per_batch) * p.gate_mod_stride + n), gm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gs[e] += gm[e];
+        }
+        *reinterpret_cast<f32x4*>(gwave + lane * 8) = (f32x4){gs[0], gs[1], gs[2], gs[3]};
+        *reinterpret_cast<f32x4*>(gwave + lane * 8 + 4) = (f32x4){gs[4], gs[5], gs[6], gs[7]};
+      }
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -276,7 +299,11 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GemmArgs<T> p) {
             float o[8], h[8];
             unpack8<T>(v, o);
             unpack8<T>(hv, h);
-            if (p.gate_table) {
+            if (gate_lds) {
+              const f32x4 g0 = *reinterpret_cast<const f32x4*>(gwave + cchunk * 8), g1 = *reinterpret_cast<const f32x4*>(gwave + cchunk * 8 + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { h[e] += g0[e] * o[e]; h[4 + e] += g1[e] * o[4 + e]; }
+            } else if (p.gate_table) {
               const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
               const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
               float gt[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};

@@ -207,6 +207,57 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   // ---- epilogue 2: wave w streams rows 32w .. 32w+31 in 16-byte chunks
   constexpr int CPR = BN / 8;
   constexpr int CHUNKS = 32 * CPR;
+  if (EPI == FEPI_BIAS_GATE_RESID) {
+#ifndef FG_EPI_SERIAL
+    // 64 % CPR == 0: a lane keeps its column chunk for all its rows.  All hidden-state chunks of the wave's 32 rows are requested in
+    // one batch (inside a loop each load would wait behind the previous row's store to the same buffer), and the gate of a strip that
+    // lies in one sample and segment is fetched once per lane instead of once per chunk.
+    constexpr int NIT = CHUNKS / 64, RSTEP = 64 / CPR;
+    const int cchunk = lane % CPR, rl0 = lane / CPR;
+    const int n = n0 + cchunk * 8;
+    const int mw = m0 + wave * 32;
+    Pack8 hpre[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int m = mw + rl0 + it * RSTEP;
+      m = m < p.M ? m : p.M - 1;
+      hpre[it] = gload16(p.resid + (size_t)m * p.ldr + n);
+    }
+    const int m_last = (mw + 31 < p.M ? mw + 31 : p.M - 1);
+    const int b_first = seg_batch(mw < p.M ? mw : p.M - 1, p.seg0, p.rows_per_batch0, p.rows_per_batch1);
+    const bool uni = p.gate && (mw < p.seg0) == (m_last < p.seg0) && b_first == seg_batch(m_last, p.seg0, p.rows_per_batch0, p.rows_per_batch1);
+    float gu[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (uni) unpack8<T>(gload16(p.gate + (size_t)b_first * p.gate_stride + n), gu);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int rl = rl0 + it * RSTEP;
+      const int ml = wave * 32 + rl;
+      const int m = m0 + ml;
+      if (m >= p.M) continue;
+      Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+      if (p.C) gstore16(p.C + (size_t)m * p.ldc + n, v);
+      float o[8], h[8];
+      unpack8<T>(v, o);
+      unpack8<T>(hpre[it], h);
+      if (p.gate) {
+        float gm[8];
+        if (uni) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gm[e] = gu[e];
+        } else {
+          unpack8<T>(gload16(p.gate + (size_t)seg_batch(m, p.seg0, p.rows_per_batch0, p.rows_per_batch1) * p.gate_stride + n), gm);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += round_elem<T>(gm[e] * o[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += o[e];
+      }
+      gstore16(p.resid + (size_t)m * p.ldr + n, pack8<T>(h));
+    }
+    return;
+#endif
+  }
   for (int id = lane; id < CHUNKS; id += 64) {
     const int rl = id / CPR, cchunk = id - rl * CPR;
     const int ml = wave * 32 + rl;

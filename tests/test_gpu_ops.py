@@ -93,11 +93,12 @@ def test_ln_modulate(dtype_name):
     assert rel_l2(y, n * (1 + sc) + sh) < TOL[dtype_name]
 
 
-@pytest.mark.parametrize("n_src", [1, 3, 9, 84])
-def test_cache_accumulate(n_src):
-    """h += sum gate_i * C_i; gate-less sources mimic attn2 (cached_transformer_block.py:289)."""
+@pytest.mark.parametrize("n_src,B,Ntok", [(1, 2, 256), (3, 2, 256), (9, 2, 256), (84, 2, 256), (5, 3, 6), (7, 1, 1022)])
+def test_cache_accumulate(n_src, B, Ntok):
+    """h += sum gate_i * C_i; gate-less sources mimic attn2 (cached_transformer_block.py:289).  Token counts divisible by 4 take the
+    4-rows-per-thread kernel, ragged ones (6, 1022 tokens per sample) the one-chunk-per-thread kernel."""
     eng = small_engine("float16")
-    B, Ntok, D = 2, 256, 1152
+    D = 1152
     M = B * Ntok
     h0 = _r((M, D), torch.float16, 1.0, 1)
     srcs = [_r((M, D), torch.float16, 0.2, 10 + i) for i in range(n_src)]

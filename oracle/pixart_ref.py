@@ -115,13 +115,17 @@ def make_weights(cfg: PixArtConfig, seed: int = 0, std: float = 0.02, bias_std: 
 # --------------------------------------------------------------------------
 # embeddings  (diffusers.models.embeddings [ext])
 # --------------------------------------------------------------------------
-def sincos_pos_embed_2d(embed_dim: int, grid_size: int, base_size: int, interpolation_scale: float = 1.0) -> torch.Tensor:
-    """get_2d_sincos_pos_embed [ext]: fp32 [grid*grid, embed_dim].
+def sincos_pos_embed_2d(embed_dim: int, grid_size, base_size: int, interpolation_scale: float = 1.0) -> torch.Tensor:
+    """get_2d_sincos_pos_embed [ext]: fp32 [grid_h*grid_w, embed_dim]; ``grid_size`` an int or (grid_h, grid_w) -- PatchEmbed.forward [ext]
+    rebuilds the table with the actual (height, width) grid when the latent is not the checkpoint's sample size, each axis scaled by its own
+    ``grid / base_size``.
 
     First half of the channels encodes the column index, second half the row
     index (the meshgrid(w, h) quirk of the original MAE code).
     """
-    coords = np.arange(grid_size, dtype=np.float32) / (grid_size / base_size) / interpolation_scale
+    gh, gw = (grid_size, grid_size) if isinstance(grid_size, int) else grid_size
+    coords_h = np.arange(gh, dtype=np.float32) / (gh / base_size) / interpolation_scale
+    coords_w = np.arange(gw, dtype=np.float32) / (gw / base_size) / interpolation_scale
 
     def one_d(dim: int, pos: np.ndarray) -> np.ndarray:
         omega = np.arange(dim // 2, dtype=np.float64)
@@ -130,8 +134,8 @@ def sincos_pos_embed_2d(embed_dim: int, grid_size: int, base_size: int, interpol
         out = np.einsum("m,d->md", pos.reshape(-1).astype(np.float64), omega)
         return np.concatenate([np.sin(out), np.cos(out)], axis=1)
 
-    col = np.tile(coords[None, :], (grid_size, 1))  # [i, j] -> coords[j]
-    row = np.tile(coords[:, None], (1, grid_size))  # [i, j] -> coords[i]
+    col = np.tile(coords_w[None, :], (gh, 1))  # [i, j] -> coords_w[j]
+    row = np.tile(coords_h[:, None], (1, gw))  # [i, j] -> coords_h[i]
     emb = np.concatenate([one_d(embed_dim // 2, col), one_d(embed_dim // 2, row)], axis=1)
     return torch.from_numpy(emb).float()
 
@@ -168,6 +172,8 @@ class PixArtOracle:
         grid = cfg.sample_size // cfg.patch_size
         interp = cfg.interpolation_scale if cfg.interpolation_scale is not None else max(cfg.sample_size // 64, 1)
         self.pos_embed = sincos_pos_embed_2d(cfg.dim, grid, base_size=cfg.sample_size // cfg.patch_size, interpolation_scale=interp)
+        self._pos_cache = {(grid, grid): self.pos_embed}
+        self._interp = interp
         self.cache = CacheState()
 
     # -- helpers ---------------------------------------------------------
@@ -183,8 +189,11 @@ class PixArtOracle:
     # -- _process_input pieces (pixart_transformer_2d_edited.py:293-330) ---
     def patch_embed(self, latents: torch.Tensor) -> torch.Tensor:
         x = F.conv2d(latents.float(), self.w["pos_embed.proj.weight"], self.w["pos_embed.proj.bias"], stride=self.cfg.patch_size)
+        gh, gw = x.shape[-2], x.shape[-1]
         x = x.flatten(2).transpose(1, 2)  # [B, N, D], token = row*W + col
-        return self.q(x + self.pos_embed[None])
+        if (gh, gw) not in self._pos_cache:  # PatchEmbed.forward [ext]: table rebuilt for the actual grid
+            self._pos_cache[(gh, gw)] = sincos_pos_embed_2d(self.cfg.dim, (gh, gw), base_size=self.cfg.sample_size // self.cfg.patch_size, interpolation_scale=self._interp)
+        return self.q(x + self._pos_cache[(gh, gw)][None])
 
     def _timestep_mlp(self, values: torch.Tensor, prefix: str) -> torch.Tensor:
         """TimestepEmbedding(256 -> width) on Timesteps(256) of ``values`` [ext]."""
@@ -272,19 +281,21 @@ class PixArtOracle:
         ctx = self.caption_projection(self.q(enc.float()))
         for i in range(cfg.num_layers):
             h = self.block(i, step, step_flags[i], h, ctx, enc_bias, mod)
-        return self.create_output(h, embedded)
+        return self.create_output(h, embedded, latents.shape[-2] // cfg.patch_size, latents.shape[-1] // cfg.patch_size)
 
-    def create_output(self, h, embedded):  # :332-376
+    def create_output(self, h, embedded, gh: int | None = None, gw: int | None = None):  # :332-376; (height, width) of the token grid from :301-304
         cfg = self.cfg
         tbl = self.w["scale_shift_table"][None] + embedded[:, None]
         shift, scale = tbl.chunk(2, dim=1)
         h = self.q(self.layer_norm(h) * (1 + scale) + shift)
         h = self.lin(h, "proj_out")
         B = h.shape[0]
-        g, p, c = cfg.sample_size // cfg.patch_size, cfg.patch_size, cfg.out_channels
-        h = h.reshape(B, g, g, p, p, c)
+        p, c = cfg.patch_size, cfg.out_channels
+        gh = gh if gh is not None else cfg.sample_size // p
+        gw = gw if gw is not None else cfg.sample_size // p
+        h = h.reshape(B, gh, gw, p, p, c)
         h = torch.einsum("nhwpqc->nchpwq", h)
-        return h.reshape(B, c, g * p, g * p)
+        return h.reshape(B, c, gh * p, gw * p)
 
     def reset_cache(self) -> None:
         self.cache.reset()

@@ -311,3 +311,36 @@ def test_micro_conditioning_step_and_loop_parity():
     # engine counts layers=2 blocks; the closed form is for the same block count because `bits` has that many
     assert st["linear_macs_reference"] == int(per_step.sum())
     eng.close()
+
+
+def test_ragged_geometry_step_parity():
+    """Shapes nothing is tuned for: odd transformer batch (3), non-square latent 16 x 48 (192 tokens per sample: GEMM row tiles straddle
+    samples, so the per-tile gate shortcut must fall back), 77 text tokens with ragged masks including one sample with every token masked
+    (softmax over equal -10000 biases, as the reference computes it)."""
+    from ecad_amd.engine import EcadEngine
+
+    layers, steps, Bt, H, W, T = 2, 4, 3, 16, 48, 77
+    bits = rand_bits(steps, layers, 0.5, seed=21)
+    cfg = PixArtConfig(num_layers=layers)
+    w = make_weights(cfg, seed=6)
+    eng = EcadEngine(num_layers=layers, max_batch=4, max_tokens=256, max_text_tokens=120)
+    eng.load_state_dict(w)
+    eng.set_schedule(bits)
+    g = torch.Generator().manual_seed(8)
+    enc = torch.randn(Bt, T, 4096, generator=g) * 0.1
+    mask = torch.zeros(Bt, T, dtype=torch.int64)
+    mask[0, :T] = 1
+    mask[1, :5] = 1  # sample 2 stays fully masked
+    eng.begin_image_batch(enc.cuda(), mask.cuda(), H, W)
+    ref = PixArtOracle(cfg, w)
+    worst = 0.0
+    for s in range(steps):
+        x = torch.randn(Bt, 4, H, W, generator=g)
+        t = torch.tensor([950.0, 420.0, 77.0]) - 10.0 * s
+        out = eng.step(s, x.cuda(), t.cuda())
+        assert out.shape == (Bt, 8, H, W)
+        exp = ref.forward(x.half().float(), enc.half().float(), mask, t, s, bits[s])
+        worst = max(worst, rel_l2(out, exp))
+    print(f"ragged geometry worst per-step rel-L2: {worst:.3e}")
+    assert worst < 4e-3
+    eng.close()

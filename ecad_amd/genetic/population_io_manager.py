@@ -22,6 +22,7 @@ from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCach
 
 class PixArtPopulationIOManager:
     CONFIG_FILENAME = "manager_config.json"
+    CHECKPOINT_FILENAME = "checkpoint.pkl"  # reference: population_io_manager.py:27,116-145 (dill dump of the algorithm, per generation dir)
     SCORE_KEY = "total_score"
     METRIC_KEY = "total_macs_T"
 
@@ -123,6 +124,28 @@ class PixArtPopulationIOManager:
     def get_constraint_violations(self, population: np.ndarray) -> np.ndarray:
         diff = np.sum(np.asarray(population, dtype=np.bool_) != self.default_bits[None], axis=1)
         return (self.min_diff_from_default - diff).reshape(-1, 1)
+
+    # -- algorithm checkpoint (resume a search where it stopped) -----------------------------------
+    def save_algorithm(self, algorithm: Any) -> None:
+        n_gen = getattr(algorithm, "n_gen", None)
+        if n_gen is not None:  # the algorithm's generation counter is the authority
+            self.generation_num = n_gen
+        import dill
+
+        target = self._gen_dir() / self.CHECKPOINT_FILENAME
+        with open(target, "wb") as f:
+            dill.dump(algorithm, f)
+        print(f"algorithm checkpoint -> {target}")
+
+    def load_algorithm(self, generation: int | None = None) -> Any:
+        """FileNotFoundError when the generation has no checkpoint: callers start from the seed population then."""
+        import dill
+
+        source = self._gen_dir(generation) / self.CHECKPOINT_FILENAME
+        with open(source, "rb") as f:
+            algorithm = dill.load(f)
+        print(f"algorithm checkpoint <- {source} (generation {algorithm.n_gen})")
+        return algorithm
 
     # -- evaluation results -------------------------------------------------------------------
     def write_evaluation(self, index: int, score: float, bits: np.ndarray, generation: int | None = None) -> None:

@@ -160,3 +160,105 @@ def test_flux_population_manager_contract(tmp_path):
     mgr.to_json()
     again = FluxPopulationIOManager.from_json(tmp_path / "p/kat/gen_001/manager_config.json")
     assert again.to_dict() == mgr.to_dict()
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference-named single-GPU entry point: command line, cycle, checkpoint / resume
+# ---------------------------------------------------------------------------------------------
+# flags of ecad/genetic/train_nsga2_base.py:43-163 (get_base_argparser) + train_nsga2_single_gpu.py:256-260, with their defaults
+REFERENCE_FLAGS = {
+    "image_generator": None, "load_from": None, "name": None, "num_cycles": "1", "print_not_submit": False, "embedding_dir": None, "generation_num": None,
+    "num_inference_steps": 20, "benchmark_prompts": None, "file_mode": None, "image_naming_mode": None, "min_diff_from_default": 1, "population_size": 72,
+    "batch_size": 100, "num_images_per_prompt": 10, "exactly_n_images": 1000, "regen_if_not_n_images": 1000, "maximize_MACs": False, "print_eval_outputs": False,
+}
+
+
+def _stub_score(_index, bits):
+    """Deterministic stand-in for the GPU scorer: prefers recomputing early steps (so the two objectives trade off)."""
+    w = np.linspace(1.0, 0.1, bits.shape[0])[:, None, None]
+    return float((bits * w).sum() / w.sum() / bits[0].size) - 1.0
+
+
+def test_single_gpu_trainer_command_line_is_the_references(tmp_path):
+    from ecad_amd.genetic import train_nsga2_single_gpu as T
+
+    args = T.parse_args(["--image-generator", "PixArtAlphaImageGenerator", "--name", "x"])
+    got = vars(args)
+    for flag, default in REFERENCE_FLAGS.items():
+        if flag in ("image_generator", "name"):
+            continue
+        assert flag in got, flag
+        assert got[flag] == (1 if flag == "num_cycles" else default), flag  # validate_base_args turns "1" into 1
+    assert got["all_populations_dir"].parts[-3:] == ("results", "genetic", "populations")
+    assert got["all_benchmarks_dir"].parts[-4:] == ("results", "benchmark", "genetic", "populations")
+    assert T.get_offline_eval_kwargs(args).keys() == {"embedding_dir", "num_images_per_prompt", "exactly_n_images", "regen_if_not_n_images", "benchmark_prompts",
+                                                      "file_mode", "image_naming_mode"}
+    assert T.parse_args(["--name", "x", "--num-cycles", "inf"]).num_cycles == "inf"
+    with pytest.raises(ValueError, match="name or path"):
+        T.parse_args([])
+    with pytest.raises(ValueError, match="integer or 'inf'"):
+        T.parse_args(["--name", "x", "--num-cycles", "many"])
+    with pytest.raises(ValueError, match="print-not-submit"):
+        T.parse_args(["--name", "x", "--num-cycles", "3", "--print-not-submit"])
+    with pytest.raises(SystemExit):  # argparse: not a registered generator
+        T.parse_args(["--name", "x", "--image-generator", "NoSuchGenerator"])
+
+
+def test_single_gpu_trainer_cycle_checkpoint_and_resume(tmp_path, capsys):
+    """Three cycles in one go == one cycle, a fresh process state (manager and algorithm restored from gen_XXX/manager_config.json +
+    checkpoint.pkl), two more cycles: same candidates, same files.  Evaluation is the injected stub (the GPU scorer is exercised by the
+    multi-GPU trainer's tests); every other line is the shipped loop."""
+    from ecad_amd.genetic import train_nsga2_single_gpu as T
+    from ecad_amd.genetic.population_io_manager import PixArtPopulationIOManager
+
+    seed = np.unpackbits(np.load(GOLD / "ga_seed_population.npz")["bits"], axis=1)[:8, :1680].astype(bool)
+
+    def common(root):
+        return ["--image-generator", "PixArtAlphaImageGenerator", "--all-populations-dir", str(root / "p"), "--all-benchmarks-dir", str(root / "b"), "--population-size", "8"]
+
+    def seeded(root):
+        PixArtPopulationIOManager("run", root / "p", root / "b", generation_num=0, population_size=8).save_population(seed, 0)
+
+    # no seed population and nobody to ask: the reference's ValueError
+    with pytest.raises(ValueError, match="No initial population found"):
+        T.run(T.parse_args(common(tmp_path / "none") + ["--name", "run"]), score_fn=_stub_score, allow_random_seed_population=False)
+
+    # --- uninterrupted
+    a = tmp_path / "a"
+    seeded(a)
+    mgr_a, algo_a = T.run(T.parse_args(common(a) + ["--name", "run", "--num-cycles", "3"]), score_fn=_stub_score)
+    assert mgr_a.generation_num == algo_a.n_gen == 4  # generations 1..3 evaluated and told, generation 4 written and waiting
+    assert (a / "p/run/gen_004/checkpoint.pkl").exists() and (a / "p/run/gen_004/manager_config.json").exists()
+    assert np.array_equal(mgr_a.load_population_vectors(1), seed)  # generation 1 is the seed population (train_nsga2_base.py:236-250)
+    assert mgr_a.check_offline_eval() is False and len(list((a / "p/run/gen_004/candidates").glob("cand_*.json"))) == 8
+    scores = json.loads((a / "b/run/gen_003/candidates/cand_000/scores.json").read_text())
+    cand = json.loads((a / "p/run/gen_003/candidates/cand_000.json").read_text())
+    assert set(scores) == {"total_score"} and "total_macs_T" in cand["metrics"] and cand["cache_schedule"]["num_blocks"] == 28
+
+    # --- interrupted after one cycle, resumed from the files alone
+    b = tmp_path / "b"
+    seeded(b)
+    T.run(T.parse_args(common(b) + ["--name", "run", "--num-cycles", "1"]), score_fn=_stub_score)
+    capsys.readouterr()
+    mgr_b, algo_b = T.run(T.parse_args(common(b) + ["--load-from", str(b / "p/run/gen_002/manager_config.json"), "--num-cycles", "2"]), score_fn=_stub_score)
+    assert "algorithm checkpoint <-" in capsys.readouterr().out
+    assert mgr_b.generation_num == 4
+    for g in (2, 3, 4):
+        assert np.array_equal(mgr_a.load_population_vectors(g), mgr_b.load_population_vectors(g)), g
+    assert np.array_equal(algo_a.F, algo_b.F) and np.array_equal(algo_a.X, algo_b.X)
+    # survivors are non-dominated-sorted on (1 - score, TMACs): the all-recompute-ish end and the cheap end both survive
+    assert algo_a.F[:, 1].min() < algo_a.F[:, 1].max()
+
+    # --- resumed on a generation that already has its scores: advance first, then evaluate the new generation (one of each per cycle)
+    calls = []
+    T.InProcessEvaluator("PixArtAlphaImageGenerator", score_fn=_stub_score)(mgr_b)  # evaluate generation 4 out of band
+    mgr_c, _ = T.run(T.parse_args(common(b) + ["--load-from", str(b / "p/run/gen_004/manager_config.json"), "--num-cycles", "1"]),
+                     score_fn=lambda i, bits: calls.append(i) or _stub_score(i, bits))
+    assert calls == list(range(8)) and mgr_c.generation_num == 5 and mgr_c.check_offline_eval()
+    assert not (b / "p/run/gen_006").exists()
+
+    # --- --print-not-submit describes the evaluation of the generation it just wrote and leaves the benchmark directory alone
+    T.run(T.parse_args(common(b) + ["--load-from", str(b / "p/run/gen_005/manager_config.json"), "--print-not-submit"]), score_fn=_stub_score)
+    out = capsys.readouterr().out
+    assert "generation 6: 8 candidate schedule(s)" in out and "stand-in for ImageReward" in out
+    assert (b / "p/run/gen_006/candidates/cand_000.json").exists() and not (b / "b/run/gen_006").exists()

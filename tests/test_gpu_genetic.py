@@ -1,0 +1,64 @@
+"""-m gpu: the NSGA-II harness with the real in-process evaluator (one resident engine, whole-loop graph replay per candidate) -- row f-4
+and the config-4 workload of SURVEY 8(d), at a population small enough for a test."""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = ROOT / "tests" / "golden"
+
+
+def _embedding_dir(root, n=2):
+    d = root / "emb"
+    d.mkdir()
+    g = torch.Generator().manual_seed(0)
+    for i in range(n):
+        mask = torch.zeros(1, 120, dtype=torch.int64)
+        mask[:, : 20 + 30 * i] = 1
+        neg_mask = torch.zeros(1, 120, dtype=torch.int64)
+        neg_mask[:, :2] = 1
+        torch.save({"prompt_embeds": torch.randn(1, 120, 4096, generator=g) * 0.1, "prompt_attention_mask": mask,
+                    "negative_prompt_embeds": torch.randn(1, 120, 4096, generator=g) * 0.1, "negative_prompt_attention_mask": neg_mask}, d / f"{i:03}__prompt_id:{i}.pt")
+    return d
+
+
+def test_single_gpu_trainer_real_evaluator(tmp_path):
+    from ecad_amd.benchmark.compute_macs import total_macs_T
+    from ecad_amd.genetic import train_nsga2_single_gpu as T
+    from ecad_amd.genetic.population_io_manager import PixArtPopulationIOManager
+
+    seed = np.unpackbits(np.load(GOLD / "ga_seed_population.npz")["bits"], axis=1)[:5, :1680].astype(bool)
+    seed = np.vstack([np.ones((1, 1680), dtype=bool), seed])  # candidate 0: the uncached schedule itself
+    PixArtPopulationIOManager("run", tmp_path / "p", tmp_path / "b", generation_num=0, population_size=6).save_population(seed, 0)
+    args = T.parse_args(["--image-generator", "PixArtAlphaImageGenerator", "--name", "run", "--all-populations-dir", str(tmp_path / "p"), "--all-benchmarks-dir",
+                         str(tmp_path / "b"), "--population-size", "6", "--embedding-dir", str(_embedding_dir(tmp_path)), "--batch-size", "2", "--num-images-per-prompt", "2",
+                         "--min-diff-from-default", "0", "--print-eval-outputs"])
+    mgr, algo = T.run(args)
+    assert mgr.generation_num == algo.n_gen == 2 and len(list((tmp_path / "p/run/gen_002/candidates").glob("cand_*.json"))) == 6
+    scores = [json.loads((tmp_path / f"b/run/gen_001/candidates/cand_{i:03d}/scores.json").read_text())["total_score"] for i in range(6)]
+    assert scores[0] == 0.0  # same schedule, same seeds, same graph: bit-identical latents
+    assert all(-1.0 < s < 0.0 for s in scores[1:])  # cached candidates drift from the uncached run, by less than its norm
+    for i in range(6):
+        m = json.loads((tmp_path / f"p/run/gen_001/candidates/cand_{i:03d}.json").read_text())["metrics"]["total_macs_T"]
+        assert m == total_macs_T(seed[i].reshape(20, 28, 3))
+    assert abs(algo.F[:, 1].max() - 5.71379613696) < 1e-9  # the uncached candidate survives with the reference's all-true TMACs
+
+
+def test_multi_gpu_trainer_one_rank(tmp_path, monkeypatch, capsys):
+    """train_nsga2_multi_gpu at world size 1 (the same code path every rank runs; the collectives degenerate to identities)."""
+    from ecad_amd.genetic import train_nsga2_multi_gpu as M
+
+    monkeypatch.setattr(sys, "argv", ["train_nsga2_multi_gpu", "--name", "mg", "--populations-dir", str(tmp_path / "p"), "--benchmarks-dir", str(tmp_path / "b"),
+                                      "--seed-population", str(GOLD / "ga_seed_population.npz"), "--population-size", "4", "--generations", "2", "--images", "2"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    M.main()
+    out = capsys.readouterr().out
+    assert "generation 2:" in out and "evaluated on 1 rank(s)" in out
+    assert len(list((tmp_path / "b/mg/gen_002/candidates").glob("cand_*/scores.json"))) == 4

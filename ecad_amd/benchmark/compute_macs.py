@@ -57,7 +57,17 @@ def flux_macs_per_step(bits_full: np.ndarray, bits_single: np.ndarray, tokens: i
     return batch * (overhead + (ef * cost_full[None, None, :]).sum(axis=(1, 2)) + (es * cost_single[None, None, :]).sum(axis=(1, 2)))
 
 
-def annotate_schedule_file(path: Path, recompute_existing: bool = False) -> bool:
+# geometry per checkpoint name, as the reference's WEIGHTS_TO_SHAPES table has it (compute_macs.py:22-39): latent side multiplier over 32 x 32
+# and whether the micro-conditioning embedders run (text length is 120 for all three there, SEQ_LEN :42)
+WEIGHTS_TO_GEOMETRY = {
+    "PixArt-alpha/PixArt-XL-2-256x256": dict(tokens=256, size_embedder_macs=0),
+    "PixArt-alpha/PixArt-Sigma-XL-2-256x256": dict(tokens=256, size_embedder_macs=0),
+    "PixArt-alpha/PixArt-XL-2-1024-MS": dict(tokens=4096, size_embedder_macs=3 * (256 * 384 + 384 * 384)),
+}
+DEFAULT_WEIGHTS = {"PixArtAlphaImageGenerator": "PixArt-alpha/PixArt-XL-2-256x256", "PixArtSigmaImageGenerator": "PixArt-alpha/PixArt-Sigma-XL-2-256x256"}
+
+
+def annotate_schedule_file(path: Path, recompute_existing: bool = False, image_generator: str | None = None, print_detailed: bool = False) -> bool:
     with open(path) as f:
         data = json.load(f)
     metrics = data.get("metrics", {}) or {}
@@ -71,7 +81,13 @@ def annotate_schedule_file(path: Path, recompute_existing: bool = False) -> bool
         per_step = flux_macs_per_step(*fs.to_device_bits(), tokens=(cfg.get("height", 256) // 16) * (cfg.get("width", 256) // 16))
     else:
         sched = PixArtCacheSchedule.from_json(path)
-        per_step = macs_per_step(sched.to_numpy())
+        weights = (sched.top_level_config or {}).get("transformer_weights") or DEFAULT_WEIGHTS.get(image_generator or "PixArtAlphaImageGenerator")
+        if weights not in WEIGHTS_TO_GEOMETRY:
+            raise ValueError(f"Shapes for weights {weights} not found.")
+        per_step = macs_per_step(sched.to_numpy(), **WEIGHTS_TO_GEOMETRY[weights])
+    if print_detailed:
+        for step, macs in enumerate(per_step):
+            print(f"  step {step:03}: {int(macs):>16d} MACs")
     metrics["by_inference_step"] = {f"{s:03}": {"macs": int(m)} for s, m in enumerate(per_step)}
     metrics["total_macs"] = int(per_step.sum())
     metrics["total_macs_T"] = float(per_step.sum()) / 1e12
@@ -81,14 +97,22 @@ def annotate_schedule_file(path: Path, recompute_existing: bool = False) -> bool
     return True
 
 
+def get_argparser() -> argparse.ArgumentParser:
+    """Flags of the reference's compute_macs.py (:371-397)."""
+    ap = argparse.ArgumentParser(description="Closed-form MACs for PixArt / FLUX cache schedules (writes the metrics block into each JSON).")
+    ap.add_argument("--image-generator", type=str, required=False, choices=["PixArtAlphaImageGenerator", "PixArtSigmaImageGenerator", "FluxImageGenerator"],
+                    help="model family for schedule files whose config block does not name the weights")
+    ap.add_argument("--input-dir", "-i", type=Path, required=True, help="schedule file or directory of schedule JSONs (searched recursively)")
+    ap.add_argument("--recompute-existing", action="store_true", help="also files that already carry metrics")
+    ap.add_argument("--print-detailed", action="store_true", help="print the MACs of every step")
+    return ap
+
+
 def main():
-    ap = argparse.ArgumentParser(description="Closed-form MACs for PixArt cache schedules (writes metrics into the JSON).")
-    ap.add_argument("--input-dir", type=Path, required=True, help="schedule file or directory of schedule JSONs")
-    ap.add_argument("--recompute-existing", action="store_true")
-    args = ap.parse_args()
+    args = get_argparser().parse_args()
     files = [args.input_dir] if args.input_dir.is_file() else sorted(args.input_dir.glob("**/*.json"))
     for f in files:
-        print(("updated " if annotate_schedule_file(f, args.recompute_existing) else "skipped ") + str(f))
+        print(("updated " if annotate_schedule_file(f, args.recompute_existing, args.image_generator, args.print_detailed) else "skipped ") + str(f))
 
 
 if __name__ == "__main__":

@@ -175,3 +175,27 @@ def test_vae_decoder_shapes_and_diffusers_key_names():
     assert 49e6 < n < 50e6  # SD VAE decoder + post_quant_conv ~49.5 M parameters
     img = vae.decode(torch.randn(1, 4, 8, 8))[0]
     assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()
+
+
+def test_compute_macs_cli_geometry_follows_the_weights(tmp_path, capsys):
+    """compute_macs.py picks the geometry from the schedule's transformer_weights as the reference's WEIGHTS_TO_SHAPES does (:22-39,66-70): the
+    1024-MS alpha file gets N = 4096 and the size embedders, i.e. exactly the reference's measured numbers; unknown weights are an error."""
+    import shutil
+
+    from ecad_amd.benchmark import compute_macs as CM
+
+    vec = json.loads((ROOT / "tests/golden/alpha1024_vectors.json").read_text())["alpha_cache_schedules/gen_default_1024x1024/default_1024x1024.json"]
+    f = tmp_path / "s.json"
+    shutil.copy(ROOT / "schedules/alpha_cache_schedules/gen_default_1024x1024/default_1024x1024.json", f)
+    assert CM.annotate_schedule_file(f) is False  # carries metrics already
+    assert CM.annotate_schedule_file(f, recompute_existing=True, print_detailed=True) is True
+    m = json.loads(f.read_text())["metrics"]
+    assert [m["by_inference_step"][f"{s:03}"]["macs"] for s in range(20)] == vec["macs"] and m["total_macs"] == vec["total_macs"]
+    assert "step 019:" in capsys.readouterr().out
+    d = json.loads(f.read_text())
+    d["config"]["transformer_weights"] = "someone/else"
+    f.write_text(json.dumps(d))
+    with pytest.raises(ValueError, match="Shapes for weights someone/else not found"):
+        CM.annotate_schedule_file(f, recompute_existing=True)
+    flags = {a.dest for a in CM.get_argparser()._actions}
+    assert {"image_generator", "input_dir", "recompute_existing", "print_detailed"} <= flags

@@ -143,16 +143,33 @@ ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
     if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INST + B_INST) : "memory");  // only the newest stage may still be in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading the stage about to be refilled
+    const char* abase = smem + stage * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+    // The first fragment set is requested BEFORE the next stage's DMA is issued, so its LDS latency hides behind the eight DMA issues instead
+    // of following them (plain GEMM, in-run A/B: 9216 x 9216 x 3072 940 -> 1018 TFLOP/s, 9216 x 3072 x 15360 1014 -> 1089, 8192^3 1200 ->
+    // 1266; issuing the DMA after half of the first MFMA group instead: equal or worse; consuming the second fragment set after the NEXT
+    // step's barrier so that the matrix pipe has work while the barrier resolves: +2..4 % at BN = 128, but 22 spilled VGPRs and -25 % at BN = 256).
+    Pack8 af0[FM], wf0[FN];
+    {
+      const int coff = (g ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + STAGES - 1 < nk) {
       int ns = stage + STAGES - 1;
       ns = ns >= STAGES ? ns - STAGES : ns;
       issue(ns);
     }
-    const char* abase = smem + stage * STAGE_BYTES;
-    const char* bbase = abase + A_BYTES;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int coff = ((kk * 4 + g) ^ swz) * 16;
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
+    {
+      const int coff = ((4 + g) ^ swz) * 16;
       Pack8 af[FM], wf[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);

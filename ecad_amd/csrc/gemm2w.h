@@ -91,9 +91,10 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     const int stage = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed (nothing else is in flight)
     __builtin_amdgcn_s_barrier();                      // tile kt complete; everyone is done reading the other stage
-    if (kt + 1 < nk) issue(stage ^ 1);
     const char* abase = smem + stage * G2_STAGE_BYTES;
     const char* bbase = abase + G2_A_BYTES;
+#ifdef G_LATE_READS
+    if (kt + 1 < nk) issue(stage ^ 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int coff = ((kk * 4 + g) ^ swz) * 16;
@@ -107,6 +108,36 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #pragma unroll
         for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
     }
+#else
+    // first fragment set requested before the next stage's DMA is issued: its LDS latency hides behind the DMA issues (fgemm.h has the numbers)
+    Pack8 af0[FM], wf0[FN];
+    {
+      const int coff = (g ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) issue(stage ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
+    {
+      const int coff = ((4 + g) ^ swz) * 16;
+      Pack8 af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+    }
+#endif
   }
   __syncthreads();
 

@@ -131,13 +131,14 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A_INST(4) + 2: oldest stage retired for every wave
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    const char* abase = smem + stage * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+#ifdef G_LATE_READS
     if (kt + 2 < nk) {
       int ns = stage + 2;
       ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
       issue(ns);
     }
-    const char* abase = smem + stage * STAGE_BYTES;
-    const char* bbase = abase + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int coff = ((kk * 4 + g) ^ swz) * 16;
@@ -151,6 +152,40 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
 #pragma unroll
         for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
     }
+#else
+    // first fragment set requested before the next stage's DMA is issued: its LDS latency hides behind the DMA issues (fgemm.h has the numbers)
+    Pack8 af0[FM], wf0[FN];
+    {
+      const int coff = (g ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk) {
+      int ns = stage + 2;
+      ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+      issue(ns);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
+    {
+      const int coff = ((4 + g) ^ swz) * 16;
+      Pack8 af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+    }
+#endif
     stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
   }
   __syncthreads();

@@ -127,6 +127,58 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   }
 #endif
   int stage = 0;
+#ifndef G3_NO_XBAR
+  // second fragment set of a step consumed after the NEXT step's barrier: the matrix pipe has a full group to chew on while the barrier
+  // resolves and the new stage's first fragments travel from LDS (11 more live fragment registers: fits this kernel's 72 accumulators;
+  // 244 VGPRs, no spills).  In-run A/B: Q -2.7 %, attn1-out -3.7 %, attn2-out -3.2 %, cross-Q -3.0 %.  -DG3_NO_XBAR: the plain loop below.
+  Pack8 afp[FM], wfp[FN];
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* abase = smem + stage * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+    Pack8 af0[FM], wf0[FN];
+    {
+      const int coff = (g ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk) {
+      int ns = stage + 2;
+      ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+      issue(ns);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt > 0) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wfp[j], afp[i], acc[i][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int coff = ((4 + g) ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) afp[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wfp[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
+    stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wfp[j], afp[i], acc[i][j]);
+#else
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A_INST(4) + 2: oldest stage retired for every wave
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -188,6 +240,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
 #endif
     stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
   }
+#endif
   __syncthreads();
   T* ctile = reinterpret_cast<T*>(smem);
 #pragma unroll

@@ -139,6 +139,68 @@ ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   issue(0);
   if (STAGES == 3 && nk > 1) issue(1);
   int stage = 0;
+#ifndef FG_NO_XBAR
+  // gemm2w.h's scheme: the last PN = 2 columns of a step's second fragment set are consumed after the NEXT barrier (8 MFMAs of pipe work
+  // while the barrier resolves).  FLUX-1024 in-run: single-stream QKV+MLP -1 %, proj_out -2.9 %, +0.6 % end to end.  The full set spills
+  // at BN = 256 (-25 %).  -DFG_NO_XBAR: the plain loop below.
+  constexpr int PN = 2;
+  Pack8 afp[FM], wfp[PN];
+  for (int kt = 0; kt < nk; ++kt) {
+    if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INST + B_INST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* abase = smem + stage * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+    Pack8 af0[FM], wf0[FN];
+    {
+      const int coff = (g ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + STAGES - 1 < nk) {
+      int ns = stage + STAGES - 1;
+      ns = ns >= STAGES ? ns - STAGES : ns;
+      issue(ns);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt > 0) {
+#pragma unroll
+      for (int j = 0; j < PN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][FN - PN + j] = mfma16<T>(wfp[j], afp[i], acc[i][FN - PN + j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
+    {
+      const int coff = ((4 + g) ^ swz) * 16;
+      Pack8 wf[FN - PN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) afp[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN - PN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < PN; ++j) wfp[j] = lds_read16(bbase + b_row_off + (FN - PN + j) * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < FN - PN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], afp[i], acc[i][j]);
+    }
+    stage = stage + 1 >= STAGES ? 0 : stage + 1;
+  }
+#pragma unroll
+  for (int j = 0; j < PN; ++j)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i][FN - PN + j] = mfma16<T>(wfp[j], afp[i], acc[i][FN - PN + j]);
+  __syncthreads();
+  return;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INST + B_INST) : "memory");  // only the newest stage may still be in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

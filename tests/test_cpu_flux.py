@@ -179,3 +179,27 @@ def test_flux_host_surface_without_gpu():
     assert 11.8e9 < n < 12.0e9  # FLUX.1-dev: 11.9 B parameters
     with pytest.raises(ValueError):
         get_image_generator_type("FluxImageGenerator")()  # CUDA is required (same hard check as the reference)
+
+
+def test_flow_match_schedule_and_euler_are_exact_on_straight_paths():
+    """Properties that do not depend on the source the restatement was written from: the shifted sigma grid starts at 1, falls strictly to
+    0 and equals exp(mu) / (exp(mu) + 1/s - 1) of the uniform grid; the Euler update x += (sigma' - sigma) * v integrates a rectified-flow
+    (straight) path x_sigma = (1 - sigma) x0 + sigma * eps exactly, for any grid, so a point-mass target is reached to rounding."""
+    import math
+
+    from ecad_amd.pipelines.flow_match import calculate_shift
+
+    for n_tok in (256, 1024, 4096):
+        sig = flux_ref.flow_match_sigmas(20, n_tok).astype(np.float64)
+        assert sig[0] == 1.0 and sig[-1] == 0.0 and np.all(np.diff(sig) < 0)
+        mu = calculate_shift(n_tok)
+        uniform = np.linspace(1.0, 1.0 / 20, 20)
+        assert np.allclose(sig[:-1], math.exp(mu) / (math.exp(mu) + (1.0 / uniform - 1.0)), rtol=1e-6)
+        rng = np.random.default_rng(n_tok)
+        x0, eps = rng.standard_normal(32), rng.standard_normal(32)
+        x = eps.copy()  # sigma = 1: pure noise
+        for i in range(20):
+            v = (x - x0) / sig[i]  # the exact velocity eps - x0 along the path through (x0, current x)
+            x = x + (sig[i + 1] - sig[i]) * v
+        assert np.abs(x - x0).max() < 1e-12
+    assert abs(calculate_shift(256) - 0.5) < 1e-12 and abs(calculate_shift(4096) - 1.16) < 1e-12  # the two anchors of the linear shift law

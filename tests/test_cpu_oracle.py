@@ -192,3 +192,32 @@ def test_added_cond_kwargs_enter_the_conditioning():
     assert torch.allclose(out, out3.flip(0), atol=1e-5)
     mod, emb = m.adaln_single(t, cond)
     assert mod.shape == (2, 6 * cfg.dim) and emb.shape == (2, cfg.dim)
+
+
+def test_dpm_solver_solves_the_probability_flow_ode():
+    """Independent of any source the restatement was written from: for data ~ N(0, c^2 I) the optimal noise prediction is known in closed
+    form and the probability-flow ODE has the exact solution x_t = x_T * sqrt((a_t^2 c^2 + s_t^2) / (a_T^2 c^2 + s_T^2)), (a, s) = (alpha, sigma) of the
+    VP schedule.  DPM-Solver++(2M) must (a) be exact for a point mass (c = 0: the data prediction is constant), (b) converge to the ODE
+    solution with second order in the number of steps."""
+    rng = np.random.default_rng(0)
+    xT = rng.standard_normal(64)
+
+    def run(steps, c):
+        s = DPMSolverPP2M(steps)
+        x = xT.copy()
+        for i in range(steps):
+            a, sg = DPMSolverPP2M._alpha_sigma(np.float64(s.sigmas[i]))
+            eps = sg * x / (a * a * c * c + sg * sg)  # E[eps | x_t] for x0 ~ N(0, c^2)
+            x = np.asarray(s.step(eps, x), dtype=np.float64)
+        a_T, s_T = DPMSolverPP2M._alpha_sigma(np.float64(s.sigmas[0]))
+        a_0, s_0 = DPMSolverPP2M._alpha_sigma(np.float64(s.sigmas[-1]))  # (1, 0): the final sigma is zero
+        exact = xT * np.sqrt((a_0**2 * c * c + s_0**2) / (a_T**2 * c * c + s_T**2))
+        return np.abs(x - exact).max() / max(np.abs(exact).max(), 1e-30), x
+
+    err0, x = run(20, 0.0)
+    assert np.abs(x).max() < 1e-12  # point mass at 0: every step lands on the data prediction's ray, the last one on the point
+    e20, _ = run(20, 0.5)
+    e160, _ = run(160, 0.5)
+    # 8x the steps: a first-order method gains 8x, a second-order one 64x (measured: 4.6e-2 -> 3.0e-4, i.e. 156x; the integer timestep grid
+    # and the first-order first / last steps make individual doublings uneven, so only the overall rate is asserted)
+    assert e20 < 6e-2 and e160 < e20 / 30

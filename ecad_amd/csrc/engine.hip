@@ -222,6 +222,9 @@ template <typename T> class EngineT : public EngineBase {
     HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
     gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = 0;
+    // since gemm3s consumes its second fragment set across the K-step barrier it beats the persistent producer / consumer kernel on FF2
+    // too (in-run: 19.77 -> 18.80 ms per batch = 1008 TFLOP/s) and on the caption / small GEMMs; pgemm stays selectable (ECAD_GEMM=persistent)
+    gemm_impl_cls[KC_GEMM_FF2] = gemm_impl_cls[KC_GEMM_CAPTION] = gemm_impl_cls[KC_GEMM_SMALL] = 0;
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);

@@ -1,6 +1,8 @@
-// gemm3s.h -- non-persistent sibling of pgemm.h: one 256x144 tile per workgroup, 8 mixed waves (each issues its share
-// of the LDS-DMA and owns 32 rows x 144 columns), 3-stage ring, one raw barrier per K-step with counted vmcnt.
-// Kept for in-process A/B against the persistent producer/consumer kernel (ECAD_GEMM=classic selects it).
+// gemm3s.h -- the 256x144-tile GEMM of the PixArt path: one tile per workgroup, 8 mixed waves (each issues its share of the LDS-DMA and
+// owns 32 rows x 144 columns), 3-stage ring, one raw barrier per K-step with counted vmcnt.  Serves every N = 1152 shape (Q, both attention
+// out-projections, cross-attention Q) and, since its second fragment set is consumed across the K-step barrier, FF2 / caption / the small
+// GEMMs as well (FF2: 1.0 PFLOP/s; the persistent producer / consumer kernel of pgemm.h, which it replaced there, is ECAD_GEMM=persistent).
+// ECAD_GEMM=classic runs every GEMM on it.
 #pragma once
 #include "common.h"
 #include "gemm.h"

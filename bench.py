@@ -5,25 +5,30 @@ schedules_in_paper/pixart_alpha_256/ours_fast.json, batch 16 (transformer batch 
 One "step" = one pass of the hot path over one image batch of 16: hoisted caption projection + text K/V,
 20 x (CFG-doubled transformer forward with the cache gate -> guidance -> learned-sigma drop ->
 DPM-Solver++(2M) update), latents out.  Inputs (prompt embeddings, masks, initial latents) are resident
-in HBM when the timed region starts; VAE decode / PIL are NOT in the timed region.
+in HBM when the timed region starts; VAE decode / PIL are NOT in `value`'s timed region (the PNG-ready rate,
+which is what the reference's own latency numbers contain, is reported beside it as `png_ready_images_per_s`).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, independent replicas over disjoint image batches (weak scaling), no data-path
-collective; RCCL carries only the barrier and the max-over-ranks time.
+collective; RCCL carries only the barrier and the max-over-ranks time.  Started without a torchrun environment
+(`python bench.py --gpus 8`), the parent -- before anything touches the GPU -- starts `torch.distributed.run` with
+N fresh rank processes as a CHILD and relays rank 0's JSON line and the exit code (never an exec).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
 import numpy as np
-import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -35,6 +40,7 @@ GUIDANCE = 4.5
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 
+torch = None  # imported by the rank processes only: the launcher parent never loads it
 
 _T0 = time.time()
 
@@ -55,7 +61,84 @@ def usable_cores() -> int:
     return n
 
 
-def device_weights(cfg_like, seed: int, device) -> dict[str, torch.Tensor]:
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun environment
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Start N rank processes under torch.distributed.run as a child of this (GPU-free) process; pass its stdout / stderr / exit code through."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(Path(__file__).resolve())] + argv
+    log("launching", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rank_env(requested_gpus: int) -> tuple[int, int, int]:
+    """(world, rank, local_rank) from the torchrun environment; refuses a `--gpus` that contradicts it instead of mislabelling the line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if requested_gpus != world:
+        raise SystemExit(f"bench.py: --gpus {requested_gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {requested_gpus} (or unset WORLD_SIZE and let bench.py start the ranks)")
+    return world, rank, local_rank
+
+
+def timed_steps(one_step, steps: int, sync, dist=None, comm_device=None) -> float:
+    """The contract's timed region: barrier + device sync | exactly `steps` steps | device sync + barrier; returns the MAX over ranks (seconds)."""
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job(world: int, units_per_rank_step: int, steps: int, elapsed: float) -> dict:
+    """value = the units ALL ranks processed / the max-over-ranks time (weak scaling: per-rank work fixed)."""
+    return {"value": world * units_per_rank_step * steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": steps, "ms_per_step": 1000.0 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
+
+
+def kernel_source_stamp() -> str:
+    """sha256 over the kernel sources + C ABI headers: a PMC traffic profile is only quoted for the code it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(list((ROOT / "ecad_amd" / "csrc").glob("*.h")) + list((ROOT / "ecad_amd" / "csrc").glob("*.hip")) + list((ROOT / "include").glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def stamped_traffic(workload: str, dtype: str) -> tuple[dict, str | None, str]:
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc profile whose stamp (workload, dtype, kernel sources) matches this run; otherwise nothing."""
+    stamp = kernel_source_stamp()
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        s = d.get("_stamp")
+        if s and s.get("kernel_sources") == stamp and s.get("workload") == workload and s.get("dtype") == dtype:
+            return d, f.name, stamp
+    return {}, None, stamp
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def device_weights(cfg_like, seed: int, device) -> dict:
     """Random-init weights of the PixArt-XL-2 architecture, generated on the device (fp16)."""
     from ecad_amd.transformer_2d_models.pixart_transformer_2d_edited import state_dict_shapes
 
@@ -83,7 +166,7 @@ def synthetic_batch(batch: int, seed: int, device, T: int = 120, side: int = 32)
     return enc, m, latents.to(device)
 
 
-def cpu_baseline(weights: dict[str, torch.Tensor], bits: np.ndarray, images: int) -> dict:
+def cpu_baseline(weights: dict, bits: np.ndarray, images: int) -> dict:
     """The oracle (fp32 PyTorch restatement of the reference module graph) timed on the host cores."""
     from oracle.pipeline_ref import denoise, synthetic_inputs
     from oracle.pixart_ref import PixArtConfig, PixArtOracle
@@ -105,7 +188,25 @@ def cpu_baseline(weights: dict[str, torch.Tensor], bits: np.ndarray, images: int
     }
 
 
-def main_flux(args, world, rank, device):
+def main_stub(args, world, rank):
+    """Rank bookkeeping without a GPU (tests/test_cpu_bench.py, gloo): the same launcher, rank_env, timed_steps and whole_job as the real run around a
+    sleeping stand-in for the hot path.  The line says it is a stub in `metric`, `data` and `config.workload`; nothing here is a measurement."""
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    per_step = 0.02 * (1 + rank)  # rank r is (r + 1) x slower: the reported time must be the slowest rank's
+    elapsed = timed_steps(lambda: time.sleep(per_step), args.steps, lambda: None, dist if world > 1 else None, torch.device("cpu"))
+    if rank == 0:
+        res = {"metric": "STUB rank bookkeeping (no GPU work)", **whole_job(world, args.batch or BATCH, args.steps, elapsed), "warmup": args.warmup, "dtype": "none", "data": "stub",
+               "config": {"workload": "stub: sleep(0.02 s x (rank + 1)) per step", "batch_per_gpu": args.batch or BATCH}}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_flux(args, world, rank, device, dist):
     """Secondary workload (BASELINE config 5): FLUX.1-dev geometry at 1024x1024, batch 2, 20 steps,
     schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json, bf16 (the reference's dtype), random-init weights; replicas per rank."""
     from ecad_amd.pipelines.flow_match import flow_match_sigmas, model_scalars
@@ -137,30 +238,15 @@ def main_flux(args, world, rank, device):
         out = one_batch(use_graph)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all(), "non-finite latents"
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_batch(use_graph)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = timed_steps(lambda: one_batch(use_graph), args.steps, torch.cuda.synchronize, dist, device)
     if rank == 0:
         st = eng.stats()
-        value = world * B * args.steps / elapsed
+        job = whole_job(world, B, args.steps, elapsed)
+        value = job["value"]
         flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"])
         res = {
-            "metric": "images/sec at fixed schedule (FLUX.1-dev 1024, 20-step, fast_256_to_1024) [secondary]", "value": value, "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp8-e4m3 block GEMMs, bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
+            "metric": "images/sec at fixed schedule (FLUX.1-dev 1024, 20-step, fast_256_to_1024) [secondary]", **job, "warmup": args.warmup,
+            "dtype": "fp8-e4m3 block GEMMs, bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
             "config": {
                 "workload": f"FLUX.1-dev geometry 1024x1024 (N=4096 + T=512 tokens, D=3072, 19+38 blocks), 20 steps, {sched_path}, batch=2 (no CFG; guidance 5 embedded), 1xMI355X per rank",
                 "batch_per_gpu": B, "timed_region": "context/pooled embedding hoist, all-step adaLN GEMM, 20 transformer steps with cache gate, flow-match Euler; packed latents out (no VAE/PIL)",
@@ -194,28 +280,75 @@ def main_flux(args, world, rank, device):
         dist.destroy_process_group()
 
 
+# secondary workloads reported inside the default line (never in `value`): each is this script run as a CHILD process with its own flags
+SECONDARY = {
+    "alpha256_batch1_latency": ["--batch", "1", "--steps", "20", "--warmup", "3"],
+    "alpha256_batch100_paper_latency_config": ["--batch", "100", "--steps", "3", "--warmup", "1"],
+    "alpha256_fp8_block_gemms": ["--fp8", "--steps", "5", "--warmup", "1"],
+    "sigma1024_batch4": ["--workload", "sigma1024", "--steps", "3", "--warmup", "1"],
+    "flux1024_batch2_bf16": ["--workload", "flux1024", "--steps", "2", "--warmup", "1"],
+}
+
+
+def run_secondary(names: list[str]) -> dict:
+    out = {}
+    for name in names:
+        cmd = [sys.executable, str(Path(__file__).resolve())] + SECONDARY[name] + ["--no-cpu-baseline", "--no-roofline", "--no-decode-tail", "--no-secondary"]
+        t0 = time.time()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                out[name] = {"error": (p.stderr or p.stdout)[-400:]}
+                continue
+            d = json.loads(lines[-1])
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"], "workload": d["config"]["workload"],
+                         "ms_per_image": d["config"].get("ms_per_image"), "whole_job_mfma_fraction": d["config"].get("whole_job_mfma_fraction"), "wall_s": round(time.time() - t0, 1)}
+        except Exception as e:  # a secondary number must never take the headline line down
+            out[name] = {"error": repr(e)[-400:]}
+        log(f"secondary {name}: {out[name].get('value', out[name].get('error'))}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE if launched by torchrun, else 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="images per batch for the PixArt workloads (default 16 alpha256 = the metric's config, 4 sigma1024); other values are secondary lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--decode-tail", action="store_true", help="also measure the secondary PNG-ready rate (HIP VAE decode + PIL)")
-    ap.add_argument("--no-decode-tail", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--decode-tail", action="store_true", help=argparse.SUPPRESS)  # on by default since round 2; kept so older command lines still parse
+    ap.add_argument("--no-decode-tail", action="store_true", help="skip the PNG-ready rate (HIP VAE decode + PIL), reported by default next to `value`")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary workloads (batch 1 / batch 100 / fp8 / Sigma-1024 / FLUX-1024) reported under `secondary`")
+    ap.add_argument("--secondary", default="all", help="comma-separated subset of: " + ", ".join(SECONDARY))
     ap.add_argument("--fp8", action="store_true", help="opt-in OCP e4m3 block GEMMs (north_star / BASELINE config 5 name fp8 MFMA); secondary: dtype then reads fp8, the headline stays f16 / bf16")
     ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024", "flux1024"],
                     help="alpha256 = BASELINE metric config (default); sigma1024 / flux1024 = BASELINE configs 3 / 5 (secondary, not the headline)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the rank bookkeeping only
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus is not None and args.gpus > 1:  # nothing has touched the GPU (torch is not even imported): start the ranks as a child and relay
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+        if args.gpus is None:
+            args.gpus = 1
+    elif args.gpus is None:
+        args.gpus = int(os.environ["WORLD_SIZE"])
+    world, rank, local_rank = rank_env(args.gpus)
+
+    global torch
+    import torch as _torch
+
+    torch = _torch
+    if args.stub:
+        return main_stub(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -223,21 +356,22 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
 
     if args.workload == "flux1024":
-        return main_flux(args, world, rank, device)
+        return main_flux(args, world, rank, device, dist)
 
     from ecad_amd.engine import EcadEngine
     from ecad_amd.pipelines.dpm_solver import DPMSolverMultistepScheduler
     from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
 
     log('imports done')
-    global BATCH, SCHEDULE
+    batch, schedule = args.batch or BATCH, SCHEDULE
     side, text_tokens, sample_size, interp = 32, 120, 32, None
     if args.workload == "sigma1024":  # PixArt-Sigma 1024x1024, batch 4, T = 300; schedule transferred from sigma_256/ours_fast
-        BATCH, side, text_tokens, sample_size, interp = 4, 128, 300, 128, 2
-        SCHEDULE = ROOT / "schedules/schedules_in_paper/pixart_sigma_256/ours_fast.json"
-    sched = PixArtCacheSchedule.from_json(SCHEDULE)
+        batch, side, text_tokens, sample_size, interp = args.batch or 4, 128, 300, 128, 2
+        schedule = ROOT / "schedules/schedules_in_paper/pixart_sigma_256/ours_fast.json"
+    headline = args.workload == "alpha256" and batch == BATCH and not args.fp8
+    sched = PixArtCacheSchedule.from_json(schedule)
     bits = sched.to_numpy()
-    eng = EcadEngine(num_layers=28, max_batch=2 * BATCH, max_tokens=(side // 2) ** 2, max_text_tokens=text_tokens, sample_size=sample_size,
+    eng = EcadEngine(num_layers=28, max_batch=2 * batch, max_tokens=(side // 2) ** 2, max_text_tokens=text_tokens, sample_size=sample_size,
                      interpolation_scale=interp, dtype=torch.float16, device=local_rank, fp8=True if args.fp8 else None)
     weights = device_weights(type("C", (), dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2,
                                                 num_layers=28, caption_channels=4096)), seed=0, device=device)
@@ -249,7 +383,7 @@ def main():
     solver.set_timesteps(NUM_STEPS)
     ts = solver.timesteps.numpy().astype(np.float32)
     coefs = solver.coefficient_table()
-    enc, mask, latents = synthetic_batch(BATCH, seed=1000 + rank, device=device, T=text_tokens, side=side)  # disjoint work per rank
+    enc, mask, latents = synthetic_batch(batch, seed=1000 + rank, device=device, T=text_tokens, side=side)  # disjoint work per rank
 
     def one_batch(graph=True):
         return eng.run_schedule(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=graph)
@@ -261,52 +395,36 @@ def main():
     log('warmup done')
     assert torch.isfinite(out).all(), "non-finite latents"
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_batch(use_graph)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = timed_steps(lambda: one_batch(use_graph), args.steps, torch.cuda.synchronize, dist, device)
 
     log(f'timed region done: {elapsed:.3f}s')
     if rank == 0:
         st = eng.stats()
-        images = world * BATCH * args.steps
-        value = images / elapsed
-        flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"]) / BATCH
+        job = whole_job(world, batch, args.steps, elapsed)
+        value = job["value"]
+        flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"]) / batch
+        dtype_label = "fp8-e4m3 block GEMMs, f16 elsewhere [opt-in, not the headline precision]" if args.fp8 else "f16"
+        if args.workload == "alpha256":
+            metric = "images/sec at fixed schedule (PixArt-alpha 256, 20-step, ours_fast)" + ("" if batch == BATCH else f" [secondary: batch {batch}]")
+            workload = f"PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch={batch} (CFG batch {2 * batch}), 1xMI355X per rank"
+        else:
+            metric = "images/sec at fixed schedule (PixArt-Sigma 1024, 20-step, sigma ours_fast transfer) [secondary]"
+            workload = f"PixArt-Sigma 1024x1024 geometry (N=4096, T=300), 20 steps, pixart_sigma_256/ours_fast.json transferred, batch={batch} (CFG batch {2 * batch}), 1xMI355X per rank"
         res = {
-            "metric": "images/sec at fixed schedule (PixArt-alpha 256, 20-step, ours_fast)" if args.workload == "alpha256"
-            else "images/sec at fixed schedule (PixArt-Sigma 1024, 20-step, sigma ours_fast transfer) [secondary]",
-            "value": value,
-            "unit": "images/s",
-            "n_gpus": world,
-            "steps": args.steps,
+            "metric": metric,
+            **job,
             "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "fp8-e4m3 block GEMMs, f16 elsewhere [opt-in, not the headline precision]" if args.fp8 else "f16",
+            "dtype": dtype_label,
             "data": "synthetic",
             "config": {
-                "workload": ("PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch=16 (CFG batch 32), 1xMI355X per rank"
-                             if args.workload == "alpha256" else
-                             "PixArt-Sigma 1024x1024 geometry (N=4096, T=300), 20 steps, pixart_sigma_256/ours_fast.json transferred, batch=4 (CFG batch 8), 1xMI355X per rank"),
-                "batch_per_gpu": BATCH,
+                "workload": workload,
+                "batch_per_gpu": batch,
                 "guidance_scale": GUIDANCE,
                 "timed_region": "caption-proj + text-KV hoist, 20 transformer steps with cache gate, CFG, DPM-Solver++; latents out (no VAE/PIL)",
                 "weights": "random-init PixArt-XL-2 shapes (no checkpoint available offline)",
                 "hipgraph": bool(use_graph and st["graph_nodes"] > 0),
                 "kernel_launches_per_batch": st["launches_per_batch"],
-                "ms_per_image": 1000.0 * elapsed / (args.steps * BATCH),
+                "ms_per_image": 1000.0 * elapsed / (args.steps * batch),
                 "reference_equivalent_tflop_per_image": flop_per_image / 1e12,
                 "whole_job_mfma_fraction": value / world * flop_per_image / 1e12 / PEAK_MFMA_TFLOPS,
                 "published_reference_a6000_images_per_s": 11.89,
@@ -328,10 +446,9 @@ def main():
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             all_ms = sum(v["ms"] for v in gemms.values())
             all_fl = sum(v["flops"] for v in gemms.values())
-            traffic = None
-            pmc = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
-            if pmc:  # HBM bytes per launch from the latest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                traffic = json.load(open(pmc[-1])).get(dom, {}).get("hbm_bytes_per_launch")
+            # HBM bytes per launch by PMC (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/pmc_traffic.py): quoted only from a
+            # committed profile stamped with THIS workload, dtype and kernel-source hash; otherwise null (it is not measured inside this run)
+            pmc, pmc_file, stamp = stamped_traffic(f"{args.workload}_b{batch}", "fp8" if args.fp8 else "f16")
             res["roofline"] = {
                 "bound": "mfma",
                 "kernel": dom,
@@ -339,7 +456,9 @@ def main():
                 "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_MFMA_TFLOPS,
-                "traffic": traffic,
+                "traffic": pmc.get(dom, {}).get("hbm_bytes_per_launch"),
+                "traffic_source": pmc_file,
+                "kernel_sources_stamp": stamp,
                 "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                 "flops_per_launch": d["flops"] / d["launches"],
                 "avg_launch_ms": d["ms"] / d["launches"],
@@ -352,10 +471,9 @@ def main():
             if rep and rep["launches"]:
                 gbs = rep["bytes"] / (rep["ms"] * 1e-3) / 1e9
                 hbm_kernel = "cache_hit_step" if rep is prof.get("cache_hit_step") else "cache_replay"
-                hbm_traffic = json.load(open(pmc[-1])).get(hbm_kernel, {}).get("hbm_bytes_per_launch") if pmc else None
                 res["roofline_hbm"] = {"bound": "hbm", "kernel": hbm_kernel, "achieved": gbs,
-                                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": hbm_traffic,
-                                       "bytes_per_launch": rep["bytes"] / rep["launches"], "avg_launch_ms": rep["ms"] / rep["launches"],
+                                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc.get(hbm_kernel, {}).get("hbm_bytes_per_launch"),
+                                       "traffic_source": pmc_file, "bytes_per_launch": rep["bytes"] / rep["launches"], "avg_launch_ms": rep["ms"] / rep["launches"],
                                        "launches_measured": rep["launches"]}
                 mid = prof.get("cache_replay")
                 if mid and mid["launches"] and mid is not rep:
@@ -365,9 +483,10 @@ def main():
             tot = sum(v["ms"] for v in prof.values())
             res["time_breakdown_ms_per_batch"] = {k: round(v["ms"] / reps, 3) for k, v in prof.items() if v["launches"]}
             res["time_breakdown_ms_per_batch"]["_sum"] = round(tot / reps, 3)
-        if world == 1 and args.decode_tail and args.workload == "alpha256":
-            # Secondary: what the reference's timed region also contains (VAE decode + postprocess -> PIL), on the native
-            # decoder.  Not in `value`.
+            res["tflops_by_class"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["launches"] and v["flops"] > 0 and v["ms"] > 0}
+        if world == 1 and not args.no_decode_tail and args.workload == "alpha256":
+            # What the reference's timed region also contains (VAE decode + postprocess -> PIL: pixart_image_generator.py:405-438), on the native
+            # decoder.  Extra keys, never in `value`.
             from PIL import Image
 
             from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
@@ -388,13 +507,20 @@ def main():
                 png_ready()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / reps
-            res["config"]["png_ready_images_per_s"] = BATCH / dt
-            res["config"]["png_ready_ms_per_image"] = 1000.0 * dt / BATCH
+            res["png_ready_images_per_s"] = batch / dt
+            res["png_ready_ms_per_image"] = 1000.0 * dt / batch
             res["config"]["decode_tail_ms_per_batch"] = 1000.0 * (dt - elapsed / args.steps)
-            res["config"]["decode_tail"] = "HIP AutoencoderKL decoder (ecad_vae_decode, random-init SD-VAE geometry) -> uint8 NHWC -> host -> PIL; PyTorch/MIOpen decoder measured 41.5 ms per batch"
-            log(f"png-ready: {BATCH / dt:.1f} img/s")
-        if world == 1 and not args.no_cpu_baseline and args.workload == "alpha256":
+            res["config"]["decode_tail"] = "HIP AutoencoderKL decoder (ecad_vae_decode, random-init SD-VAE geometry) -> uint8 NHWC -> host -> PIL; the reference's 84.09 ms/image (A6000) includes this tail"
+            log(f"png-ready: {batch / dt:.1f} img/s")
+            del vae
+        if world == 1 and not args.no_cpu_baseline and headline:
             res["cpu_baseline"] = cpu_baseline(weights, bits, images=2)
+        if world == 1 and headline and not args.no_secondary:
+            names = list(SECONDARY) if args.secondary == "all" else [n for n in args.secondary.split(",") if n in SECONDARY]
+            eng.close()  # the children get the GPU memory back
+            weights.clear()
+            torch.cuda.empty_cache()
+            res["secondary"] = run_secondary(names)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

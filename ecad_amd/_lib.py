@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libecad_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ECAD_DTYPE_F16, ECAD_DTYPE_BF16, ECAD_DTYPE_F32 = 0, 1, 2
 ECAD_E_INVALID, ECAD_E_HIP, ECAD_E_NOT_READY, ECAD_E_UNSUPPORTED = -1, -2, -3, -4
@@ -122,6 +122,8 @@ SIGNATURES = {
     "ecad_set_profiling": (_I, [_P, _I]),
     "ecad_get_profile": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ecad_op_gemm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I64, _I, _P]),
+    "ecad_op_gemm_ex": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I64, _I64, _P, _P, _P, _I64, _I, _P]),
+    "ecad_op_attention_ex": (_I, [_P, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
     "ecad_op_ln_modulate": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _I64, _I, _P]),
     "ecad_op_cache_accumulate": (_I, [_P, _P, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _I64, _I, _P]),
     "ecad_op_attention": (_I, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),

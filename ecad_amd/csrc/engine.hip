@@ -78,6 +78,10 @@ struct EngineBase {
   virtual int get_profile(int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) = 0;
   virtual int op_gemm(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, void* resid, const float* gate_table,
                       const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t st) = 0;
+  virtual int op_gemm_ex(int kernel, int site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int64_t lda, int64_t ldc,
+                         void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t st) = 0;
+  virtual int op_attention_ex(int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H,
+                              int Nq, int Nk, int dh, const float* bias, hipStream_t st) = 0;
   virtual int op_ln(const void* x, void* y, int M, int D, const float* tsh, const float* tsc, const void* msh, const void* msc, int64_t mstride,
                     int rows_per_batch, hipStream_t st) = 0;
   virtual int op_accumulate(void* h, int M, int D, int n_src, const void* const* srcs, const float* const* gts, const void* const* gms, int64_t mstride,
@@ -1123,6 +1127,55 @@ template <typename T> class EngineT : public EngineBase {
     HIPCHK(hipGetLastError());
     return ECAD_OK;
   }
+  // The kernel is named by the caller: the per-class choice table is overridden for this one launch and restored, so the instantiation is
+  // exactly the one the engine's call site `site` launches.  Refuses (never substitutes) when the kernel cannot run the shape.
+  int op_gemm_ex(int kernel, int site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int Nn, int K, int64_t lda, int64_t ldc, void* resid,
+                 const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (site < 0 || site > KC_GEMM_KV1) return fail(ECAD_E_INVALID, "call_site %d is not a GEMM class", site);
+    if (epi == EPI_BIAS_CACHE_RESID && !resid) return fail(ECAD_E_INVALID, "epilogue 3 needs resid");
+    GemmArgs<T> g{};
+    g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
+    g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K;
+    g.lda = lda > 0 ? (int)lda : K; g.ldw = K; g.ldc = ldc > 0 ? (int)ldc : Nn; g.ldr = Nn;
+    if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
+    if (kernel == 3) {
+      if (Nn % 128) return fail(ECAD_E_UNSUPPORTED, "gemm.h tiles need N %% 128 == 0, got %d", Nn);
+      switch (epi) {
+        case EPI_BIAS: launch_gemm_epi<EPI_BIAS>(g, s); break;
+        case EPI_BIAS_GELU: launch_gemm_epi<EPI_BIAS_GELU>(g, s); break;
+        case EPI_BIAS_SILU: launch_gemm_epi<EPI_BIAS_SILU>(g, s); break;
+        case EPI_BIAS_CACHE_RESID: launch_gemm_epi<EPI_BIAS_CACHE_RESID>(g, s); break;
+        default: return fail(ECAD_E_INVALID, "bad epilogue %d", epi);
+      }
+      HIPCHK(hipGetLastError());
+      return ECAD_OK;
+    }
+    if (kernel < 0 || kernel > 2) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
+    if (Nn % PG_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
+    if (kernel == 2) {
+      if (Nn % G2_BN) return fail(ECAD_E_UNSUPPORTED, "gemm2w tiles need N %% 288 == 0, got %d", Nn);
+      if (site != KC_GEMM_FF1 && site != KC_GEMM_TEXTKV && site != KC_GEMM_SMALL && site != KC_GEMM_KV1)
+        return fail(ECAD_E_UNSUPPORTED, "gemm2w is instantiated for the FF1 / text-KV / attn1-KV / small call sites only");
+    }
+    const int keep = gemm_impl_cls[site];
+    gemm_impl_cls[site] = kernel;
+    const int rc = launch_gemm(epi, site, g, s);
+    gemm_impl_cls[site] = keep;
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int op_attention_ex(int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk,
+                      int dh, const float* bias, hipStream_t s) override {
+    if (kernel < 0 || kernel > 2) return fail(ECAD_E_INVALID, "attention kernel %d unknown", kernel);
+    if (kernel == 2 && dh != 72) return fail(ECAD_E_UNSUPPORTED, "attention128.h is instantiated for head_dim 72 on this path, got %d", dh);
+    const int keep = attn_shared;
+    if (kernel) attn_shared = kernel == 2;
+    const int rc = op_attention(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Nq, Nk, dh, bias, s);
+    attn_shared = keep;
+    return rc;
+  }
   int op_ln(const void* x, void* y, int M, int Dd, const float* tsh, const float* tsc, const void* msh, const void* msc, int64_t mstride, int rows_per_batch,
             hipStream_t s) override {
     HIPCHK(hipSetDevice(dev));
@@ -1212,6 +1265,13 @@ int ecad_set_profiling(EcadEngine* e, int on) { ENG(e); return E->set_profiling(
 int ecad_get_profile(EcadEngine* e, int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) { ENG(e); return E->get_profile(maxc, names, ms, launches, flops, bytes); }
 int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, void* stream) {
   ENG(e); return E->op_gemm(epi, A, W, bias, out, M, N, K, resid, gate_table, gate_mod, gate_mod_stride, rows_per_batch, (hipStream_t)stream);
+}
+int ecad_op_gemm_ex(EcadEngine* e, int kernel, int call_site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int64_t lda, int64_t ldc,
+                    void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, void* stream) {
+  ENG(e); return E->op_gemm_ex(kernel, call_site, epi, A, W, bias, out, M, N, K, lda, ldc, resid, gate_table, gate_mod, gate_mod_stride, rows_per_batch, (hipStream_t)stream);
+}
+int ecad_op_attention_ex(EcadEngine* e, int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream) {
+  ENG(e); return E->op_attention_ex(kernel, q, ldq, k, ldk, v, ldv, out, ldo, B, H, Nq, Nk, dh, bias, (hipStream_t)stream);
 }
 int ecad_op_ln_modulate(EcadEngine* e, const void* x, void* y, int M, int D, const float* tsh, const float* tsc, const void* msh, const void* msc, int64_t mstride, int rows_per_batch, void* stream) {
   ENG(e); return E->op_ln(x, y, M, D, tsh, tsc, msh, msc, mstride, rows_per_batch, (hipStream_t)stream);

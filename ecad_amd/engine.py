@@ -204,6 +204,22 @@ class EcadEngine:
         )
         return out
 
+    GEMM_KERNELS = {"tile144": 0, "persistent": 1, "wide288": 2, "tile128": 3}
+    GEMM_SITES = {"qkv": 0, "attn1_out": 1, "attn2_q": 2, "attn2_out": 3, "ff1": 4, "ff2": 5, "text_kv": 6, "caption": 7, "small": 8, "attn1_kv": 9}
+
+    def op_gemm_ex(self, kernel: str, site: str, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None):
+        """``op_gemm`` on a named kernel / call-site instantiation (``ecad_op_gemm_ex``); ``a`` and ``out`` may be column slices (row stride > width)."""
+        M, K = a.shape
+        N = w.shape[0]
+        if out is None and epi != 3:
+            out = torch.empty((M, N), device=self.device, dtype=self.dtype)
+        self._chk(
+            self.lib.ecad_op_gemm_ex(self._h, self.GEMM_KERNELS[kernel], self.GEMM_SITES[site], epi, a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(out), M, N, K,
+                                     a.stride(0), out.stride(0) if out is not None else 0, _ptr(resid), _ptr(gate_table), _ptr(gate_mod),
+                                     int(gate_mod_stride), int(rows_per_batch), _stream_ptr())
+        )
+        return out
+
     def op_ln_modulate(self, x, table_shift, table_scale, mod_shift, mod_scale, mod_stride, rows_per_batch):
         M, D = x.shape
         y = torch.empty_like(x)
@@ -218,9 +234,13 @@ class EcadEngine:
         self._chk(self.lib.ecad_op_cache_accumulate(self._h, h.data_ptr(), M, D, n, arr(srcs), arr(gate_tables), arr(gate_mods), int(mod_stride), int(rows_per_batch), _stream_ptr()))
         return h
 
-    def op_attention(self, q, k, v, B, H, Nq, Nk, dh, bias=None):
-        """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer)."""
+    def op_attention(self, q, k, v, B, H, Nq, Nk, dh, bias=None, kernel: str = "auto"):
+        """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer).  kernel: auto | generic (attention.h) | shared (attention128.h)."""
         out = torch.empty((B * Nq, H * dh), device=self.device, dtype=self.dtype)
+        if kernel != "auto":
+            self._chk(self.lib.ecad_op_attention_ex(self._h, {"generic": 1, "shared": 2}[kernel], q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                                    out.data_ptr(), out.stride(0), B, H, Nq, Nk, dh, _ptr(bias), _stream_ptr()))
+            return out
         self._chk(self.lib.ecad_op_attention(self._h, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0),
                                              B, H, Nq, Nk, dh, _ptr(bias), _stream_ptr()))
         return out

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ECAD_ABI_VERSION 1
+#define ECAD_ABI_VERSION 2
 
 enum {
   ECAD_OK = 0,
@@ -147,6 +147,16 @@ int ecad_get_profile(EcadEngine* e, int max_classes, const char** names, double*
  * 3 bias -> cache write -> resid += gate * out  (gate_table_f32 [N] + gate_mod [rows/rows_per_batch][..] may be NULL => gate 1). */
 int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                  void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, void* stream);
+/* ecad_op_gemm with the kernel named by the caller, so the parity tests reach every GEMM kernel the engine launches with the exact
+ * template instantiation of its call site (tests/test_gpu_ops.py).  kernel: ECAD_GEMM_K_*; call_site: ECAD_SITE_* = the engine's
+ * call-site class (it only selects the kernel symbol rocprof reports).  ECAD_E_UNSUPPORTED if that kernel cannot run the shape
+ * (never a silent substitution). */
+enum { ECAD_GEMM_K_TILE144 = 0 /* gemm3s.h 256x144 */, ECAD_GEMM_K_PERSISTENT = 1 /* pgemm.h */, ECAD_GEMM_K_WIDE288 = 2 /* gemm2w.h 256x288 */,
+       ECAD_GEMM_K_TILE128 = 3 /* gemm.h 128x128, N % 128 == 0 */ };
+enum { ECAD_SITE_QKV = 0, ECAD_SITE_OUT1 = 1, ECAD_SITE_Q2 = 2, ECAD_SITE_OUT2 = 3, ECAD_SITE_FF1 = 4, ECAD_SITE_FF2 = 5, ECAD_SITE_TEXTKV = 6,
+       ECAD_SITE_CAPTION = 7, ECAD_SITE_SMALL = 8, ECAD_SITE_KV1 = 9 };
+int ecad_op_gemm_ex(EcadEngine* e, int kernel, int call_site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                    int64_t lda, int64_t ldc, void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, void* stream);
 /* y = LN(x) * (1 + scale) + shift with scale = table[1*D..] + mod[b][1], shift = table[0] + mod[b][0] (adaLN-single). */
 int ecad_op_ln_modulate(EcadEngine* e, const void* x, void* y, int M, int D, const float* table_shift, const float* table_scale,
                         const void* mod_shift, const void* mod_scale, int64_t mod_stride, int rows_per_batch, void* stream);
@@ -157,6 +167,11 @@ int ecad_op_cache_accumulate(EcadEngine* e, void* h, int M, int D, int n_src, co
  * q: rows of stride ldq, k/v likewise; bias_f32 [B, Nk] or NULL. */
 int ecad_op_attention(EcadEngine* e, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo,
                       int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream);
+
+/* ecad_op_attention with the kernel named: 0 = what the engine would pick, 1 = attention.h (any head_dim <= 72, % 8 == 0), 2 =
+ * attention128.h (head_dim 72 only; ECAD_E_UNSUPPORTED otherwise). */
+int ecad_op_attention_ex(EcadEngine* e, int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo,
+                         int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream);
 
 /* ---- decode tail: AutoencoderKL decoder + postprocess ------------------------------------------------
  * Replaces `self.vae.decode(latents / scaling_factor)` and `image_processor.postprocess(..., "pil")` inside the reference's

@@ -4,10 +4,12 @@ MI355X_MICROARCH.md "rocprofv3 PMC slots").
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline
-    python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_i_pmc_traffic.json
+    python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_a_pmc_traffic.json [workload=alpha256_b16] [dtype=f16]
 
 Corrections exactly as the guide's HBM section prescribes: both counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide
-coalesced reads, so it is doubled; WRITE_SIZE is exact.  bench.py reads the newest profiles/r*_pmc_traffic.json for `roofline.traffic`.
+coalesced reads, so it is doubled; WRITE_SIZE is exact.  The output carries a `_stamp` (workload, dtype, sha256 of the kernel sources it was
+measured on -- run this script on the same tree as the counter passes); bench.py quotes `roofline.traffic` only from a profile whose stamp
+matches its own run and reports null otherwise.
 """
 import csv
 import json
@@ -73,8 +75,15 @@ def main():
         res[cls] = {"kernel": sym or sym2, "launches": nf or nw, "fetch_size_kb_raw_per_launch": fkb, "write_size_kb_per_launch": wkb,
                     "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0,
                     "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM); WRITE_SIZE exact; separate --pmc passes, eager (no graph) run"}
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+
+    res["_stamp"] = {"workload": sys.argv[4] if len(sys.argv) > 4 else "alpha256_b16", "dtype": sys.argv[5] if len(sys.argv) > 5 else "f16",
+                     "kernel_sources": bench.kernel_source_stamp()}
     out.write_text(json.dumps(res, indent=1))
     for k, v in res.items():
+        if k.startswith("_"):
+            continue
         print(f"{k:22s} launches {v['launches']:5d}  HBM {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB / launch")
 
 

@@ -13,14 +13,14 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import rel_l2
+from gpu_util import rel_l2, within
 
 pytestmark = pytest.mark.gpu
 
 from oracle import flux_ref  # noqa: E402  (checker only)
 from oracle.schedule_ref import resolve_executed  # noqa: E402
 
-DTYPES = [(torch.float16, 2e-3), (torch.bfloat16, 1e-2)]
+DTYPES = [(torch.float16, 6e-4), (torch.bfloat16, 5e-3)]  # <= 2x measured: GEMM 2.1e-4..3.1e-4 / 1.7e-3..2.5e-3, attention and RoPE 2.7e-4 / 2.2e-3
 
 
 def tiny_cfg(layers=2, single=3):
@@ -77,15 +77,15 @@ def test_fgemm_split_a_gated_residual_two_segments(op_engine, dtype, tol, bn):
     out = eng.op_gemm(2, bn, A1, W, bias, A2=A2, resid=resid, gate=gate[:, D:], seg0=B * T, rows_per_batch0=T, rows_per_batch1=N)
     torch.cuda.synchronize()
     ref = torch.cat([A1, A2], 1).float() @ W.float().T + bias
-    assert rel_l2(out.float(), ref) <= tol
+    assert within(rel_l2(out.float(), ref), tol)
     b_of_row = torch.cat([torch.arange(B).repeat_interleave(T), torch.arange(B).repeat_interleave(N)]).cuda()
     want = resid0.float() + gate[:, D : 2 * D].float()[b_of_row] * ref
-    assert rel_l2(resid.float(), want) <= tol
+    assert within(rel_l2(resid.float(), want), tol)
     # no cache copy requested, no gate: plain accumulate
     resid2 = resid0.clone()
     eng.op_gemm(2, bn, A1, W, bias, A2=A2, resid=resid2, want_out=False)
     torch.cuda.synchronize()
-    assert rel_l2(resid2.float(), resid0.float() + ref) <= tol
+    assert within(rel_l2(resid2.float(), resid0.float() + ref), tol)
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
@@ -115,7 +115,7 @@ def test_qk_norm_rope_matches_oracle(op_engine, dtype, tol):
             cs = slice(which * D, (which + 1) * D)
             want[tr, cs] = ref_part(qkv[tr, cs], w[wt], cos[:T], sin[:T])
             want[ir, cs] = ref_part(qkv[ir, cs], w[wi], cos[T:], sin[T:])
-    assert rel_l2(got.float(), want) <= tol
+    assert within(rel_l2(got.float(), want), tol)
     assert torch.equal(got[:, 2 * D :].cpu(), qkv[:, 2 * D :])  # v untouched
 
 
@@ -136,7 +136,7 @@ def test_joint_attention_matches_sdpa(op_engine, dtype, tol, T, N):
         q, k, v = [x[:, i * D : (i + 1) * D].view(S, H, 128).transpose(0, 1) for i in range(3)]
         o = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(128), -1) @ v
         want[rows] = o.transpose(0, 1).reshape(S, D)
-    assert rel_l2(out.float(), want) <= tol
+    assert within(rel_l2(out.float(), want), tol)
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
@@ -152,7 +152,7 @@ def test_ln_modulate_two_segments(op_engine, dtype, tol):
     b_of_row = torch.cat([torch.arange(B).repeat_interleave(T), torch.arange(B).repeat_interleave(N)])
     ln = torch.nn.functional.layer_norm(x.float(), (D,), eps=1e-6)
     want = ln * (1 + mod[:, D:].float()[b_of_row]) + mod[:, :D].float()[b_of_row]
-    assert rel_l2(y.float(), want) <= tol
+    assert within(rel_l2(y.float(), want), tol)
 
 
 # ------------------------------------------------------------------------------------------------ engine
@@ -168,7 +168,7 @@ def make_pair(cfg, dtype, bits_full, bits_single, seed=0, **kw):
     return eng, flux_ref.FluxOracle(cfg, w, round_dtype=None if dtype is None else dtype)
 
 
-@pytest.mark.parametrize("dtype,tol,shape", [(torch.float16, 6e-3, (2, 32, 8, 8)), (torch.bfloat16, 4e-2, (2, 32, 8, 8)), (torch.float16, 6e-3, (3, 21, 5, 7))])
+@pytest.mark.parametrize("dtype,tol,shape", [(torch.float16, 1.4e-3, (2, 32, 8, 8)), (torch.bfloat16, 1e-2, (2, 32, 8, 8)), (torch.float16, 1.4e-3, (3, 21, 5, 7))])
 def test_step_parity_random_schedule(dtype, tol, shape):
     """ecad_flux_step == FluxTransformer2DEdited.forward at every schedule row, caches (and dead-component skipping) included.  The last case
     is ragged on purpose: 3 samples, 21 text and 5 x 7 = 35 image tokens (row strips of the GEMM epilogues straddle samples and the
@@ -193,14 +193,14 @@ def test_step_parity_random_schedule(dtype, tol, shape):
         want = ref.forward(x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), gd), ids, s, bf[s], bs[s])
         worst = max(worst, rel_l2(got.float(), want))
     print(f"flux step parity {dtype}: worst rel-L2 {worst:.2e}")
-    assert worst <= tol
+    assert within(worst, tol)
     st = eng.stats()
     ef, es = resolve_executed(bf), resolve_executed(bs)
     assert st["components_executed"] + st["components_dead"] == int(ef.sum() + es.sum())
     assert st["components_cached"] == int((~ef).sum() + (~es).sum())
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-2), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 7e-4), (torch.bfloat16, 5e-3)])
 def test_run_schedule_matches_oracle_and_graph_is_bit_exact(dtype, tol):
     cfg = tiny_cfg(2, 2)
     steps, B, T, gh, gw = 8, 2, 32, 8, 8
@@ -227,7 +227,7 @@ def test_run_schedule_matches_oracle_and_graph_is_bit_exact(dtype, tol):
         xo = (xo + (float(sig[s + 1]) - float(sig[s])) * v).to(dtype).float()
     err = rel_l2(outs[0], xo)
     print(f"flux final latents {dtype}: rel-L2 {err:.2e}")
-    assert err <= tol
+    assert within(err, tol)
 
 
 def test_forced_recompute_and_all_cached_steps_are_exact_replays():
@@ -276,7 +276,7 @@ def test_flux_errors():
         eng.load_state_dict({"not.a.weight": torch.zeros(1)})
 
 
-@pytest.mark.parametrize("fp8,tol", [(False, 4e-2), (True, 1.2e-1)])
+@pytest.mark.parametrize("fp8,tol", [(False, 1.6e-2), (True, 1.25e-1)])
 def test_full_width_geometry_matches_oracle(fp8, tol):
     """FLUX.1-dev width and token counts (D = 3072 = 24 x 128, N = 4096 image + T = 512 text tokens, batch 2: the BASELINE config-5
     shapes every kernel is tuned for -- 256-wide tiles, S = 4608 attention without a tail, 1.06 M-row adaLN matrix per 57 blocks
@@ -307,7 +307,7 @@ def test_full_width_geometry_matches_oracle(fp8, tol):
         want = ref.forward(x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), 4992.0), ids, s, bf[s], bs[s])
         err = rel_l2(got.float(), want)
         print(f"flux full-width step {s} (fp8={fp8}): rel-L2 {err:.2e}")
-        assert err <= tol
+        assert within(err, tol)
 
 
 @pytest.mark.parametrize("bn", [128, 256])
@@ -330,14 +330,14 @@ def test_fp8_gemm_matches_fp32_within_e4m3_noise(op_engine, bn):
     assert torch.isfinite(out.float()).all()
     err = rel_l2(out.float(), ref)
     print(f"fp8 gemm bn {bn}: rel-L2 {err:.3e}")
-    assert err <= 6e-2
-    assert rel_l2(out_gelu.float(), torch.nn.functional.gelu(ref, approximate="tanh")) <= 6e-2
-    assert rel_l2(out[7].float(), bias) <= 1e-2
+    assert within(err, 4e-2)
+    assert within(rel_l2(out_gelu.float(), torch.nn.functional.gelu(ref, approximate="tanh")), 4e-2)
+    assert within(rel_l2(out[7].float(), bias), 3.5e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle(dtype):
-    """Opt-in fp8 mode (ecad_flux_set_fp8): same schedule, same inputs.  Stated tolerance per forward against the fp32 oracle: 1.5e-1
+    """Opt-in fp8 mode (ecad_flux_set_fp8): same schedule, same inputs.  Stated tolerance per forward against the fp32 oracle: 1.1e-2 at this reduced width (measured 5.4e-3; full width: 1.25e-1, test_full_width_geometry_matches_oracle)
     rel-L2 (every block GEMM carries ~4 % e4m3 noise; the bf16 engine sits at 5e-3), and the fp8 run must stay bit-reproducible
     between hipGraph replay and eager launches."""
     cfg = tiny_cfg(2, 3)
@@ -368,7 +368,7 @@ def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle(dtype):
         want = ref.forward(x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), 4992.0), ids, s, bf[s], bs[s])
         worst = max(worst, rel_l2(got.float(), want))
     print(f"flux fp8 step parity: worst rel-L2 {worst:.2e}")
-    assert worst <= 1.5e-1
+    assert within(worst, 1.1e-2)
     sig = flux_ref.flow_match_sigmas(steps, gh * gw)
     tm, gm = flux_ref.model_scalars(sig, 5.0, dtype)
     outs = []

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import rel_l2
+from gpu_util import rel_l2, within
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,7 @@ def test_generator_end_to_end_matches_oracle(tmp_path):
     stepwise = gen.generate_images(emb, images_per_prompt=2, output_type="latent")
     for a_list, b_list in zip(native, stepwise):
         for a, b in zip(a_list, b_list):
-            assert rel_l2(a.float(), b.float()) <= 1e-2  # same kernels; the Euler update runs in torch here (one extra fp32 rounding)
+            assert within(rel_l2(a.float(), b.float()), 1e-3)  # same kernels; the Euler update runs in torch here (one extra fp32 rounding)
     ms = gen.generate_images_timed(emb, output_type="latent")
     assert ms > 0
 
@@ -68,7 +68,7 @@ def test_generator_end_to_end_matches_oracle(tmp_path):
         got = torch.stack([native[b][k].float().cpu() for b in range(B)])
         err = rel_l2(got, x)
         print(f"flux generator seed {seed}: final latents rel-L2 {err:.2e}")
-        assert err <= 6e-2
+        assert within(err, 5e-3)
 
 
 def test_pipeline_pack_unpack_and_errors():

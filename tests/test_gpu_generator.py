@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from gpu_util import within
+
 pytestmark = pytest.mark.gpu
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -45,7 +47,7 @@ def test_generator_surface_and_both_loops_agree(embedding_dir, tmp_path, capsys)
     la, lb = torch.stack([x[0] for x in a]).float(), torch.stack([x[0] for x in b]).float()
     rel = float((la - lb).norm() / lb.norm())
     print(f"native loop vs per-step loop rel-L2: {rel:.2e}")
-    assert torch.isfinite(la).all() and rel < 5e-3  # same arithmetic up to where fp16 rounding is applied in the solver
+    assert torch.isfinite(la).all() and within(rel, 3e-3)  # same arithmetic up to where fp16 rounding is applied in the solver
     # PNG path + reference file naming
     gen.diffusion_pipeline.native_loop = True
     gen.generate_from_saved_prompts(embedding_dir, tmp_path / "out", batch_size=2, images_per_prompt=2)
@@ -109,7 +111,7 @@ def test_alpha_1024_ms_schedule_runs_micro_conditioned(embedding_dir):
     b = gen.generate_images(batch, images_per_prompt=1, output_type="latent")[0][0].float()
     rel = float((a - b).norm() / b.norm())
     print(f"1024-MS native loop vs per-step forward(): rel-L2 {rel:.2e}")
-    assert rel < 5e-3
+    assert within(rel, 3.5e-3)
     with pytest.raises(ValueError, match="added_cond_kwargs"):
         tr(torch.zeros(2, 4, 128, 128), encoder_hidden_states=torch.zeros(2, 120, 4096), timestep=torch.zeros(2), added_cond_kwargs=None)
     gen.free_diffusion_pipeline()
@@ -131,5 +133,5 @@ def test_pipeline_without_classifier_free_guidance(embedding_dir):
     b = gen.diffusion_pipeline(**{**kw, "guidance_scale": 1.0 + 1e-6, "latents": lat.clone()})[0].float()
     rel = float((a - b).norm() / b.norm())
     print(f"no-CFG vs CFG at guidance 1: rel-L2 {rel:.2e}")
-    assert torch.isfinite(a).all() and rel < 3e-3
+    assert torch.isfinite(a).all() and within(rel, 1e-3)
     gen.free_diffusion_pipeline()

@@ -2,7 +2,8 @@
 
 Tolerances (floating point, stated per test): inputs are rounded to the storage type first, the
 reference is evaluated in fp32 on those rounded values, so the remaining error is the kernel's
-fp32-accumulate + one output rounding: rel-L2 <= 2e-3 for fp16, 1.2e-2 for bf16.
+fp32-accumulate + one output rounding: rel-L2 <= 4.5e-4 for fp16, 3.6e-3 for bf16 (measured on MI355X: 2.1e-4 / 1.7e-3 = one output
+rounding; attention 2.8e-4 / 2.2e-3 -> 6e-4 / 4.5e-3).  Every tolerance here is <= 2x the value `pytest -s` prints ([parity] lines).
 """
 import math
 
@@ -10,11 +11,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import rel_l2, small_engine
+from gpu_util import rel_l2, small_engine, within
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"float16": 2e-3, "bfloat16": 1.2e-2}
+TOL = {"float16": 4.5e-4, "bfloat16": 3.6e-3}
+ATT_TOL = {"float16": 6e-4, "bfloat16": 4.5e-3}
 
 
 def _r(shape, dtype, scale=1.0, seed=0):
@@ -31,7 +33,113 @@ def test_gemm_bias(dtype_name, M, N, K):
     bias = _r((N,), torch.float32, 0.5, 3)
     out = eng.op_gemm(0, a, w, bias)
     ref = a.float() @ w.float().t() + bias
-    assert rel_l2(out, ref) < TOL[dtype_name]
+    assert within(rel_l2(out, ref), TOL[dtype_name])
+
+
+def tile_rel_l2(out, ref, bm=256, bn=144):
+    """Worst rel-L2 over the bm x bn output tiles: one wrong tile of a 8192 x 4608 product is 0.1 % of the elements and must not hide in the global norm."""
+    M, N = ref.shape
+    d = (out.float() - ref).pow(2)
+    r = ref.pow(2)
+    pm, pn = (-M) % bm, (-N) % bn
+    d, r = F.pad(d, (0, pn, 0, pm)), F.pad(r, (0, pn, 0, pm))
+    dn = d.view((M + pm) // bm, bm, (N + pn) // bn, bn).sum((1, 3))
+    rn = r.view((M + pm) // bm, bm, (N + pn) // bn, bn).sum((1, 3))
+    return float((dn / rn.clamp_min(1e-30)).sqrt().max())
+
+
+# (kernel, call site, epilogue, M, N, K): the instantiations the engine launches, at the shapes it launches them with (config A: M = 8192) plus ragged M.
+# wide288 = gemm2w.h (FF1 + GELU, attn1 K,V two-thirds of the fused QKV weight, hoisted text K/V of all 28 blocks); tile144 = gemm3s.h;
+# persistent = pgemm.h (ECAD_GEMM=persistent); tile128 = gemm.h (N % 144 != 0).
+KERNEL_CASES = [
+    ("wide288", "ff1", 1, 8192, 4608, 1152),
+    ("wide288", "ff1", 1, 600, 4608, 1152),
+    ("wide288", "attn1_kv", 0, 8192, 2304, 1152),
+    ("wide288", "text_kv", 0, 3840, 64512, 1152),
+    ("wide288", "text_kv", 0, 77, 2304, 1152),
+    ("wide288", "small", 0, 1000, 576, 256),
+    ("tile144", "qkv", 0, 8192, 1152, 1152),
+    ("tile144", "qkv", 0, 8192, 3456, 1152),
+    ("tile144", "attn2_q", 0, 700, 1152, 1152),
+    ("tile144", "ff1", 1, 8192, 4608, 1152),
+    ("tile144", "caption", 1, 3840, 1152, 4096),
+    ("tile144", "small", 2, 40, 1152, 256),
+    ("persistent", "ff1", 1, 8192, 4608, 1152),
+    ("persistent", "text_kv", 0, 3840, 8064, 1152),
+    ("persistent", "qkv", 0, 600, 3456, 1152),
+    ("persistent", "caption", 1, 3840, 1152, 4096),
+    ("tile128", "small", 1, 1000, 1024, 512),
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("kernel,site,epi,M,N,K", KERNEL_CASES)
+def test_gemm_every_kernel_by_call_site(dtype_name, kernel, site, epi, M, N, K):
+    """Every GEMM kernel the engine can launch, through ecad_op_gemm_ex with the call site's own template instantiation; worst output TILE
+    against fp32 torch (cached_transformer_block.py:348-353,374-382 are the Linear layers these replace)."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    a, w = _r((M, K), dt, 1.0, 21), _r((N, K), dt, 0.05, 22)
+    bias = _r((N,), torch.float32, 0.5, 23)
+    out = eng.op_gemm_ex(kernel, site, epi, a, w, bias)
+    ref = a.float() @ w.float().t() + bias
+    ref = {0: lambda x: x, 1: lambda x: F.gelu(x, approximate="tanh"), 2: F.silu}[epi](ref)
+    worst = tile_rel_l2(out, ref)
+    del ref
+    assert within(worst, TOL[dtype_name])
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
+    """The split QKV launch of the engine: Q on 256x144 tiles into columns [0, D), K,V on 256x288 tiles into columns [D, 3D) of one [M, 3D] buffer
+    (row stride 3D on the output) -- together they must equal one fused projection, and neither may touch the other's columns."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    M, D = 8192, 1152
+    a, w = _r((M, D), dt, 1.0, 31), _r((3 * D, D), dt, 0.05, 32)
+    bias = _r((3 * D,), torch.float32, 0.5, 33)
+    qkv = torch.full((M, 3 * D), 7.0, dtype=dt, device="cuda")
+    eng.op_gemm_ex("wide288", "attn1_kv", 0, a, w[D:], bias[D:], out=qkv[:, D:])
+    assert bool((qkv[:, :D] == 7.0).all())
+    eng.op_gemm_ex("tile144", "qkv", 0, a, w[:D], bias[:D], out=qkv[:, :D])
+    ref = a.float() @ w.float().t() + bias
+    assert within(tile_rel_l2(qkv, ref), TOL[dtype_name])
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("kernel,site,K,B,Ntok", [("tile144", "attn1_out", 1152, 32, 256), ("tile144", "attn2_out", 1152, 3, 192), ("tile144", "ff2", 4608, 32, 256),
+                                                 ("persistent", "ff2", 4608, 32, 256), ("persistent", "attn1_out", 1152, 3, 192), ("tile128", "small", 1152, 3, 192)])
+def test_gemm_cache_gate_residual_every_kernel(dtype_name, kernel, site, K, B, Ntok):
+    """cache <- out; hidden += gate * out with gates of O(1) (cached_transformer_block.py:243-246,317-320,355-360) on every kernel that carries that epilogue, at
+    config A's shape (M = 8192: one sample per 256-row tile -> gate via LDS) and with 192 tokens per sample (tiles straddle samples -> per-chunk gate)."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    D = 1152 if kernel != "tile128" else 1024
+    M = B * Ntok
+    a, w = _r((M, K), dt, 1.0, 41), _r((D, K), dt, 0.03, 42)
+    bias = _r((D,), torch.float32, 0.1, 43)
+    h0 = _r((M, D), dt, 1.0, 44)
+    table = _r((D,), torch.float32, 1.0, 45)
+    mod = _r((B, 6 * D), dt, 1.0, 46)
+    h = h0.clone()
+    cache = torch.zeros((M, D), dtype=dt, device="cuda")
+    eng.op_gemm_ex(kernel, site, 3, a, w, bias, resid=h, gate_table=table, gate_mod=mod[:, 2 * D :], gate_mod_stride=6 * D, rows_per_batch=Ntok, out=cache)
+    out_ref = (a.float() @ w.float().t() + bias).to(dt).float()
+    gate = (table[None] + mod[:, 2 * D : 3 * D].float()).repeat_interleave(Ntok, 0)
+    h_ref = h0.float() + gate * out_ref
+    assert within(tile_rel_l2(cache, out_ref), TOL[dtype_name])
+    assert within(tile_rel_l2(h, h_ref), TOL[dtype_name])
+
+
+def test_gemm_ex_refuses_instead_of_substituting():
+    eng = small_engine("float16")
+    a, w = _r((256, 1152), torch.float16, 1.0, 1), _r((1152, 1152), torch.float16, 0.05, 2)
+    with pytest.raises(ValueError, match="288"):
+        eng.op_gemm_ex("wide288", "ff1", 1, a, w[:1008], None)  # N = 1008 = 7 * 144: not a multiple of 288
+    with pytest.raises(ValueError, match="call sites"):
+        eng.op_gemm_ex("wide288", "attn1_out", 0, a, w, None)
+    with pytest.raises(ValueError, match="144"):
+        eng.op_gemm_ex("tile144", "qkv", 0, a, w[:1024], None)
 
 
 def test_gemm_asymmetric_identity():
@@ -52,7 +160,7 @@ def test_gemm_activation(epi, fn):
     bias = _r((1152,), torch.float32, 0.5, 6)
     out = eng.op_gemm(epi, a, w, bias)
     ref = fn(a.float() @ w.float().t() + bias)
-    assert rel_l2(out, ref) < 2e-3
+    assert within(rel_l2(out, ref), TOL["float16"])
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
@@ -74,8 +182,8 @@ def test_gemm_cache_gate_residual(dtype_name, gated):
     out_ref = (a.float() @ w.float().t() + bias).to(dt).float()
     gate = (table[None] + mod[:, 2 * D : 3 * D].float()).repeat_interleave(Ntok, 0) if gated else 1.0
     h_ref = h0.float() + gate * out_ref
-    assert rel_l2(cache, out_ref) < TOL[dtype_name]
-    assert rel_l2(h, h_ref) < TOL[dtype_name]
+    assert within(rel_l2(cache, out_ref), TOL[dtype_name])
+    assert within(rel_l2(h, h_ref), TOL[dtype_name])
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
@@ -90,7 +198,7 @@ def test_ln_modulate(dtype_name):
     n = F.layer_norm(x.float(), (D,), eps=1e-6)
     sh = (tsh[None] + mod[:, :D].float()).repeat_interleave(Ntok, 0)
     sc = (tsc[None] + mod[:, D : 2 * D].float()).repeat_interleave(Ntok, 0)
-    assert rel_l2(y, n * (1 + sc) + sh) < TOL[dtype_name]
+    assert within(rel_l2(y, n * (1 + sc) + sh), TOL[dtype_name])
 
 
 @pytest.mark.parametrize("n_src,B,Ntok", [(1, 2, 256), (3, 2, 256), (9, 2, 256), (84, 2, 256), (5, 3, 6), (7, 1, 1022)])
@@ -114,7 +222,7 @@ def test_cache_accumulate(n_src, B, Ntok):
         else:
             g = (tables[i][None] + mods[i][:, :D].float()).repeat_interleave(Ntok, 0)
             ref = ref + g * srcs[i].float()
-    assert rel_l2(h, ref) < 2e-3
+    assert within(rel_l2(h, ref), TOL["float16"])
 
 
 def _attn_ref(q, k, v, B, H, Nq, Nk, dh, bias):
@@ -137,7 +245,31 @@ def test_self_attention(dtype_name, Nq, Nk):
     D = H * dh
     out = eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, Nq, Nk, dh)
     ref = _attn_ref(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, Nq, Nk, dh, None)
-    assert rel_l2(out, ref) < 2 * TOL[dtype_name]
+    assert within(rel_l2(out, ref), ATT_TOL[dtype_name])
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("dh,Nq,Nk,masked", [(72, 256, 256, False), (72, 256, 120, True), (64, 256, 256, False), (64, 200, 77, True), (40, 1024, 1024, False), (8, 64, 64, False)])
+def test_attention_generic_kernel(dtype_name, dh, Nq, Nk, masked):
+    """attention.h (two-rounds kernel): what the engine launches whenever head_dim != 72 and under ECAD_ATTN=generic; forced here through ecad_op_attention_ex."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    B, H = 2, 4
+    D = H * dh
+    q = _r((B * Nq, D), dt, 1.0, 1)
+    kv = _r((B * Nk, 2 * D), dt, 1.0, 2)
+    bias = None
+    if masked:
+        lens = torch.tensor([Nk, max(1, Nk // 3)])
+        bias = ((1 - (torch.arange(Nk)[None] < lens[:, None]).float()) * -10000.0).cuda()
+    out = eng.op_attention(q, kv[:, :D], kv[:, D:], B, H, Nq, Nk, dh, bias=bias, kernel="generic")
+    ref = _attn_ref(q, kv[:, :D], kv[:, D:], B, H, Nq, Nk, dh, bias)
+    assert within(rel_l2(out, ref), ATT_TOL[dtype_name])
+    if dh != 72:
+        with pytest.raises(ValueError, match="head_dim 72"):
+            eng.op_attention(q, kv[:, :D], kv[:, D:], B, H, Nq, Nk, dh, bias=bias, kernel="shared")
+        auto = eng.op_attention(q, kv[:, :D], kv[:, D:], B, H, Nq, Nk, dh, bias=bias)  # the engine's own choice for this head_dim is this kernel
+        assert torch.equal(auto, out)
 
 
 @pytest.mark.parametrize("T", [120, 300, 1])
@@ -153,7 +285,7 @@ def test_cross_attention_masked(T):
     bias = ((1 - mask) * -10000.0).cuda()
     out = eng.op_attention(q, kv[:, :D], kv[:, D:], B, H, Nq, T, dh, bias=bias)
     ref = _attn_ref(q, kv[:, :D], kv[:, D:], B, H, Nq, T, dh, bias)
-    assert rel_l2(out, ref) < 4e-3
+    assert within(rel_l2(out, ref), ATT_TOL["float16"])
 
 
 def test_attention_large_scores_online_softmax():
@@ -165,4 +297,4 @@ def test_attention_large_scores_online_softmax():
     qkv[200:208, D : 2 * D] *= 6.0  # keys in the 4th tile get much larger logits
     out = eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh)
     ref = _attn_ref(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh, None)
-    assert rel_l2(out, ref) < 4e-3
+    assert within(rel_l2(out, ref), ATT_TOL["float16"])

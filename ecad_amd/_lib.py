@@ -54,6 +54,10 @@ class EcadStats(C.Structure):
         ("workspace_bytes", C.c_int64),
         ("graph_nodes", C.c_int32),
         ("launches_per_batch", C.c_int32),
+        ("plan_builds", C.c_int32),
+        ("graph_captures", C.c_int32),
+        ("dynamic_step_plans", C.c_int32),
+        ("plan_sets_cached", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -118,6 +122,10 @@ SIGNATURES = {
     "ecad_step": (_I, [_P, _I, _P, _P, _P, _P]),
     "ecad_run_schedule": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, _I, _P]),
     "ecad_reset_cache": (_I, [_P]),
+    "ecad_set_custom_components": (_I, [_P, C.POINTER(C.c_uint8), _I, _P, _P, _P, _P]),
+    "ecad_block_attn": (_I, [_P, _I, _I, _P, _P, _P]),
+    "ecad_block_ff": (_I, [_P, _I, _P, _P, _P]),
+    "ecad_copy_batch_context": (_I, [_P, _P, _P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P]),
     "ecad_cache_stats": (_I, [_P, C.POINTER(EcadStats)]),
     "ecad_set_profiling": (_I, [_P, _I]),
     "ecad_get_profile": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -156,6 +164,9 @@ SIGNATURES = {
     "ecad_flux_op_attention": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ecad_flux_op_ln_modulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I64, _P]),
 }
+
+# EcadComponentFn (include/ecad_hip.h): int fn(void* user, int step, int block, int component, const void* in, void* out, int Bt, int N, int D, void* stream)
+COMPONENT_FN = C.CFUNCTYPE(_I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P)
 
 _lib = None
 

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <list>
 #include <map>
 #include <string>
 #include <vector>
@@ -73,6 +74,10 @@ struct EngineBase {
   virtual int run_schedule(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, float* latents, const float* ts, const float* coef,
                            float guidance, int use_graph, hipStream_t st) = 0;
   virtual int reset_cache() = 0;
+  virtual int set_custom(const uint8_t* mask, int blocks, EcadComponentFn fn, void* user, void* io_in, void* io_out) = 0;
+  virtual int block_attn(int block, int which, const void* x, void* out, hipStream_t st) = 0;
+  virtual int block_ff(int block, const void* x, void* out, hipStream_t st) = 0;
+  virtual int copy_context(void* ctx_out, float* bias_out, int* Bt, int* N, int* T, hipStream_t st) = 0;
   virtual int stats(EcadStats* s) = 0;
   virtual int set_profiling(int on) = 0;
   virtual int get_profile(int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) = 0;
@@ -92,7 +97,7 @@ struct EngineBase {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Op {
-  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE, COMB } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE, COMB, CUSTOM } kind;
   int cls = KC_MISC;
   int epi = 0;
   GemmArgs<T> g{};
@@ -172,6 +177,39 @@ template <typename T> class EngineT : public EngineBase {
   std::vector<SrcDesc> desc_host;
   std::vector<float> coef_host, ts_host;
   EcadStats st{};
+  // ---- plan sets of recently used (schedule, shapes): op lists + descriptors + the captured graph, keyed by content, so alternating between a few
+  // schedules (the GA's reference run + candidates, a server's handful of presets) neither re-lowers nor re-captures (env ECAD_PLAN_CACHE=n, default 4)
+  struct PlanStash {
+    std::string key;
+    std::vector<Op<T>> begin, run;
+    std::vector<std::vector<Op<T>>> step;
+    std::vector<SrcDesc> dh;
+    SrcDesc* dd = nullptr;
+    size_t dcap = 0;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    float gg = 0.f;
+    EcadStats st{};
+    bool comb = false;
+  };
+  std::list<PlanStash> plan_lru;
+  size_t plan_lru_cap = 4;
+  std::string cur_key;
+  int plan_builds = 0, graph_captures = 0;
+  // ---- ecad_step: which cache slots hold a usable value RIGHT NOW (reset by begin_image_batch / reset_cache; a slot whose write the static plan
+  // skipped as dead counts as unusable).  A step whose "flag or no usable cache" set differs from the static resolution runs an ad-hoc plan.
+  std::vector<uint8_t> valid_rt;
+  SrcDesc* desc_dyn_dev = nullptr;
+  size_t desc_dyn_cap = 0, desc_dyn_pos = 0;
+  int dynamic_steps = 0;
+  // ---- user compute plug-ins (cached_transformer_block.py:125-165): components routed to a host callback in ecad_step mode
+  std::vector<uint8_t> custom_mask;  // [L][3]
+  bool any_custom = false;
+  EcadComponentFn custom_fn = nullptr;
+  void* custom_user = nullptr;
+  T* io_in = nullptr;
+  T* io_out = nullptr;
+  int cur_step_idx = 0;
   // ---- graph
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
@@ -193,6 +231,8 @@ template <typename T> class EngineT : public EngineBase {
     hipSetDevice(dev);
     if (graph_exec) hipGraphExecDestroy(graph_exec);
     if (graph) hipGraphDestroy(graph);
+    for (auto& e : plan_lru) free_stash(e);
+    if (desc_dyn_dev) hipFree(desc_dyn_dev);
     if (cap_stream) hipStreamDestroy(cap_stream);
     for (auto e : ev_pool) hipEventDestroy(e);
     if (warena) hipFree(warena);
@@ -232,6 +272,9 @@ template <typename T> class EngineT : public EngineBase {
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
+    if (const char* l = getenv("ECAD_PLAN_CACHE")) plan_lru_cap = (size_t)(atoi(l) > 0 ? atoi(l) : 0);
+    custom_mask.assign((size_t)cfg.num_layers * 3, 0);
+    valid_rt.assign((size_t)cfg.num_layers * 3, 0);
     if (const char* l = getenv("ECAD_LN_COMB")) use_comb = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
@@ -416,12 +459,12 @@ template <typename T> class EngineT : public EngineBase {
     for (auto& kv : dests)
       if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "weight '%s' was never loaded", kv.first.c_str());
     finalized = true;
-    plan_valid = false;
+    drop_all_plans();
     if (fp8) return build_fp8_weights();
     return ECAD_OK;
   }
   int set_fp8(int on) override {
-    if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; plan_valid = false; }
+    if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; drop_all_plans(); }
     return ECAD_OK;
   }
   // added_cond_kwargs of forward (pixart_transformer_2d_edited.py:208-211): host arrays, copied here; read by the size-embedding
@@ -528,9 +571,66 @@ template <typename T> class EngineT : public EngineBase {
   }
 
   // -------------------------------------------------------------------------------------------
+  // plan-set cache
+  static void free_stash(PlanStash& e) {
+    if (e.ge) hipGraphExecDestroy(e.ge);
+    if (e.g) hipGraphDestroy(e.g);
+    if (e.dd) hipFree(e.dd);
+    e.ge = nullptr; e.g = nullptr; e.dd = nullptr;
+  }
+  std::string make_key() const {
+    std::string k((const char*)bits.data(), bits.size());
+    k.append((const char*)custom_mask.data(), custom_mask.size());
+    const int geo[8] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0};
+    k.append((const char*)geo, sizeof geo);
+    return k;
+  }
+  // move the live plan set (if any) to the front of the LRU; evict beyond the capacity (device sync first: an evicted graph may still be in flight)
+  void stash_current() {
+    if (!plan_valid) return;
+    plan_valid = false;
+    if (plan_lru_cap == 0) return;  // build_plans tears the stale set down
+    PlanStash e;
+    e.key = std::move(cur_key);
+    e.begin = std::move(plan_begin); e.run = std::move(plan_run); e.step = std::move(plan_step); e.dh = std::move(desc_host);
+    e.dd = desc_dev; e.dcap = desc_cap; e.g = graph; e.ge = graph_exec; e.gg = graph_guidance; e.st = st; e.comb = comb_live;
+    desc_dev = nullptr; desc_cap = 0; graph = nullptr; graph_exec = nullptr;
+    plan_begin.clear(); plan_run.clear(); plan_step.clear(); desc_host.clear(); cur_key.clear();
+    plan_lru.push_front(std::move(e));
+    if (plan_lru.size() > plan_lru_cap) {
+      hipDeviceSynchronize();
+      while (plan_lru.size() > plan_lru_cap) { free_stash(plan_lru.back()); plan_lru.pop_back(); }
+    }
+  }
+  bool restore_plans(const std::string& key) {
+    for (auto it = plan_lru.begin(); it != plan_lru.end(); ++it) {
+      if (it->key != key) continue;
+      if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+      if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+      if (desc_dev) { hipFree(desc_dev); desc_dev = nullptr; }
+      PlanStash& e = *it;
+      plan_begin = std::move(e.begin); plan_run = std::move(e.run); plan_step = std::move(e.step); desc_host = std::move(e.dh);
+      desc_dev = e.dd; desc_cap = e.dcap; graph = e.g; graph_exec = e.ge; graph_guidance = e.gg; comb_live = e.comb;
+      st = e.st;
+      cur_key = key;
+      plan_lru.erase(it);
+      plan_valid = true;
+      return true;
+    }
+    return false;
+  }
+  void drop_all_plans() {
+    plan_valid = false;
+    if (!plan_lru.empty()) hipDeviceSynchronize();
+    for (auto& e : plan_lru) free_stash(e);
+    plan_lru.clear();
+  }
+
+  // -------------------------------------------------------------------------------------------
   int set_schedule(const uint8_t* b, int nsteps, int nblocks) override {
     if (nblocks != L) return fail(ECAD_E_INVALID, "schedule has %d blocks, model has %d", nblocks, L);
     if (nsteps < 1 || nsteps > 64) return fail(ECAD_E_INVALID, "num_inference_steps %d out of range [1, 64]", nsteps);
+    stash_current();  // the plans and graph of the outgoing schedule stay reachable by content
     steps = nsteps;
     bits.assign(b, b + (size_t)nsteps * L * 3);
     executed.assign(bits.size(), 0);
@@ -610,8 +710,18 @@ template <typename T> class EngineT : public EngineBase {
   }
 
   // ops of one transformer forward at schedule row s.  mod_s/emb_s: adaLN tables of this step.
-  void emit_transformer(std::vector<Op<T>>& ops, int s, const T* mod_s, int64_t mstride, const T* emb_s, int64_t estride, bool bind_call) {
+  // `ex_rt` (ecad_step only): the components that execute in THIS call, overriding the static resolution (all cache writes are then kept)
+  void emit_transformer(std::vector<Op<T>>& ops, int s, const T* mod_s, int64_t mstride, const T* emb_s, int64_t estride, bool bind_call, const uint8_t* ex_rt = nullptr) {
     const int M = Bt * N, Mt = Bt * Tt;
+    auto live = [&](int b, int c) { return ex_rt ? true : cache_write_live(s, b, c); };
+    // a component routed to the user's compute plug-in (step plans only): its input lands in io_in, the callback fills io_out with the
+    // sub-layer output, which then joins the pending gated sums exactly like a cached tensor would (gate applied by the engine, :243-246)
+    auto custom = [&](int b, int c) { return bind_call && any_custom && custom_mask[(size_t)b * 3 + c]; };
+    auto emit_custom = [&](int b, int c, const T* src) {
+      Op<T> o; o.kind = Op<T>::CUSTOM; o.cls = KC_MISC; o.i0 = b; o.i1 = c; o.p0 = src; o.bytes = 2.0 * M * (double)D * sizeof(T);
+      ops.push_back(o);
+      a8_src = nullptr;
+    };
     const size_t slot = (size_t)M * D;
     {
       Op<T> o; o.kind = Op<T>::PATCH; o.cls = KC_PATCH; o.p0 = model_in; o.call_latents = bind_call; o.bytes = (double)M * D * sizeof(T);
@@ -621,13 +731,17 @@ template <typename T> class EngineT : public EngineBase {
     const int ldkv = L * 2 * D;
     for (int b = 0; b < L; ++b) {
       const Blk& B = blk[b];
-      const uint8_t* ex = &executed[((size_t)s * L + b) * 3];
+      const uint8_t* ex = ex_rt ? ex_rt + (size_t)b * 3 : &executed[((size_t)s * L + b) * 3];
       const T* cb = comb_live && !bind_call ? comb + ((size_t)s * L + b) * 4 * D : nullptr;  // shared-timestep (run) plan only
       T* c0 = cache + ((size_t)b * 3 + 0) * slot;
       T* c1 = cache + ((size_t)b * 3 + 1) * slot;
       T* c2 = cache + ((size_t)b * 3 + 2) * slot;
       // --- attn1
-      if (ex[0]) {
+      if (custom(b, 0)) {
+        emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, false, nullptr, nullptr);
+        emit_custom(b, 0, xn);
+        pend.push_back(Pending{io_out, B.sst + 2 * D, mod_s + 2 * D});
+      } else if (ex[0]) {
         emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, true, cb ? cb + 0 * D : nullptr, cb ? cb + 1 * D : nullptr);
         if (split_qkv && (2 * D) % G2_BN == 0) {
           // Q columns on 256x144 tiles (256 tiles) + K,V columns on 256x288 tiles (256 tiles): the wide tiles move 32 % fewer
@@ -642,14 +756,18 @@ template <typename T> class EngineT : public EngineBase {
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = 4.0 * Bt * (double)NH * N * (double)N * DH; a.bytes = 4.0 * M * (double)D * sizeof(T);
         ops.push_back(a);
-        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, cache_write_live(s, b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
-        if (cache_write_live(s, b, 0)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, live(b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
+        if (live(b, 0)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 4ll * M * D * D; st.linear_macs_executed += 4ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)N * D;
       } else {
         pend.push_back(Pending{c0, B.sst + 2 * D, mod_s + 2 * D});
       }
       // --- attn2 (no norm for ada_norm_single, cached_transformer_block.py:264-267; no gate, :289)
-      if (ex[1]) {
+      if (custom(b, 1)) {
+        emit_replay(ops, pend, M, mstride);
+        emit_custom(b, 1, h);
+        pend.push_back(Pending{io_out, nullptr, nullptr});
+      } else if (ex[1]) {
         emit_replay(ops, pend, M, mstride);
         push_gemm(ops, mk_gemm(KC_GEMM_Q2, EPI_BIAS, h, B.w_q2, B.b_q2, qc, M, D, D, D, D));
         Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_CROSS; a.attn_masked = true;
@@ -658,18 +776,22 @@ template <typename T> class EngineT : public EngineBase {
         a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = 4.0 * Bt * (double)NH * N * (double)Tt * DH; a.bytes = (2.0 * M + 2.0 * Mt) * D * sizeof(T);
         ops.push_back(a);
-        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, cache_write_live(s, b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
-        if (cache_write_live(s, b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, live(b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
+        if (live(b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
       } else {
         pend.push_back(Pending{c1, nullptr, nullptr});
       }
       // --- ff
-      if (ex[2]) {
+      if (custom(b, 2)) {
+        emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride, false, nullptr, nullptr);
+        emit_custom(b, 2, xn);
+        pend.push_back(Pending{io_out, B.sst + 5 * D, mod_s + 5 * D});
+      } else if (ex[2]) {
         emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride, true, cb ? cb + 2 * D : nullptr, cb ? cb + 3 * D : nullptr);
         push_gemm(ops, mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D), true);
-        push_gemm(ops, mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, cache_write_live(s, b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
-        if (cache_write_live(s, b, 2)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        push_gemm(ops, mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, live(b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
+        if (live(b, 2)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 8ll * M * D * D; st.linear_macs_executed += 8ll * M * D * D;
       } else {
         pend.push_back(Pending{c2, B.sst + 5 * D, mod_s + 5 * D});
@@ -768,6 +890,7 @@ template <typename T> class EngineT : public EngineBase {
     if (graph) { hipGraphDestroy(graph); graph = nullptr; }
     st.graph_nodes = 0;
     plan_valid = true;
+    ++plan_builds;
     return ECAD_OK;
   }
 
@@ -778,8 +901,19 @@ template <typename T> class EngineT : public EngineBase {
     if (n > cfg.max_tokens) return fail(ECAD_E_INVALID, "%d image tokens exceed max_tokens %d", n, cfg.max_tokens);
     if (T_ < 1 || T_ > cfg.max_text_tokens) return fail(ECAD_E_INVALID, "text tokens %d outside [1, %d]", T_, cfg.max_text_tokens);
     if (!plan_valid || Bt_ != Bt || H_ != Hl || W_ != Wl || T_ != Tt) {
+      stash_current();
       Bt = Bt_; Hl = H_; Wl = W_; Tt = T_; N = n;
-      return build_plans();
+      if (!finalized) return fail(ECAD_E_NOT_READY, "weights not finalized");
+      if (steps == 0) return fail(ECAD_E_NOT_READY, "no schedule set");
+      const std::string key = make_key();
+      if (restore_plans(key)) {
+        const int gh = Hl / P, gw = Wl / P;
+        if (pos_grid != gh * 100000 + gw) { int rc = build_pos_table(gh, gw); if (rc) return rc; }
+        return ECAD_OK;
+      }
+      int rc = build_plans();
+      if (rc == ECAD_OK) cur_key = key;
+      return rc;
     }
     return ECAD_OK;
   }
@@ -980,6 +1114,14 @@ template <typename T> class EngineT : public EngineBase {
         hipLaunchKernelGGL((cfg_solver_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, noise, lat_buf, x0_prev, model_in, coef_dev + o.i0 * 8, guidance, B, CIN, COUT, Hl * Wl);
         break;
       }
+      case Op<T>::CUSTOM: {
+        if (!custom_fn || !io_in || !io_out) return fail(ECAD_E_NOT_READY, "block %d component %d is routed to a compute plug-in but no callback is registered", o.i0, o.i1);
+        hipError_t ce = hipMemcpyAsync(io_in, o.p0, (size_t)M * D * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (ce != hipSuccess) return fail(ECAD_E_HIP, "staging the plug-in input failed: %s", hipGetErrorString(ce));
+        const int rc = custom_fn(custom_user, cur_step_idx, o.i0, o.i1, io_in, io_out, Bt, N, D, (void*)s);
+        if (rc) return fail(ECAD_E_INVALID, "compute plug-in of block %d component %d failed (callback returned %d)", o.i0, o.i1, rc);
+        break;
+      }
       case Op<T>::DUP: {
         const int total = (Bt / 2) * CIN * Hl * Wl;
         hipLaunchKernelGGL((cfg_duplicate_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, lat_buf, model_in, total);
@@ -1038,6 +1180,7 @@ template <typename T> class EngineT : public EngineBase {
     rc = run_ops(plan_begin, s, 0.f, true);
     if (rc) return rc;
     batch_begun = true;
+    std::fill(valid_rt.begin(), valid_rt.end(), 0);  // caches dropped: reset_cache (:155-158)
     return ECAD_OK;
   }
 
@@ -1047,13 +1190,55 @@ template <typename T> class EngineT : public EngineBase {
     if (step_idx < 0 || step_idx >= steps) return fail(ECAD_E_INVALID, "step_idx %d outside [0, %d)", step_idx, steps);
     if (!latents || !timestep || !out) return fail(ECAD_E_INVALID, "NULL pointer argument");
     call_latents = latents; call_timestep = timestep; call_out = out;
-    return run_ops(plan_step[step_idx], s, 0.f, true);
+    cur_step_idx = step_idx;
+    // what executes now = flag or no usable cache (cached_transformer_block.py:340-347), from the caches as they are at this call
+    std::vector<uint8_t> ex((size_t)L * 3);
+    bool as_planned = true;
+    for (int i = 0; i < L * 3; ++i) {
+      const size_t k = (size_t)step_idx * L * 3 + i;
+      ex[i] = bits[k] || !valid_rt[i];
+      if (!(any_custom && custom_mask[i]) && ex[i] != executed[k]) as_planned = false;
+    }
+    if (as_planned) {
+      int rc = run_ops(plan_step[step_idx], s, 0.f, true);
+      if (rc) return rc;
+      for (int i = 0; i < L * 3; ++i)
+        if (ex[i]) valid_rt[i] = cache_write_live(step_idx, i / 3, i % 3);  // a write skipped as dead leaves nothing usable behind
+      return ECAD_OK;
+    }
+    // the caller reset the caches mid-run (or stepped out of order): lower this one step from the live cache state
+    std::vector<Op<T>> ops;
+    std::vector<SrcDesc> keep_desc;
+    keep_desc.swap(desc_host);
+    const EcadStats keep_st = st;
+    emit_temb(ops, nullptr, Bt, (size_t)step_idx * Bt, true);
+    emit_transformer(ops, step_idx, mod_all + (size_t)step_idx * Bt * 6 * D, 6 * D, temb + (size_t)step_idx * Bt * D, D, true, ex.data());
+    std::vector<SrcDesc> dyn;
+    dyn.swap(desc_host);
+    desc_host.swap(keep_desc);
+    st = keep_st;
+    if (!dyn.empty()) {
+      const size_t region = 8192;  // descriptors per ad-hoc plan (3L + a few): a ring of regions, so plans still in flight keep theirs
+      if (dyn.size() > region) return fail(ECAD_E_UNSUPPORTED, "ad-hoc step plan needs %zu descriptors", dyn.size());
+      if (!desc_dyn_dev) { desc_dyn_cap = region * 8; HIPCHK(hipMalloc((void**)&desc_dyn_dev, desc_dyn_cap * sizeof(SrcDesc))); }
+      if (desc_dyn_pos + region > desc_dyn_cap) { HIPCHK(hipStreamSynchronize(s)); desc_dyn_pos = 0; }
+      SrcDesc* base = desc_dyn_dev + desc_dyn_pos;
+      desc_dyn_pos += region;
+      HIPCHK(hipMemcpy(base, dyn.data(), dyn.size() * sizeof(SrcDesc), hipMemcpyHostToDevice));
+      for (auto& o : ops) if (o.desc_off >= 0) o.f.srcs = base + o.desc_off;
+    }
+    ++dynamic_steps;
+    int rc = run_ops(ops, s, 0.f, true);
+    if (rc) return rc;
+    for (int i = 0; i < L * 3; ++i) if (ex[i]) valid_rt[i] = 1;
+    return ECAD_OK;
   }
 
   int run_schedule(int Bt_, int H_, int W_, const void* enc, const uint8_t* mask, int T_, float* latents, const float* ts, const float* coef,
                    float guidance, int use_graph, hipStream_t s) override {
     HIPCHK(hipSetDevice(dev));
     if (Bt_ % 2) return fail(ECAD_E_INVALID, "run_schedule needs a CFG-doubled batch (Bt even), got %d", Bt_);
+    if (any_custom) return fail(ECAD_E_UNSUPPORTED, "the schedule routes components to host compute plug-ins: the whole-loop graph cannot call back into the host, use ecad_step");
     if (!enc || !latents || !ts || !coef) return fail(ECAD_E_INVALID, "NULL pointer argument");
     int rc = ensure_shapes(Bt_, H_, W_, T_);
     if (rc) return rc;
@@ -1082,6 +1267,7 @@ template <typename T> class EngineT : public EngineBase {
         if (rc) return rc;
         if (e != hipSuccess) return fail(ECAD_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
         HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+        ++graph_captures;
         size_t nn = 0;
         hipGraphGetNodes(graph, nullptr, &nn);
         st.graph_nodes = (int)nn;
@@ -1094,11 +1280,76 @@ template <typename T> class EngineT : public EngineBase {
     }
     HIPCHK(hipMemcpyAsync(latents, lat_buf, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     batch_begun = false;  // caches are dropped after the last step (image_generator.py:197-202)
+    std::fill(valid_rt.begin(), valid_rt.end(), 0);
     return ECAD_OK;
   }
 
-  int reset_cache() override { batch_begun = false; return ECAD_OK; }
-  int stats(EcadStats* s) override { *s = st; return ECAD_OK; }
+  // reset_cache (:155-158) drops the three cached outputs of every block and nothing else: the hoisted caption projection / text K/V of the batch are
+  // recomputations, not caches, so a batch that has begun stays begun and the next ecad_step recomputes whatever it finds no usable cache for
+  int reset_cache() override { std::fill(valid_rt.begin(), valid_rt.end(), 0); return ECAD_OK; }
+  int set_custom(const uint8_t* mask, int blocks, EcadComponentFn fn, void* user, void* in, void* out) override {
+    if (mask && blocks != L) return fail(ECAD_E_INVALID, "plug-in mask has %d blocks, model has %d", blocks, L);
+    bool any = false;
+    for (int i = 0; mask && i < L * 3; ++i) any = any || mask[i];
+    if (any && (!fn || !in || !out)) return fail(ECAD_E_INVALID, "a compute plug-in needs a callback and the two [max_batch * max_tokens, D] I/O buffers");
+    stash_current();
+    custom_mask.assign((size_t)L * 3, 0);
+    if (any) custom_mask.assign(mask, mask + (size_t)L * 3);
+    any_custom = any; custom_fn = any ? fn : nullptr; custom_user = user; io_in = (T*)in; io_out = (T*)out;
+    return ECAD_OK;
+  }
+  // the block's own sub-layers for use inside a plug-in (the reference's `self.attn1(...)` / `self.attn2(...)` / `self.ff(...)`): plain bias epilogues,
+  // no gate, no cache; geometry and text K/V of the batch that has begun.  fp16 / bf16 kernels also in fp8 mode.
+  int block_attn(int block, int which, const void* x, void* out, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (!batch_begun || !plan_valid) return fail(ECAD_E_NOT_READY, "ecad_begin_image_batch must be called first");
+    if (block < 0 || block >= L || (which != 1 && which != 2) || !x || !out) return fail(ECAD_E_INVALID, "bad block %d / attention %d / NULL pointer", block, which);
+    const Blk& B = blk[block];
+    const int M = Bt * N;
+    AttnArgs a{};
+    a.out = attn_o; a.ldo = D; a.B = Bt; a.H = NH; a.Nq = N; a.dh = DH; a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+    int rc;
+    if (which == 1) {
+      if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_QKV, mk_gemm(KC_GEMM_QKV, EPI_BIAS, (const T*)x, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D).g, s))) return rc;
+      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D; a.Nk = N; a.bias = nullptr;
+      if ((rc = launch_attn(a, (N % 128) != 0, s))) return rc;
+      if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_SMALL, mk_gemm(KC_GEMM_SMALL, EPI_BIAS, attn_o, B.w_o1, B.b_o1, (T*)out, M, D, D, D, D).g, s))) return rc;
+    } else {
+      if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_Q2, mk_gemm(KC_GEMM_Q2, EPI_BIAS, (const T*)x, B.w_q2, B.b_q2, qc, M, D, D, D, D).g, s))) return rc;
+      a.q = qc; a.ldq = D; a.k = kv2 + (size_t)block * 2 * D; a.v = kv2 + (size_t)block * 2 * D + D; a.ldk = a.ldv = L * 2 * D; a.Nk = Tt; a.bias = bias_buf;
+      if ((rc = launch_attn(a, true, s))) return rc;
+      if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_SMALL, mk_gemm(KC_GEMM_SMALL, EPI_BIAS, attn_o, B.w_o2, B.b_o2, (T*)out, M, D, D, D, D).g, s))) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int block_ff(int block, const void* x, void* out, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (!batch_begun || !plan_valid) return fail(ECAD_E_NOT_READY, "ecad_begin_image_batch must be called first");
+    if (block < 0 || block >= L || !x || !out) return fail(ECAD_E_INVALID, "bad block %d / NULL pointer", block);
+    const Blk& B = blk[block];
+    const int M = Bt * N;
+    int rc;
+    if ((rc = launch_gemm(EPI_BIAS_GELU, KC_GEMM_FF1, mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, (const T*)x, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D).g, s))) return rc;
+    if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_SMALL, mk_gemm(KC_GEMM_SMALL, EPI_BIAS, ffmid, B.w_ff2, B.b_ff2, (T*)out, M, D, 4 * D, 4 * D, D).g, s))) return rc;
+    HIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
+  int copy_context(void* ctx_out, float* bias_out, int* Bt_, int* N_, int* T_, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (!batch_begun || !plan_valid) return fail(ECAD_E_NOT_READY, "ecad_begin_image_batch must be called first");
+    if (ctx_out) HIPCHK(hipMemcpyAsync(ctx_out, ctx, (size_t)Bt * Tt * D * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (bias_out) HIPCHK(hipMemcpyAsync(bias_out, bias_buf, (size_t)Bt * Tt * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (Bt_) *Bt_ = Bt;
+    if (N_) *N_ = N;
+    if (T_) *T_ = Tt;
+    return ECAD_OK;
+  }
+  int stats(EcadStats* s) override {
+    *s = st;
+    s->plan_builds = plan_builds; s->graph_captures = graph_captures; s->dynamic_step_plans = dynamic_steps; s->plan_sets_cached = (int32_t)plan_lru.size();
+    return ECAD_OK;
+  }
   int set_profiling(int on) override {
     profiling = on != 0;
     for (int i = 0; i < KC_COUNT; ++i) { prof_ms[i] = prof_flops[i] = prof_bytes[i] = 0; prof_launch[i] = 0; }
@@ -1260,6 +1511,10 @@ int ecad_run_schedule(EcadEngine* e, int Bt, int H, int W, const void* enc, cons
   ENG(e); return E->run_schedule(Bt, H, W, enc, mask, T, latents, ts, coef, guidance, use_graph, (hipStream_t)stream);
 }
 int ecad_reset_cache(EcadEngine* e) { ENG(e); return E->reset_cache(); }
+int ecad_set_custom_components(EcadEngine* e, const uint8_t* mask, int blocks, EcadComponentFn fn, void* user, void* io_in_dev, void* io_out_dev) { ENG(e); return E->set_custom(mask, blocks, fn, user, io_in_dev, io_out_dev); }
+int ecad_block_attn(EcadEngine* e, int block, int which, const void* x_dev, void* out_dev, void* stream) { ENG(e); return E->block_attn(block, which, x_dev, out_dev, (hipStream_t)stream); }
+int ecad_block_ff(EcadEngine* e, int block, const void* x_dev, void* out_dev, void* stream) { ENG(e); return E->block_ff(block, x_dev, out_dev, (hipStream_t)stream); }
+int ecad_copy_batch_context(EcadEngine* e, void* ctx_out_dev, float* bias_out_dev, int* Bt, int* N, int* T, void* stream) { ENG(e); return E->copy_context(ctx_out_dev, bias_out_dev, Bt, N, T, (hipStream_t)stream); }
 int ecad_cache_stats(EcadEngine* e, EcadStats* s) { ENG(e); if (!s) return E->fail(ECAD_E_INVALID, "NULL stats"); return E->stats(s); }
 int ecad_set_profiling(EcadEngine* e, int on) { ENG(e); return E->set_profiling(on); }
 int ecad_get_profile(EcadEngine* e, int maxc, const char** names, double* ms, int64_t* launches, double* flops, double* bytes) { ENG(e); return E->get_profile(maxc, names, ms, launches, flops, bytes); }

@@ -80,6 +80,18 @@ def broadcast_population(bits: np.ndarray | None, shape: tuple[int, int]) -> np.
     return t.cpu().numpy().astype(np.bool_)
 
 
+def broadcast_ints(values, n: int) -> list[int]:
+    """Rank 0's `n` integers to everyone (generation header: error flag, generation number, population rows)."""
+    rank, world = _world()
+    if world == 1:
+        return [int(v) for v in values]
+    t = torch.zeros(n, dtype=torch.int64, device=_comm_device())
+    if rank == 0:
+        t.copy_(torch.tensor([int(v) for v in values], dtype=torch.int64))
+    dist.broadcast(t, src=0)
+    return [int(v) for v in t.cpu().tolist()]
+
+
 def max_over_ranks(value: float) -> float:
     rank, world = _world()
     if world == 1:

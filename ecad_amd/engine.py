@@ -147,7 +147,12 @@ class EcadEngine:
             ts = ts.expand(Bt)
         ts = ts.contiguous()
         out = torch.empty((Bt, self.cfg.out_channels, latents.shape[2], latents.shape[3]), device=self.device, dtype=self.dtype)
-        self._chk(self.lib.ecad_step(self._h, int(step_idx), latents.data_ptr(), ts.data_ptr(), out.data_ptr(), _stream_ptr(stream)))
+        rc = self.lib.ecad_step(self._h, int(step_idx), latents.data_ptr(), ts.data_ptr(), out.data_ptr(), _stream_ptr(stream))
+        custom = getattr(self, "_custom", None)
+        if rc != 0 and custom is not None and custom[3]["error"] is not None:  # a plug-in raised: the user's exception, not the engine's wrapper
+            err, custom[3]["error"] = custom[3]["error"], None
+            raise err
+        self._chk(rc)
         return out
 
     def run_schedule(self, enc, mask, latents: torch.Tensor, timesteps, solver_coef, guidance_scale: float = 4.5, use_graph: bool = True, stream=None) -> torch.Tensor:
@@ -172,6 +177,58 @@ class EcadEngine:
 
     def reset_cache(self) -> None:
         self._chk(self.lib.ecad_reset_cache(self._h))
+
+    # -- user compute plug-ins (ecad_set_custom_components) -------------------------------------
+    def set_custom_components(self, mask: np.ndarray | None, callback=None) -> None:
+        """mask [blocks, 3] (attn1, attn2, ff) of components routed to ``callback(step, block, component, x) -> Tensor`` during ``step``: ``x`` is the
+        sub-layer input [Bt, N, D] (a view of an engine-filled buffer), the return value the sub-layer output before gate and residual."""
+        if mask is None or not np.asarray(mask).any():
+            self._chk(self.lib.ecad_set_custom_components(self._h, None, 0, None, None, None, None))
+            self._custom = None
+            return
+        mask = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        if mask.ndim != 2 or mask.shape[1] != 3:
+            raise ValueError(f"plug-in mask must have shape (blocks, 3), got {mask.shape}")
+        rows = self.cfg.max_batch * self.cfg.max_tokens
+        io_in = torch.empty((rows, self.dim), device=self.device, dtype=self.dtype)
+        io_out = torch.empty((rows, self.dim), device=self.device, dtype=self.dtype)
+        state = {"error": None}
+
+        def trampoline(_user, step, block, comp, _in, _out, Bt, N, D, _stream):
+            try:
+                out = callback(step, block, comp, io_in[: Bt * N].view(Bt, N, D))
+                io_out[: Bt * N].copy_(out.reshape(Bt * N, D))
+                return 0
+            except BaseException as e:  # noqa: BLE001  (re-raised by step() on this thread)
+                state["error"] = e
+                return 1
+
+        fn = L.COMPONENT_FN(trampoline)
+        self._custom = (fn, io_in, io_out, state)  # keep the ctypes thunk and the buffers alive as long as the engine may call them
+        self._chk(self.lib.ecad_set_custom_components(self._h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), mask.shape[0], C.cast(fn, C.c_void_p), None,
+                                                      io_in.data_ptr(), io_out.data_ptr()))
+
+    def block_attn(self, block: int, which: int, x: torch.Tensor) -> torch.Tensor:
+        """The block's own ``attn1(x)`` (which 1) / ``attn2(x, text of the batch)`` (which 2): [Bt, N, D] -> [Bt, N, D], bias only."""
+        x = x.to(device=self.device, dtype=self.dtype).contiguous()
+        out = torch.empty_like(x)
+        self._chk(self.lib.ecad_block_attn(self._h, int(block), int(which), x.data_ptr(), out.data_ptr(), _stream_ptr()))
+        return out
+
+    def block_ff(self, block: int, x: torch.Tensor) -> torch.Tensor:
+        x = x.to(device=self.device, dtype=self.dtype).contiguous()
+        out = torch.empty_like(x)
+        self._chk(self.lib.ecad_block_ff(self._h, int(block), x.data_ptr(), out.data_ptr(), _stream_ptr()))
+        return out
+
+    def batch_context(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """(caption-projected text [Bt, T, D], additive mask bias [Bt, 1, T]) of the batch that has begun -- the block's ``encoder_hidden_states`` / mask."""
+        Bt, N, T = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.ecad_copy_batch_context(self._h, None, None, C.byref(Bt), C.byref(N), C.byref(T), _stream_ptr()))
+        ctx = torch.empty((Bt.value, T.value, self.dim), device=self.device, dtype=self.dtype)
+        bias = torch.empty((Bt.value, 1, T.value), device=self.device, dtype=torch.float32)
+        self._chk(self.lib.ecad_copy_batch_context(self._h, ctx.data_ptr(), bias.data_ptr(), None, None, None, _stream_ptr()))
+        return ctx, bias.to(self.dtype)
 
     def stats(self) -> dict:
         s = L.EcadStats()

@@ -1,5 +1,8 @@
 """Minimal NSGA-II with the reference's operator settings (``ecad/genetic/train_nsga2_base.py:234-242``):
-population 72, 4-point crossover p = 0.9, bit-flip mutation p = 0.05, seed 0, ask/tell with offline evaluation.
+population 72, ``PointCrossover(prob=0.9, n_points=4)``, ``BitflipMutation(prob=0.05)``, seed 0, ask/tell with offline evaluation.
+
+Mutation follows pymoo 0.6.1.3's semantics [ext]: ``prob`` is the chance that an offspring is mutated AT ALL; a mutated offspring flips
+each bit with ``prob_var``, which pymoo defaults to ``min(0.5, 1 / n_var)`` (1/1680 here) -- about 0.05 expected flips per child, not 84.
 
 Stand-in for ``pymoo==0.6.1.3`` (``requirements.txt:39``), which is not installed here: same algorithm family
 (constraint-dominated fast non-dominated sort, crowding distance, binary tournament, duplicate elimination) and
@@ -57,9 +60,11 @@ def crowding_distance(F: np.ndarray) -> np.ndarray:
 
 
 class NSGA2:
-    def __init__(self, pop_size: int = 72, n_var: int = 1680, crossover_prob: float = 0.9, n_points: int = 4, mutation_prob: float = 0.05, seed: int = 0):
+    def __init__(self, pop_size: int = 72, n_var: int = 1680, crossover_prob: float = 0.9, n_points: int = 4, mutation_prob: float = 0.05,
+                 mutation_prob_var: float | None = None, seed: int = 0):
         self.pop_size, self.n_var = pop_size, n_var
         self.crossover_prob, self.n_points, self.mutation_prob = crossover_prob, n_points, mutation_prob
+        self.mutation_prob_var = min(0.5, 1.0 / n_var) if mutation_prob_var is None else mutation_prob_var  # pymoo: Mutation.get_prob_var
         self.rng = np.random.default_rng(seed)
         self.n_gen = 0
         self.X = self.F = self.G = None  # survivors
@@ -103,6 +108,12 @@ class NSGA2:
             return a if self._rank[a] < self._rank[b] else b
         return a if self._cd[a] >= self._cd[b] else b
 
+    def _mutate(self, child: np.ndarray) -> np.ndarray:
+        """BitflipMutation(prob, prob_var) [ext]: with probability `prob` the individual is mutated, and then each bit flips with `prob_var`."""
+        if self.rng.random() <= self.mutation_prob:
+            child ^= self.rng.random(self.n_var) < self.mutation_prob_var
+        return child
+
     def _offspring(self) -> np.ndarray:
         seen = {x.tobytes() for x in self.X}
         out: list[np.ndarray] = []
@@ -117,7 +128,7 @@ class NSGA2:
                     swap[cuts[k] : (cuts[k + 1] if k + 1 < len(cuts) else self.n_var)] = True
                 p1[swap], p2[swap] = p2[swap].copy(), p1[swap].copy()
             for child in (p1, p2):
-                child ^= self.rng.random(self.n_var) < self.mutation_prob
+                child = self._mutate(child)
                 key = child.tobytes()
                 if key not in seen and len(out) < self.pop_size:  # duplicate elimination, as pymoo's default
                     seen.add(key)

@@ -4,9 +4,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         -m ecad_amd.genetic.train_nsga2_multi_gpu --name demo --generations 3 --seed-population tests/golden/ga_seed_population.npz
 
-Same on-disk contract as ``ecad/genetic/train_nsga2_single_gpu.py`` (gen_XXX/candidates/cand_YYY.json, scores.json,
-manager_config.json); evaluation happens in-process on every rank instead of three serial subprocesses.  Rank 0 owns
-ask/tell and the files; ranks exchange only the bit matrix (broadcast) and 2 float64 per candidate (all-gather).
+Same on-disk contract and the same resumable cycle as ``train_nsga2_single_gpu.py`` (gen_XXX/candidates/cand_YYY.json, scores.json,
+``gen_XXX/manager_config.json`` + ``gen_XXX/checkpoint.pkl`` written after every generation; ``--load-from <manager_config.json>`` resumes, and a run
+started by either trainer can be continued by the other); evaluation happens in-process on every rank instead of three serial subprocesses.
+Rank 0 owns ask/tell and the files; ranks exchange a 3-integer header (error flag, generation, rows), the bit matrix (broadcast) and 2 float64
+per candidate (all-gather).  A failure on rank 0 reaches every rank through the header, so the job exits instead of hanging in a collective.
 """
 from __future__ import annotations
 
@@ -20,6 +22,73 @@ from ecad_amd import distributed as D
 from ecad_amd.genetic.evaluate import engine_score_fn, evaluate_population
 from ecad_amd.genetic.nsga2 import NSGA2
 from ecad_amd.genetic.population_io_manager import PixArtPopulationIOManager
+
+
+def open_search(make_manager, manager_cls, n_var: int, population_size: int, load_from: Path | None, seed_bits: np.ndarray | None):
+    """Rank 0: (manager, algorithm) resumed from ``load_from`` (+ the checkpoint.pkl beside it) or started new, with generation 1 on disk and checkpointed."""
+    from ecad_amd.genetic.train_nsga2_single_gpu import checkpoint_manager_and_algorithm
+
+    if load_from is not None:
+        mgr = manager_cls.from_json(load_from)
+        algo = mgr.load_algorithm()
+        if algo.n_var != n_var:
+            raise ValueError(f"checkpoint searches {algo.n_var}-bit schedules, this model has {n_var}")
+        return mgr, algo
+    mgr = make_manager()
+    algo = NSGA2(pop_size=population_size, n_var=n_var, crossover_prob=0.9, n_points=4, mutation_prob=0.05, seed=0)
+    if seed_bits is not None:
+        seed_bits = np.asarray(seed_bits, dtype=np.bool_)
+        if seed_bits.ndim != 2 or seed_bits.shape[1] != n_var or len(seed_bits) == 0:
+            raise ValueError(f"seed population must be [rows >= 1, {n_var}] bits, got {seed_bits.shape}")
+        seed_bits = seed_bits[:population_size]
+    algo.setup(seed_bits)
+    mgr.generation_num = algo.n_gen
+    mgr.save_population(algo.ask(), algo.n_gen)
+    checkpoint_manager_and_algorithm(mgr, algo)
+    return mgr, algo
+
+
+def sharded_search(rank: int, world: int, open_fn, n_var: int, generations: int, evaluate) -> tuple:
+    """The generation loop.  Every generation: rank 0 takes the candidates waiting on disk (fewer than pop_size rows after duplicate elimination
+    or a short seed population are fine: the header carries the row count), all ranks evaluate their shard, rank 0 writes the scores, tells,
+    asks, writes the next generation and checkpoints -- one evaluation and one advance per generation, like the single-GPU cycle."""
+    from ecad_amd.genetic.train_nsga2_single_gpu import checkpoint_manager_and_algorithm
+
+    mgr = algo = None
+    hdr, msg = [0, 0, 0], ""
+    if rank == 0:
+        try:
+            mgr, algo = open_fn()
+        except Exception as e:  # noqa: BLE001  (reported on every rank below)
+            hdr, msg = [1, 0, 0], f"{type(e).__name__}: {e}"
+    if D.broadcast_ints(hdr, 3)[0]:
+        raise RuntimeError(f"rank 0 could not open the search{': ' + msg if msg else ''}")
+    for _ in range(generations):
+        X, hdr, msg = None, [0, 0, 0], ""
+        if rank == 0:
+            try:
+                X = np.asarray(algo.ask(), dtype=np.bool_)
+                if X.ndim != 2 or X.shape[1] != n_var or len(X) == 0:
+                    raise ValueError(f"population has shape {X.shape}, expected [1..{algo.pop_size}, {n_var}]")
+                hdr = [0, algo.n_gen, len(X)]
+            except Exception as e:  # noqa: BLE001
+                hdr, msg = [1, 0, 0], f"{type(e).__name__}: {e}"
+        err, gen, rows = D.broadcast_ints(hdr, 3)
+        if err:
+            raise RuntimeError(f"rank 0 failed before generation broadcast{': ' + msg if msg else ''}")
+        X = D.broadcast_population(X, (rows, n_var))
+        F = evaluate(X)
+        if rank == 0:
+            for i in range(len(X)):
+                mgr.write_evaluation(i, 1.0 - F[i, 0], X[i], gen)
+            Xd, Fd, Gd = mgr.ask()
+            algo.tell(Xd, Fd, Gd)
+            mgr.generation_num = algo.n_gen
+            mgr.save_population(algo.ask(), algo.n_gen)
+            checkpoint_manager_and_algorithm(mgr, algo)
+            print(f"generation {gen}: {rows} candidates, best (1-score) {Fd[:, 0].min():.4f}, min TMACs {Fd[:, 1].min():.3f}, evaluated on {world} rank(s)")
+    D.barrier()
+    return mgr, algo
 
 
 def main_flux(args, rank, world, local_rank):
@@ -52,13 +121,7 @@ def main_flux(args, rank, world, local_rank):
     score_fn = flux_engine_score_fn(eng, enc, pooled, lat, gh, gw, tm, gm, sig, nb, ns)
 
     pop = args.population_size
-    mgr = algo = None
-    if rank == 0:
-        mgr = FluxPopulationIOManager(args.name, args.populations_dir, args.benchmarks_dir, generation_num=1, population_size=pop, num_blocks=nb, num_single_blocks=ns,
-                                      height=args.height, width=args.width)
-        algo = NSGA2(pop_size=pop, n_var=n_var, seed=0)
-        algo.setup(None)
-    # every rank needs the closed-form MAC objective; a manager without directories would do, the formula only needs the geometry
+    # every rank needs the closed-form MAC objective; the formula only needs the geometry
     from ecad_amd.benchmark.compute_macs import flux_macs_per_step
 
     def macs_fn(bits):
@@ -66,22 +129,12 @@ def main_flux(args, rank, world, local_rank):
         return float(flux_macs_per_step(v[:, : nb * 3].reshape(steps, nb, 3), v[:, nb * 3:].reshape(steps, ns, 3), tokens=gh * gw, dim=heads * 128,
                                         text_tokens=T, joint_attention_dim=jd, pooled_dim=pd).sum()) / 1e12
 
-    for gen in range(1, args.generations + 1):
-        X = None
-        if rank == 0:
-            X = algo.ask()
-            mgr.generation_num = gen
-            mgr.save_population(X, gen)
-        X = D.broadcast_population(X, (pop, n_var))
-        F = evaluate_population(X, score_fn, macs_fn=macs_fn)
-        if rank == 0:
-            for i in range(len(X)):
-                mgr.write_evaluation(i, 1.0 - F[i, 0], X[i], gen)
-            Xd, Fd, Gd = mgr.ask()
-            algo.tell(Xd, Fd, Gd)
-            mgr.to_json()
-            print(f"generation {gen}: best (1-score) {Fd[:, 0].min():.4f}, min TMACs {Fd[:, 1].min():.3f}, evaluated on {world} rank(s)")
-    D.barrier()
+    def make_manager():
+        return FluxPopulationIOManager(args.name, args.populations_dir, args.benchmarks_dir, generation_num=1, population_size=pop, num_blocks=nb, num_single_blocks=ns,
+                                       height=args.height, width=args.width)
+
+    sharded_search(rank, world, lambda: open_search(make_manager, FluxPopulationIOManager, n_var, pop, args.load_from, None), n_var, args.generations,
+                   lambda X: evaluate_population(X, score_fn, macs_fn=macs_fn))
 
 
 def main():
@@ -90,6 +143,7 @@ def main():
     ap.add_argument("--populations-dir", type=Path, default=Path("results/genetic/populations"))
     ap.add_argument("--benchmarks-dir", type=Path, default=Path("results/benchmark/genetic/populations"))
     ap.add_argument("--seed-population", type=Path, default=None, help="npz with packed 'bits' [pop, 210]")
+    ap.add_argument("--load-from", type=Path, default=None, help="gen_XXX/manager_config.json of an existing run (either trainer's): resume from its checkpoint.pkl")
     ap.add_argument("--population-size", type=int, default=72)
     ap.add_argument("--generations", type=int, default=1)
     ap.add_argument("--images", type=int, default=4, help="prompts per candidate evaluation (synthetic embeddings)")
@@ -121,30 +175,15 @@ def main():
     solver.set_timesteps(steps)
     score_fn = engine_score_fn(eng, enc.cuda(), mask.cuda(), lat.cuda(), solver.timesteps.numpy().astype(np.float32), solver.coefficient_table())
 
-    mgr = algo = None
-    if rank == 0:
-        mgr = PixArtPopulationIOManager(args.name, args.populations_dir, args.benchmarks_dir, generation_num=1, population_size=args.population_size, num_blocks=blocks)
-        algo = NSGA2(pop_size=args.population_size, n_var=n_var, seed=0)
-        X0 = None
-        if args.seed_population is not None:
-            X0 = np.unpackbits(np.load(args.seed_population)["bits"], axis=1)[:, :n_var].astype(np.bool_)[: args.population_size]
-        algo.setup(X0)
-    for gen in range(1, args.generations + 1):
-        X = None
-        if rank == 0:
-            X = algo.ask()
-            mgr.generation_num = gen
-            mgr.save_population(X, gen)
-        X = D.broadcast_population(X, (args.population_size, n_var))
-        F = evaluate_population(X, score_fn, steps, blocks)
-        if rank == 0:
-            for i in range(len(X)):
-                mgr.write_evaluation(i, 1.0 - F[i, 0], X[i], gen)
-            Xd, Fd, Gd = mgr.ask()
-            algo.tell(Xd, Fd, Gd)
-            mgr.to_json()
-            print(f"generation {gen}: best (1-score) {Fd[:, 0].min():.4f}, min TMACs {Fd[:, 1].min():.3f}, evaluated on {world} rank(s)")
-    D.barrier()
+    seed_bits = None
+    if rank == 0 and args.seed_population is not None and args.load_from is None:
+        seed_bits = np.unpackbits(np.load(args.seed_population)["bits"], axis=1)[:, :n_var].astype(np.bool_)
+
+    def make_manager():
+        return PixArtPopulationIOManager(args.name, args.populations_dir, args.benchmarks_dir, generation_num=1, population_size=args.population_size, num_blocks=blocks)
+
+    sharded_search(rank, world, lambda: open_search(make_manager, PixArtPopulationIOManager, n_var, args.population_size, args.load_from, seed_bits), n_var,
+                   args.generations, lambda X: evaluate_population(X, score_fn, steps, blocks))
 
 
 if __name__ == "__main__":

@@ -108,7 +108,7 @@ class PixArtAlphaPipeline:
                                  "aspect_ratio": torch.tensor([[float(height / width)]]).repeat(reps * B, 1)}
             tr.engine.set_added_cond(added_cond_kwargs["resolution"], added_cond_kwargs["aspect_ratio"])
 
-        if self.native_loop and cfg_on:
+        if self.native_loop and cfg_on and not getattr(tr, "uses_plugins", False):  # a schedule with compute plug-ins calls back into Python: per-step path
             lat = tr.engine.run_schedule(enc, mask, latents.float(), timesteps.numpy().astype(np.float32), self.scheduler.coefficient_table(), guidance_scale, use_graph=True)
             latents = lat.to(tr.dtype)
             if callback is not None:

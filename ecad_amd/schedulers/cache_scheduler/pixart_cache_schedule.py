@@ -39,6 +39,19 @@ class PixArtCacheSchedule(CacheSchedule):
     def get_custom_compute_ff(self, block_num: str) -> dict:
         return self.schedule[self.curr_step][str(block_num)].get("custom_compute_ff", {})
 
+    def custom_component_mask(self) -> np.ndarray:
+        """[blocks, 3] (attn1, attn2, ff): 1 where SOME step names a compute function other than the cached default for that block
+        (``custom_compute_attn`` covers attn1 and attn2, ``custom_compute_ff`` covers ff) -- those components run through the registered
+        Python callables (``ecad_set_custom_components``); at steps that name the default, the default callable is what gets called."""
+        mask = np.zeros((self.num_blocks, 3), dtype=np.uint8)
+        for per_block in self.schedule.values():
+            for block_num, comp in per_block.items():
+                for key, default, cols in (("custom_compute_attn", "compute_attn_cached", (0, 1)), ("custom_compute_ff", "compute_ff_cached", (2,))):
+                    name = (comp.get(key) or {}).get("name")
+                    if name is not None and name.lower() != default:
+                        mask[int(block_num), list(cols)] = 1
+        return mask
+
     def uses_only_native_compute(self) -> bool:
         """True when every block uses the default cached attn/ff functions (the HIP path)."""
         for per_block in self.schedule.values():

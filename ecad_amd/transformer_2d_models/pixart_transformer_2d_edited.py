@@ -164,14 +164,44 @@ class PixArtTransformer2DEdited:
             raise ValueError("A DiTScheduler object must be provided.")
         if cache_schedule is None:
             raise ValueError("A cache schedule is required: the native engine always runs the cached block path.")
-        if not cache_schedule.uses_only_native_compute():
-            raise ValueError("schedule names a custom_compute_attn/custom_compute_ff other than the native cached functions")
         if cache_schedule.num_blocks != self.config.num_layers:
             raise ValueError(f"schedule has {cache_schedule.num_blocks} blocks, model has {self.config.num_layers}")
+        from ecad_amd.transformer_blocks.cached_transformer_block import CachedTransformerBlock
+        from ecad_amd.transformer_blocks.custom_attn_ff import ComputeAttnRegistry, ComputeFFRegistry
+
+        # every function the schedule names must be registered NOW (the reference asserts at the first call, cached_transformer_block.py:139,158)
+        for per_block in cache_schedule.schedule.values():
+            for comp in per_block.values():
+                for key, reg in (("custom_compute_attn", ComputeAttnRegistry), ("custom_compute_ff", ComputeFFRegistry)):
+                    name = (comp.get(key) or {}).get("name")
+                    if name is not None and reg.get(name, True) is None:
+                        raise ValueError(f"Function {name} not found in registry ({reg.__name__})")
         self.dit_scheduler = dit_scheduler
         self.cache_schedule = cache_schedule
+        self.transformer_blocks = [CachedTransformerBlock(self, i) for i in range(self.config.num_layers)]
         self.engine.set_schedule(cache_schedule.to_numpy())
+        mask = cache_schedule.custom_component_mask()
+        # blocks that name a plug-in run as native sub-ops around the registered Python callable, per step; all others stay compiled into the engine
+        self.engine.set_custom_components(mask if mask.any() else None, self._run_component)
+        self.uses_plugins = bool(mask.any())
+        self._ctx = None
         self._begun_key = None
+
+    def _run_component(self, step: int, block: int, component: int, x: torch.Tensor) -> torch.Tensor:
+        """ecad_set_custom_components callback: what CachedTransformerBlock.forward does at the three call sites (:231-239,282-288,313)."""
+        blk = self.transformer_blocks[block]
+        if component == 2:
+            return blk.compute_ff(x)
+        if component == 0:
+            return blk.compute_attn("attn1", x, encoder_hidden_states=None, attention_mask=None)
+        ctx, bias = self.batch_context()
+        return blk.compute_attn("attn2", x, encoder_hidden_states=ctx, attention_mask=bias)
+
+    def batch_context(self):
+        """(encoder_hidden_states after caption projection [Bt, T, D], encoder attention bias [Bt, 1, T]) of the batch that has begun."""
+        if self._ctx is None:
+            self._ctx = self.engine.batch_context()
+        return self._ctx
 
     def load_state_dict(self, state: dict[str, torch.Tensor], strict: bool = True):
         self.engine.load_state_dict(state)
@@ -228,7 +258,8 @@ class PixArtTransformer2DEdited:
     # -- reference: reset_cache (:155-158) ------------------------------------------------------
     def reset_cache(self) -> None:
         self.engine.reset_cache()
-        self._begun_key = None
+        for blk in getattr(self, "transformer_blocks", []):
+            blk.reset_cache()
 
     def to(self, *args, **kwargs):
         return self
@@ -268,6 +299,9 @@ class PixArtTransformer2DEdited:
                 self.engine.set_added_cond(added_cond_kwargs["resolution"], added_cond_kwargs["aspect_ratio"])
             self.engine.begin_image_batch(encoder_hidden_states, enc_mask, hidden_states.shape[-2], hidden_states.shape[-1])
             self._begun_key = key
+            self._ctx = None
+            for blk in self.transformer_blocks:
+                blk.reset_cache()
         out = self.engine.step(step, hidden_states, timestep)
         if not return_dict:
             return (out,)

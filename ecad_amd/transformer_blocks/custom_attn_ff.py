@@ -1,12 +1,21 @@
 """Per-block compute plug-in registries.
 
-Same surface as the reference (``ecad/transformer_blocks/custom_attn_ff.py:6-59``):
-``ComputeAttnRegistry.register`` / ``.get(name)`` keyed by lower-cased function name,
-defaults ``compute_attn_cached`` / ``compute_ff_cached``.  In this engine the two
-defaults are NATIVE: they are what the HIP engine implements for every block, and the
-registered Python callables are markers (calling one raises -- there is no CPU path).
-A schedule that names any other function cannot run on the native path and is
-rejected at ``ecad_set_schedule`` time by the host wrapper.
+Same surface as the reference (``ecad/transformer_blocks/custom_attn_ff.py:6-59``): ``ComputeAttnRegistry.register`` /
+``.get(name)`` keyed by lower-cased function name, defaults ``compute_attn_cached`` / ``compute_ff_cached`` (registered by
+``ecad_amd.transformer_blocks.cached_transformer_block``, as the reference's block module registers them).
+
+A registered function has the reference's signature and receives the block view of the native engine
+(``CachedTransformerBlock``: ``block_num``, ``cache_schedule``, ``cached_*_output``, and ``attn1`` / ``attn2`` / ``ff`` that run the
+HIP sub-layers on device tensors):
+
+    @ComputeFFRegistry.register
+    def my_ff(block, norm_hidden_states, **kwargs) -> torch.Tensor: ...
+    @ComputeAttnRegistry.register
+    def my_attn(block, attn, hidden_states, encoder_hidden_states, attention_mask, **kwargs) -> torch.Tensor: ...
+
+A schedule that names only the defaults never leaves the device (the gate is compiled into the engine's op lists); a block whose
+schedule names anything else is driven through these Python callables in per-step mode (``ecad_set_custom_components``).
+There is no CPU path: the sub-layers the callables can reach are the engine's.
 """
 from __future__ import annotations
 
@@ -38,6 +47,7 @@ class ComputeRegistry:
 
     @classmethod
     def is_native(cls, key: str | None) -> bool:
+        """True for the names the engine compiles into its op lists (absent name or the cached default)."""
         return key is None or key.lower() == getattr(cls, "DEFAULT")
 
 
@@ -51,16 +61,6 @@ class ComputeFFRegistry(ComputeRegistry):
     DEFAULT = "compute_ff_cached"
 
 
-def _native_only(name: str):
-    def marker(*args, **kwargs):
-        raise RuntimeError(
-            f"{name} is implemented natively inside the HIP engine (libecad_hip.so); "
-            "it is not callable from Python and has no CPU fallback."
-        )
+from ecad_amd.transformer_blocks import cached_transformer_block as _defaults  # noqa: E402
 
-    marker.__name__ = name
-    return marker
-
-
-ComputeAttnRegistry.register(_native_only("compute_attn_cached"))
-ComputeFFRegistry.register(_native_only("compute_ff_cached"))
+_defaults._register_defaults()

@@ -65,6 +65,10 @@ typedef struct EcadStats {
   int64_t workspace_bytes;
   int32_t graph_nodes;           /* kernels captured in the whole-schedule hipGraph (0 = not built) */
   int32_t launches_per_batch;
+  int32_t plan_builds;           /* schedule -> op-list lowerings since ecad_create (a (schedule, shapes) seen recently is served from the plan-set cache) */
+  int32_t graph_captures;        /* hipGraph captures + instantiations since ecad_create */
+  int32_t dynamic_step_plans;    /* ecad_step calls that ran an ad-hoc plan because the usable caches differed from the static resolution (reset_cache mid-run) */
+  int32_t plan_sets_cached;      /* plan sets (with their graphs) parked in the LRU right now */
 } EcadStats;
 
 typedef struct EcadEngine EcadEngine;
@@ -132,7 +136,29 @@ int ecad_run_schedule(EcadEngine* e, int Bt, int H, int W, const void* enc_dev, 
                       float* latents_dev, const float* timesteps_host, const float* solver_coef_host,
                       float guidance_scale, int use_graph, void* stream);
 
-int ecad_reset_cache(EcadEngine* e);               /* reset_cache (:155-158) */
+/* reset_cache (:155-158; block level cached_transformer_block.py:120-123): every cached attn1 / attn2 / ff output is dropped.  A batch that has begun
+ * stays begun (its hoisted caption projection / text K/V are recomputations, not caches); the next ecad_step recomputes every component it finds
+ * no usable cache for ("flag false + empty cache => recompute", :340-347), exactly as the reference's blocks do after a mid-run reset. */
+int ecad_reset_cache(EcadEngine* e);
+
+/* ---- user compute plug-ins ------------------------------------------------------------------------------------------------
+ * Replaces CachedTransformerBlock.compute_attn / compute_ff dispatch (cached_transformer_block.py:125-165): a schedule may name, per block, a
+ * registered function `(block, attn, hidden, enc, mask, **kw) -> Tensor` / `(block, norm_hidden, **kw) -> Tensor` instead of the cached defaults.
+ * mask [blocks][3] (attn1, attn2, ff): 1 = this component is computed by `fn` in ecad_step mode.  For such a component the engine produces the
+ * sub-layer input exactly as the block does (LayerNorm + adaLN modulate for attn1 / ff; the residual stream itself for attn2, :264-267) into
+ * io_in_dev, calls fn on the launch stream's host thread, and then applies gate * out + hidden (:243-246,289,317-320) to what fn left in
+ * io_out_dev.  Caching is the plug-in's business, as in the reference (the defaults are plug-ins there too).  io_in_dev / io_out_dev:
+ * caller-owned [max_batch * max_tokens, D] buffers of the engine dtype.  fn returns 0 or non-zero to abort the step (ECAD_E_INVALID).
+ * ecad_run_schedule (whole-loop hipGraph) refuses with ECAD_E_UNSUPPORTED while any component is routed to a plug-in.  mask NULL / all zero: off. */
+typedef int (*EcadComponentFn)(void* user, int step_idx, int block, int component, const void* in_dev, void* out_dev, int Bt, int N, int D, void* stream);
+int ecad_set_custom_components(EcadEngine* e, const uint8_t* mask, int blocks, EcadComponentFn fn, void* user, void* io_in_dev, void* io_out_dev);
+/* The block's native sub-layers for use inside a plug-in = the reference's `self.attn1(h)`, `self.attn2(h, enc, mask)` (which: 1 | 2; attn2 uses the
+ * text K/V and mask bias of the batch that has begun) and `self.ff(h)`: x_dev, out_dev [Bt * N, D] engine dtype; bias only, no gate, no cache. */
+int ecad_block_attn(EcadEngine* e, int block, int which, const void* x_dev, void* out_dev, void* stream);
+int ecad_block_ff(EcadEngine* e, int block, const void* x_dev, void* out_dev, void* stream);
+/* What the block passes as `encoder_hidden_states` / `encoder_attention_mask` (pixart_transformer_2d_edited.py:255-291,315-321): the caption-projected
+ * text [Bt * T, D] (engine dtype) and the additive bias [Bt * T] float32 (0 keep / -10000 discard) of the batch that has begun; either may be NULL. */
+int ecad_copy_batch_context(EcadEngine* e, void* ctx_out_dev, float* bias_out_dev, int* Bt, int* N, int* T, void* stream);
 int ecad_cache_stats(EcadEngine* e, EcadStats* s); /* feeds the roofline accounting */
 
 /* Per-kernel-class device time of the most recent NON-graph ecad_run_schedule/ecad_step when

@@ -302,8 +302,9 @@ class FluxOracle:
 # FlowMatchEulerDiscreteScheduler with dynamic shifting + the FluxPipeline loop [ext]
 # (the loop the reference drives from ecad/image_generators/flux_image_generator.py:330-360)
 # --------------------------------------------------------------------------
-def flow_match_sigmas(num_steps: int, image_seq_len: int, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.16) -> np.ndarray:
-    """sigmas[0..num_steps] (last = 0): linspace(1, 1/n, n) shifted by mu(image_seq_len) (calculate_shift, time_shift)."""
+def flow_match_sigmas(num_steps: int, image_seq_len: int, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15) -> np.ndarray:
+    """sigmas[0..num_steps] (last = 0): linspace(1, 1/n, n) shifted by mu(image_seq_len) (calculate_shift, time_shift).  Defaults = FLUX.1-dev's
+    scheduler_config.json [ext] (max_shift 1.15), which is what diffusers 0.30.3's FluxPipeline passes; 1.16 is only its helper's unused default."""
     sig = np.linspace(1.0, 1.0 / num_steps, num_steps)
     m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
     mu = image_seq_len * m + (base_shift - m * base_seq_len)

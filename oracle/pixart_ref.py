@@ -241,6 +241,14 @@ class PixArtOracle:
 
     # -- the cache gate (cached_transformer_block.py:326-391) ----------------
     def _gated(self, step: int, block: int, comp: str, recompute: bool, fn):
+        # user compute plug-in for this (block, component) (cached_transformer_block.py:125-165): called with the default gated evaluation and
+        # the bare sub-layer, e.g. lambda cached, fresh: 2 * cached().  Set by tests through ``self.plugins[(block, comp)]``.
+        plug = getattr(self, "plugins", {}).get((block, comp))
+        if plug is not None:
+            return self.q(plug(lambda: self._gated_default(step, block, comp, recompute, fn), fn))
+        return self._gated_default(step, block, comp, recompute, fn)
+
+    def _gated_default(self, step: int, block: int, comp: str, recompute: bool, fn):
         key = (block, comp)
         if recompute or key not in self.cache.entries:
             out = fn()

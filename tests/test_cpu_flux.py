@@ -1,6 +1,8 @@
 """CPU tests for the FLUX row: oracle vs the reference's own known answers and captured vectors,
 host-side schedule mirror, oracle self-consistency.  No GPU."""
 import json
+import math
+import os
 from pathlib import Path
 
 import numpy as np
@@ -128,7 +130,7 @@ def test_flux_oracle_properties():
     o2 = flux_ref.FluxOracle(cfg, w)
     v_single = o2.forward(lat[:1], enc[:1], pooled[:1], t[:1], g[:1], ids, 0, on_f, on_s)
     assert torch.allclose(v_single, v0[:1], atol=1e-5)
-    # scheduler: sigmas decrease from ~1 to 0; mu shift at 4096 tokens is 1.16
+    # scheduler: sigmas decrease from ~1 to 0; mu shift at 4096 tokens is 1.15 (FLUX.1-dev scheduler_config.json)
     sig = flux_ref.flow_match_sigmas(20, 4096)
     assert sig.shape == (21,) and sig[-1] == 0 and (np.diff(sig) < 0).all() and abs(sig[0] - 1.0) < 1e-6
     tm, gm = flux_ref.model_scalars(sig, 5.0, torch.bfloat16)
@@ -164,9 +166,24 @@ def test_flux_host_surface_without_gpu():
     packed = FluxPipeline._pack_latents(x)
     assert packed.shape == (2, 24, 64) and torch.equal(FluxPipeline._unpack_latents(packed, 64, 96), x)
     assert torch.equal(FluxPipeline._prepare_latent_image_ids(4, 6, "cpu", torch.float32), flux_ref.latent_image_ids(4, 6))
-    assert abs(calculate_shift(256) - 0.5) < 1e-12 and abs(calculate_shift(4096) - 1.16) < 1e-12
+    assert abs(calculate_shift(256) - 0.5) < 1e-12 and abs(calculate_shift(4096) - 1.15) < 1e-12
     sig = flow_match_sigmas(20, 4096)
     assert np.array_equal(sig, flux_ref.flow_match_sigmas(20, 4096))
+    # diffusers 0.30.3 FluxPipeline: mu = calculate_shift(seq, scheduler.config.base_image_seq_len, max_image_seq_len, base_shift, max_shift) with FLUX.1-dev's
+    # scheduler_config.json (max_shift 1.15) -> sigma_1 at 1024^2 = e^1.15 / (e^1.15 + 1/0.95 - 1); a checkpoint directory's own config wins
+    assert abs(float(sig[1]) - math.exp(1.15) / (math.exp(1.15) + 1 / 0.95 - 1)) < 1e-6
+    import tempfile
+
+    from ecad_amd.pipelines.flow_match import load_scheduler_config
+
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "scheduler"))
+        json.dump({"max_shift": 1.3, "base_shift": 0.4, "shift": 3.0}, open(os.path.join(d, "scheduler", "scheduler_config.json"), "w"))
+        c = load_scheduler_config(d)
+        assert c == {"base_image_seq_len": 256, "max_image_seq_len": 4096, "base_shift": 0.4, "max_shift": 1.3}
+        assert abs(float(flow_match_sigmas(20, 4096, c)[1]) - math.exp(1.3) / (math.exp(1.3) + 1 / 0.95 - 1)) < 1e-6
+        assert FluxPipeline.from_pretrained(d).scheduler_config == c
+    assert load_scheduler_config("black-forest-labs/FLUX.1-dev")["max_shift"] == 1.15
     t, g = model_scalars(sig, 5.0, torch.bfloat16)
     to, go = flux_ref.model_scalars(sig, 5.0, torch.bfloat16)
     assert np.array_equal(t, to.numpy()) and g == float(go[0]) == 4992.0
@@ -202,4 +219,4 @@ def test_flow_match_schedule_and_euler_are_exact_on_straight_paths():
             v = (x - x0) / sig[i]  # the exact velocity eps - x0 along the path through (x0, current x)
             x = x + (sig[i + 1] - sig[i]) * v
         assert np.abs(x - x0).max() < 1e-12
-    assert abs(calculate_shift(256) - 0.5) < 1e-12 and abs(calculate_shift(4096) - 1.16) < 1e-12  # the two anchors of the linear shift law
+    assert abs(calculate_shift(256) - 0.5) < 1e-12 and abs(calculate_shift(4096) - 1.15) < 1e-12  # the two anchors of the linear shift law

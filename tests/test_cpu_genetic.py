@@ -262,3 +262,84 @@ def test_single_gpu_trainer_cycle_checkpoint_and_resume(tmp_path, capsys):
     out = capsys.readouterr().out
     assert "generation 6: 8 candidate schedule(s)" in out and "stand-in for ImageReward" in out
     assert (b / "p/run/gen_006/candidates/cand_000.json").exists() and not (b / "b/run/gen_006").exists()
+
+
+def test_bitflip_mutation_follows_pymoo_semantics():
+    """BitflipMutation(prob=0.05) in pymoo 0.6.1.3 [ext] (reference train_nsga2_base.py:238): `prob` = chance that an offspring is mutated at all,
+    per-bit rate prob_var = min(0.5, 1 / n_var).  Expected flips per child = 0.05 * 1680 / 1680 = 0.05 -- not 0.05 * 1680 = 84."""
+    from ecad_amd.genetic.nsga2 import NSGA2
+
+    algo = NSGA2(pop_size=72, n_var=1680, seed=3)
+    assert algo.mutation_prob == 0.05 and algo.mutation_prob_var == 1.0 / 1680
+    assert NSGA2(n_var=1).mutation_prob_var == 0.5  # pymoo caps the per-bit rate at 0.5
+    n = 40000
+    flips = np.array([int(algo._mutate(np.zeros(1680, dtype=bool)).sum()) for _ in range(n)])
+    touched = (flips > 0).mean()
+    # P(mutated and at least one bit flips) = 0.05 * (1 - (1 - 1/1680)^1680) = 0.0316; mean flips = 0.05
+    assert abs(flips.mean() - 0.05) < 0.006 and abs(touched - 0.05 * (1 - (1 - 1 / 1680) ** 1680)) < 0.004
+    # both rates are exposed, as in pymoo: prob = 1 mutates every child, prob_var sets the per-bit rate
+    hot = NSGA2(n_var=1680, mutation_prob=1.0, mutation_prob_var=0.05, seed=1)
+    m = np.mean([hot._mutate(np.zeros(1680, dtype=bool)).sum() for _ in range(200)])
+    assert 80 < m < 88
+
+
+def _search_worker(rank: int, world: int, port: int, root: str, mode: str):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    from ecad_amd import distributed as D
+    from ecad_amd.genetic import train_nsga2_multi_gpu as M
+    from ecad_amd.genetic.evaluate import evaluate_population
+    from ecad_amd.genetic.population_io_manager import PixArtPopulationIOManager
+
+    D.init("gloo")
+    root = Path(root)
+    n_var, pop = 1680, 8
+    seed = np.unpackbits(np.load(GOLD / "ga_seed_population.npz")["bits"], axis=1)[:, :n_var].astype(bool)
+
+    def mk(name):
+        return lambda: PixArtPopulationIOManager(name, root / "p", root / "b", generation_num=1, population_size=pop)
+
+    def ev(X):
+        return evaluate_population(X, _stub_score)
+
+    def search(name, gens, load_from=None, seed_bits=seed):
+        return M.sharded_search(rank, world, lambda: M.open_search(mk(name), PixArtPopulationIOManager, n_var, pop, load_from, seed_bits), n_var, gens, ev)
+
+    if mode == "resume":
+        search("whole", 3)
+        search("parts", 1)
+        search("parts", 2, load_from=root / "p/parts/gen_002/manager_config.json")
+    elif mode == "short_seed":  # 5 seed rows for a population of 8: generation 1 has 5 candidates and nobody hangs in the broadcast
+        search("short", 2, seed_bits=seed[:5])
+    elif mode == "rank0_fails":
+        try:
+            search("broken", 1, load_from=root / "p/none/gen_001/manager_config.json")
+        except RuntimeError as e:
+            (root / f"err{rank}.txt").write_text(str(e))
+    dist.destroy_process_group()
+
+
+def test_multi_gpu_trainer_resumes_and_never_hangs_gloo(tmp_path):
+    """World 2 over gloo.  (1) Three generations in one go == one generation, then a fresh call resumed from gen_002/manager_config.json +
+    checkpoint.pkl for two more: same candidates on disk.  (2) A seed population shorter than --population-size runs (the header carries the
+    row count).  (3) Rank 0 failing to open the search raises on EVERY rank instead of leaving the others in a collective."""
+    from ecad_amd.genetic.population_io_manager import PixArtPopulationIOManager
+
+    for mode in ("resume", "short_seed", "rank0_fails"):
+        mp.spawn(_search_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    a = PixArtPopulationIOManager.from_json(tmp_path / "p/whole/gen_004/manager_config.json")
+    b = PixArtPopulationIOManager.from_json(tmp_path / "p/parts/gen_004/manager_config.json")
+    assert a.generation_num == b.generation_num == 4
+    for g in (1, 2, 3, 4):
+        assert np.array_equal(a.load_population_vectors(g), b.load_population_vectors(g)), g
+    assert (tmp_path / "p/parts/gen_004/checkpoint.pkl").exists() and (tmp_path / "p/whole/gen_002/checkpoint.pkl").exists()
+    assert len(list((tmp_path / "p/short/gen_001/candidates").glob("cand_*.json"))) == 5
+    assert len(list((tmp_path / "p/short/gen_003/candidates").glob("cand_*.json"))) == 8
+    assert "could not open the search" in (tmp_path / "err0.txt").read_text() and "could not open the search" in (tmp_path / "err1.txt").read_text()
+    # the files are the single-GPU trainer's: it continues the sharded run from its checkpoint
+    from ecad_amd.genetic import train_nsga2_single_gpu as T
+
+    mgr, algo = T.run(T.parse_args(["--image-generator", "PixArtAlphaImageGenerator", "--all-populations-dir", str(tmp_path / "p"), "--all-benchmarks-dir", str(tmp_path / "b"),
+                                    "--population-size", "8", "--load-from", str(tmp_path / "p/parts/gen_004/manager_config.json"), "--num-cycles", "1"]), score_fn=_stub_score)
+    assert mgr.generation_num == algo.n_gen == 5

@@ -105,8 +105,25 @@ def test_registries_and_defaults():
     assert ComputeAttnRegistry.get(None).__name__ == "compute_attn_cached"
     assert ComputeFFRegistry.get("COMPUTE_FF_CACHED").__name__ == "compute_ff_cached"
     assert ComputeAttnRegistry.get("nope", True) is None
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # the defaults are real callables on an engine block (tests/test_gpu_plugins.py); anything else: loud
+        ComputeAttnRegistry.get(None)(object(), "attn1", None, None, None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        ComputeAttnRegistry.get(None)()
+        ComputeFFRegistry.get(None)(object(), None)
+
+    @ComputeFFRegistry.register
+    def My_Plugin_FF(block, norm_hidden_states, **kw):
+        return norm_hidden_states
+
+    assert ComputeFFRegistry.get("my_plugin_ff") is My_Plugin_FF and not ComputeFFRegistry.is_native("my_plugin_ff") and ComputeFFRegistry.is_native(None)
+    from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
+
+    sched = PixArtCacheSchedule.from_numpy(np.ones((2, 3, 3), bool), "m", num_blocks=3, num_inference_steps=2)
+    assert not sched.custom_component_mask().any() and sched.uses_only_native_compute()
+    sched.schedule[1]["2"]["custom_compute_ff"] = {"name": "my_plugin_ff", "kwargs": {"a": 1}}
+    sched.schedule[0]["0"]["custom_compute_attn"] = {"name": "COMPUTE_ATTN_CACHED"}  # the default by name is still native
+    assert sched.custom_component_mask().tolist() == [[0, 0, 0], [0, 0, 0], [0, 0, 1]] and not sched.uses_only_native_compute()
+    sched.schedule[0]["1"]["custom_compute_attn"] = {"name": "other"}
+    assert sched.custom_component_mask().tolist() == [[0, 0, 0], [1, 1, 0], [0, 0, 1]]
     assert PipelineRegistry.get("pixart_alpha").__name__ == "PixArtAlphaPipeline"
     with pytest.raises(NotImplementedError):
         PipelineRegistry.get("tgate")
@@ -199,3 +216,15 @@ def test_compute_macs_cli_geometry_follows_the_weights(tmp_path, capsys):
         CM.annotate_schedule_file(f, recompute_existing=True)
     flags = {a.dest for a in CM.get_argparser()._actions}
     assert {"image_generator", "input_dir", "recompute_existing", "print_detailed"} <= flags
+
+
+def test_inference_cli_guidance_scale_follows_the_reference(tmp_path):
+    """reference inference.py:208-214: ``--guidance-scale`` is forwarded to FLUX and refused for the PixArt generators (CFG 4.5 is fixed there) -- it is
+    never silently dropped.  The refusal happens before any engine is created, so it is checkable without a GPU."""
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+    from ecad_amd.inference import inference
+
+    with pytest.raises(ValueError, match="does not support guidance scale"):
+        inference.main(["PixArtAlphaImageGenerator", "-i", str(tmp_path), "--guidance-scale", "3.0"])
+    inference._check_guidance(get_image_generator_type("FluxImageGenerator"), 3.0)  # FLUX: accepted
+    inference._check_guidance(get_image_generator_type("PixArtSigmaImageGenerator"), None)  # flag absent: fine

@@ -272,6 +272,7 @@ template <typename T> class EngineT : public EngineBase {
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
+    if (const char* l = getenv("ECAD_GEMM_SCHED")) gemm_variant = atoi(l);
     if (const char* l = getenv("ECAD_PLAN_CACHE")) plan_lru_cap = (size_t)(atoi(l) > 0 ? atoi(l) : 0);
     custom_mask.assign((size_t)cfg.num_layers * 3, 0);
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
@@ -655,6 +656,7 @@ template <typename T> class EngineT : public EngineBase {
     o.kind = Op<T>::GEMM; o.cls = cls; o.epi = epi;
     o.g.A = A; o.g.W = W; o.g.bias = bias; o.g.C = C; o.g.resid = nullptr; o.g.gate_table = nullptr; o.g.gate_mod = nullptr;
     o.g.gate_mod_stride = 0; o.g.rows_per_batch = N > 0 ? N : 1; o.g.M = M; o.g.N = Nn; o.g.K = K; o.g.lda = lda; o.g.ldw = K; o.g.ldc = ldc; o.g.ldr = ldc;
+    o.g.variant = gemm_variant;
     o.flops = 2.0 * M * (double)Nn * K;
     o.bytes = ((double)M * K + (double)Nn * K + (double)M * Nn) * sizeof(T);
     return o;
@@ -934,6 +936,7 @@ template <typename T> class EngineT : public EngineBase {
   // kernel for long K with a plain tile count (FF2); 8 mixed waves for the N = 1152 RMW epilogues and QKV.
   // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
   int gemm_impl_cls[KC_COUNT];
+  int gemm_variant = 1;  // K-loop schedule (GemmArgs::variant); env ECAD_GEMM_SCHED=0: the round-1 schedule
   bool g2_attr[4][KC_COUNT] = {};
   bool split_qkv = true;  // env ECAD_SPLIT_QKV=0 keeps the single 3D-wide launch
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
@@ -1372,6 +1375,7 @@ template <typename T> class EngineT : public EngineBase {
     GemmArgs<T> g{};
     g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
     g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K; g.lda = K; g.ldw = K; g.ldc = Nn; g.ldr = Nn;
+    g.variant = gemm_variant;
     if (epi == EPI_BIAS_CACHE_RESID && !resid) return fail(ECAD_E_INVALID, "epilogue 3 needs resid");
     int rc = launch_gemm(epi, KC_GEMM_SMALL, g, s);
     if (rc) return rc;
@@ -1389,6 +1393,8 @@ template <typename T> class EngineT : public EngineBase {
     g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
     g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K;
     g.lda = lda > 0 ? (int)lda : K; g.ldw = K; g.ldc = ldc > 0 ? (int)ldc : Nn; g.ldr = Nn;
+    g.variant = (kernel >> 8) ? (kernel >> 8) - 1 : gemm_variant;  // bits 8+ of `kernel`: 1 + schedule variant to force (A/B in one process); 0 = the engine's
+    kernel &= 0xff;
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
     if (kernel == 3) {
       if (Nn % 128) return fail(ECAD_E_UNSUPPORTED, "gemm.h tiles need N %% 128 == 0, got %d", Nn);

@@ -33,6 +33,8 @@ template <typename T> struct GemmArgs {
   int rows_per_batch;       // image tokens per sample (row -> b)
   int M, N, K;
   int lda, ldw, ldc, ldr;
+  int variant;  // K-loop schedule of gemm3s.h / gemm2w.h: 0 = every wave issues its LDS-DMA pieces in one block after the barrier (round 1),
+                // 1 = staggered: pieces interleaved one per MFMA group, waves 0-3 in the first half of the step, waves 4-7 in the second
 };
 
 constexpr int GEMM_BK = 64;
@@ -158,11 +160,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
   // ---- epilogue 1: acc[i][j][r] = C[m = wm*WTM+16i+l15][n = wn*WTN+16j+4g+r]; bias/activation, round to T,
   // pack 4 consecutive n -> 8-byte LDS write into the row-major C tile (reuses the operand buffers).
   T* ctile = reinterpret_cast<T*>(smem);
+  f32x4 bvs[FN];  // one batch of loads (gemm3s.h: hipcc otherwise serializes a load -> wait -> use round trip per column group)
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + 16 * j + 4 * g);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int nl = wn * WTN + 16 * j + 4 * g;
-    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+    const f32x4 bv = bvs[j];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int ml = wm * WTM + 16 * i + l15;

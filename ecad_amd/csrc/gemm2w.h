@@ -76,6 +76,25 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     }
   };
 
+  // one 1-KiB piece of this wave's share of a stage, q = 0 .. 8 (4 A pieces, up to 5 W pieces); source pointers advance once per step (advance_src)
+  auto issue_one = [&](int stage, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    char* abase = smem + stage * G2_STAGE_BYTES;
+    if constexpr (q < A_INST) {
+      glds16(a_src[q], abase + (wave * A_INST + q) * 1024);
+    } else {
+      constexpr int i = q - A_INST;
+      const int inst = wave + i * G2_NW;
+      if (inst < B_TOTAL) glds16(b_src[i], abase + G2_A_BYTES + inst * 1024);
+    }
+  };
+  auto advance_src = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) a_src[i] += GEMM_BK;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b_src[i] += GEMM_BK;
+  };
+
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -86,6 +105,10 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   const int b_row_off = (wn * 144 + l15) * 128;
   const int nk = p.K / GEMM_BK;
 
+#ifdef G_STAMP
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_c1 = 0, st_c2 = 0;
+#endif
   issue(0);
 #ifndef G2_NO_XBAR
   // the last PN columns of a step's second fragment set are consumed after the NEXT barrier (4 * PN MFMAs of pipe work while the barrier
@@ -93,21 +116,40 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   // In-run A/B: FF1 -1.6 %, wide K,V -1.5 %, +0.8 % end to end; PN = 4 the same.  -DG2_NO_XBAR: the plain loop below.
   constexpr int PN = 2;
   Pack8 afp[FM], wfp[PN];
-  for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
+  auto step_top = [&](int kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef G_STAMP
+    if (kt == 0) st_c1 = __builtin_amdgcn_s_memtime();
+#endif
+  };
+  auto read_set0 = [&](Pack8 (&af0)[FM], Pack8 (&wf0)[FN], int stage) {
     const char* abase = smem + stage * G2_STAGE_BYTES;
     const char* bbase = abase + G2_A_BYTES;
+    const int coff = (g ^ swz) * 16;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+  };
+  auto read_set1 = [&](Pack8 (&wf)[FN - PN], int stage) {
+    const char* abase = smem + stage * G2_STAGE_BYTES;
+    const char* bbase = abase + G2_A_BYTES;
+    const int coff = ((4 + g) ^ swz) * 16;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) afp[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+    for (int j = 0; j < FN - PN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+#pragma unroll
+    for (int j = 0; j < PN; ++j) wfp[j] = lds_read16(bbase + b_row_off + (FN - PN + j) * 2048 + coff);
+  };
+  // Block schedule (round 1; also the first and the last K-step of the staggered schedule): all 9 pieces of the next stage in one block
+  auto step_block = [&](int kt) {
+    const int stage = kt & 1;
+    step_top(kt);
     Pack8 af0[FM], wf0[FN];
-    {
-      const int coff = (g ^ swz) * 16;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
-    }
+    read_set0(af0, wf0, stage);
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) issue(stage ^ 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -122,20 +164,64 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
-    {
-      const int coff = ((4 + g) ^ swz) * 16;
-      Pack8 wf[FN - PN];
+    Pack8 wf[FN - PN];
+    read_set1(wf, stage);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) afp[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+    for (int j = 0; j < FN - PN; ++j)
 #pragma unroll
-      for (int j = 0; j < FN - PN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < PN; ++j) wfp[j] = lds_read16(bbase + b_row_off + (FN - PN + j) * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN - PN; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], afp[i], acc[i][j]);
-    }
+      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], afp[i], acc[i][j]);
+  };
+  // Staggered schedule (see gemm3s.h; K-steps 1 .. nk-2): one MFMA stream for all waves, the 9 LDS-DMA pieces of the next stage one per group
+  // of 4 MFMAs -- waves 0-3 beside the first 36 MFMAs of the step, waves 4-7 (their SIMD partners) beside the last 28
+  auto step_stagger = [&](int kt) {
+    const int stage = kt & 1, nst = stage ^ 1;
+    const bool early = wave < G2_NW / 2;
+    step_top(kt);
+    Pack8 af0[FM], wf0[FN];
+    read_set0(af0, wf0, stage);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<11>([&](auto gc) {  // MFMAs 0..7: the carried columns; 8..43: the first fragment set, column by column
+      constexpr int gi = decltype(gc)::value;
+      if constexpr (gi < 9) { if (early) issue_one(nst, gc); }
+      static_for<4>([&](auto tc) {
+        constexpr int idx = gi * 4 + decltype(tc)::value;
+        if constexpr (idx < 4 * PN) {
+          constexpr int j = idx / FM, i = idx - j * FM;
+          acc[i][FN - PN + j] = mfma16<T>(wfp[j], afp[i], acc[i][FN - PN + j]);
+        } else {
+          constexpr int k2 = idx - 4 * PN;
+          constexpr int j = k2 / FM, i = k2 - j * FM;
+          acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    Pack8 wf[FN - PN];
+    read_set1(wf, stage);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<FN - PN>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (!early) {
+        issue_one(nst, jc);
+        if constexpr (j + (FN - PN) < 9) issue_one(nst, std::integral_constant<int, j + (FN - PN)>{});
+      }
+      static_for<FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        acc[i][j] = mfma16<T>(wf[j], afp[i], acc[i][j]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    advance_src();
+  };
+  {
+    int kt = 0;
+    step_block(kt++);
+    // measured NEGATIVE on this kernel (variant 2 selects it for A/B): with a 2-stage ring the pieces the late half issues in the second half of a
+    // step have half a step to land before the vmcnt(0) at the next barrier -- wide K,V 44.6 -> 49.2 us, FF1 92.6 -> 100.8 us.  The block
+    // schedule stays the default here; the staggered one is what gemm3s.h (3 stages) runs.
+    if (p.variant == 2)
+      for (; kt + 1 < nk; ++kt) step_stagger(kt);
+    for (; kt < nk; ++kt) step_block(kt);
   }
 #pragma unroll
   for (int j = 0; j < PN; ++j)
@@ -195,6 +281,17 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #endif
   }
 #endif
+#ifdef G_STAMP
+  st_c2 = __builtin_amdgcn_s_memtime();
+#endif
+  // all FN bias vectors of this lane in ONE batch before the barrier (see gemm3s.h: hipcc otherwise serializes nine load -> wait -> use round trips)
+  f32x4 bvs[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 144 + 16 * j + 4 * g);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
 
   // ---- epilogue 1: this wave's 64 x 144 block into the row-major C tile
@@ -202,8 +299,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int nl = wn * 144 + 16 * j + 4 * g;
-    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+    const f32x4 bv = bvs[j];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int ml = wm * 64 + 16 * i + l15;
@@ -211,7 +307,9 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[r];
+#ifndef G_ABL_NOGELU
         if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+#endif
         if (EPI == EPI_BIAS_SILU) v = silu(v);
         float_to_elem4<T>(o, r, v);
       }
@@ -255,9 +353,21 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
       }
       gstore16(rp, pack8<T>(h));
     } else {
+#ifdef G_ABL_NOSTORE
+      if (v.u[0] == 0x12345678u)  // ablation build (wrong results): the epilogue without its global stores
+#endif
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }
   }
+#ifdef G_STAMP
+  // diagnostic build only: cycles of prologue / K loop / epilogue and the in-kernel clock, per workgroup, into a buffer riding in the unused gate_mod slot
+  if (EPI != EPI_BIAS_CACHE_RESID && p.gate_mod && wave == 0 && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_c3 = __builtin_amdgcn_s_memtime(), st_r3 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<T*>(p.gate_mod)) + 8 * blockIdx.x;
+    dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0;
+  }
+#endif
 }
 
 }  // namespace ecad

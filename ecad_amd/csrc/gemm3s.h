@@ -75,6 +75,28 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     }
   };
 
+  // one piece (1 KiB: 8 rows x 128 B) of this wave's share of a stage; q = 0 .. A_INST + B_INST_MAX - 1
+  auto issue_one = [&](int stage, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    char* abase = smem + stage * STAGE_BYTES;
+#ifdef G3_ABL_NODMA
+    if (p.K > 0) return;  // ablation build (wrong results): how long is a K-step without its LDS-DMA issues?
+#endif
+    if constexpr (q < A_INST) {
+      glds16(a_src[q], abase + (wave * A_INST + q) * 1024);
+    } else {
+      constexpr int i = q - A_INST;
+      const int inst = wave + i * NWAVES;
+      if (inst < B_INST_TOTAL) glds16(b_src[i], abase + A_BYTES + inst * 1024);
+    }
+  };
+  auto advance_src = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) a_src[i] += GEMM_BK;
+#pragma unroll
+    for (int i = 0; i < B_INST_MAX; ++i) b_src[i] += GEMM_BK;
+  };
+
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -84,16 +106,36 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   const int a_row_off = (wave * WTM + l15) * 128;
   const int b_row_off = l15 * 128;
   const int nk = p.K / GEMM_BK;
+#ifdef G_STAMP
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_c1 = 0, st_c2 = 0;
+#endif
   issue(0);
   if (nk > 1) issue(1);
-  // EPI_BIAS_CACHE_RESID: the hidden-state chunks this lane updates in the epilogue are fetched NOW, so their HBM
-  // latency hides behind the whole K loop instead of sitting at the tail of a 1-tile-per-CU kernel
+  // EPI_BIAS_CACHE_RESID: the hidden-state chunks this lane updates in the epilogue are fetched during the K loop, so their HBM latency hides
+  // behind it instead of sitting at the tail of a 1-tile-per-CU kernel -- but not in front of it: vmcnt retires in order, so loads issued
+  // before the first K-steps make the pipeline fill wait for them (stamped: prologue 5.7k cycles against 2.6k for the plain epilogue).
+  // They go out in K-step 1, right behind that step's DMA issue (G3_RESID_EARLY: before the loop, as round 1 had it).
   constexpr int CPR = BN / 8;
   constexpr int CHUNKS = WTM * CPR;
   constexpr int NCH = (CHUNKS + 63) / 64;
   Pack8 hpre[EPI == EPI_BIAS_CACHE_RESID ? NCH : 1];
+  // The gate (scale_shift_table row + adaLN modulation) depends on the column and the sample only.  When the tile lies inside one sample
+  // (always for N = 256 / 4096 tokens and 256-row tiles) lanes 0 .. CPR-1 fetch the 8 gate values of their column chunk with the residual --
+  // three small loads per wave instead of three per output chunk at the tail -- and the epilogue reads them back from LDS.
+  float gpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  Pack8 gmod;
+  gmod.u = (u32x4){0, 0, 0, 0};
+  bool gate_lds = false;
+#ifndef G3_GATE_PER_CHUNK
+  if (EPI == EPI_BIAS_CACHE_RESID && p.gate_table) {
+    const int m_last = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
+    gate_lds = m0 / p.rows_per_batch == m_last / p.rows_per_batch;
+  }
+#endif
+  auto prefetch_resid = [&]() {
+    if (EPI != EPI_BIAS_CACHE_RESID) return;
 #ifndef G3_NO_RESID_PREFETCH
-  if (EPI == EPI_BIAS_CACHE_RESID) {
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int id = lane + it * 64;
@@ -102,79 +144,132 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
       hpre[it].u = (u32x4){0, 0, 0, 0};
       if (id < CHUNKS && m < p.M) hpre[it] = gload16(p.resid + (size_t)m * p.ldr + n0 + cchunk * 8);
     }
-  }
 #endif
-  // The gate (scale_shift_table row + adaLN modulation) depends on the column and the sample only.  When the tile lies inside one sample
-  // (always for N = 256 / 4096 tokens and 256-row tiles) lanes 0 .. CPR-1 fetch the 8 gate values of their column chunk NOW -- three small
-  // loads per wave instead of three per output chunk at the tail -- and the epilogue reads them back from LDS.
-  float gpre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  bool gate_lds = false;
-#ifndef G3_GATE_PER_CHUNK
-  if (EPI == EPI_BIAS_CACHE_RESID && p.gate_table) {
-    const int m_last = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
-    gate_lds = m0 / p.rows_per_batch == m_last / p.rows_per_batch;
     if (gate_lds && lane < CPR) {
       const int n = n0 + lane * 8;
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gpre[e] = t0[e]; gpre[4 + e] = t1[e]; }
-      if (p.gate_mod) {
-        float gm[8];
-        unpack8<T>(gload16(p.gate_mod + (size_t)(m0 / p.rows_per_batch) * p.gate_mod_stride + n), gm);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gpre[e] += gm[e];
-      }
+      if (p.gate_mod) gmod = gload16(p.gate_mod + (size_t)(m0 / p.rows_per_batch) * p.gate_mod_stride + n);
     }
-  }
+  };
+#if defined(G3_RESID_EARLY) || defined(G3_NO_XBAR)
+  const bool resid_in_loop = false;
+#else
+  const bool resid_in_loop = nk >= 3;
 #endif
+  if (!resid_in_loop) prefetch_resid();
   int stage = 0;
 #ifndef G3_NO_XBAR
   // second fragment set of a step consumed after the NEXT step's barrier: the matrix pipe has a full group to chew on while the barrier
   // resolves and the new stage's first fragments travel from LDS (11 more live fragment registers: fits this kernel's 72 accumulators;
   // 244 VGPRs, no spills).  In-run A/B: Q -2.7 %, attn1-out -3.7 %, attn2-out -3.2 %, cross-Q -3.0 %.  -DG3_NO_XBAR: the plain loop below.
   Pack8 afp[FM], wfp[FN];
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // top of K-step kt: stage kt has landed when at most the newest stage's DMA (A_INST + 2 = 6 per wave) is outstanding; in the step after the
+  // residual prefetch went out behind that DMA its NCH loads are newer still, so they may be outstanding as well
+  auto step_top = [&](int kt) {
+    if (kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (EPI == EPI_BIAS_CACHE_RESID && resid_in_loop && kt == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NCH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef G3_ABL_NOBAR
+    if (kt < 2)  // ablation build (racy): a K-step without its barrier
+#endif
     __builtin_amdgcn_s_barrier();
-    const char* abase = smem + stage * STAGE_BYTES;
+#ifdef G_STAMP
+    if (kt == 0) st_c1 = __builtin_amdgcn_s_memtime();
+#endif
+  };
+  auto read_set = [&](Pack8 (&af)[FM], Pack8 (&wf)[FN], int stg, int half) {
+    const char* abase = smem + stg * STAGE_BYTES;
     const char* bbase = abase + A_BYTES;
+    const int coff = ((half * 4 + g) ^ swz) * 16;
+#ifdef G3_ABL_NOREAD
+    if (stg != 0 && p.K > 0) return;  // ablation build (wrong results): fragments re-read only from stage 0, i.e. two steps in three run on stale registers
+#endif
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
+  };
+  auto mfma_all = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM]) {
+    static_for<FN>([&](auto jc) {
+      static_for<FM>([&](auto ic) {
+        constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
+        acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+      });
+    });
+  };
+  // Block schedule (round 1; also the first and the last two K-steps of the staggered schedule): every wave issues its pieces in one block
+  auto step_block = [&](int kt) {
+    step_top(kt);
     Pack8 af0[FM], wf0[FN];
-    {
-      const int coff = (g ^ swz) * 16;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
-    }
+    read_set(af0, wf0, stage, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 2 < nk) {
       int ns = stage + 2;
       ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
       issue(ns);
     }
+    if (resid_in_loop && kt == 1) prefetch_resid();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt > 0) {
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wfp[j], afp[i], acc[i][j]);
-    }
+    if (kt > 0) mfma_all(wfp, afp);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const int coff = ((4 + g) ^ swz) * 16;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) afp[i] = lds_read16(abase + a_row_off + i * 16 * 128 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wfp[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
-    }
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
+    read_set(afp, wfp, stage, 1);
+    mfma_all(wf0, af0);
     stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
+  };
+  // Staggered schedule (K-steps 1 .. nk-3: a carried fragment set exists and a stage is still to be fetched, so the body has no conditions).
+  // Issuing one LDS-DMA piece stalls the issuing wave for ~60-180 cycles (MI355X_MICROARCH.md, cycle constants) but hardly its SIMD partner; with
+  // every wave issuing its 6-7 pieces in one block right after the barrier both waves of a SIMD stall together and the matrix pipe idles
+  // (stamped: 1810 cycles per K-step against 1152 of MFMA work, with 8 or with 256 workgroups on the chip).  Here the pieces go out one per
+  // group of 3 MFMAs, waves 0-3 (the older half) beside the MFMAs carried over from the last step, waves 4-7 (their SIMD partners) beside the
+  // MFMAs of this step's first fragment set: whenever one wave of a SIMD sits in a DMA issue, the other has MFMAs to feed.
+  constexpr int NPIECE = A_INST + B_INST_MAX;                   // 7 slots (the last one only on the waves that own an 18th W piece)
+  constexpr int NMF = FM * FN, GROUPS = 6, PER = NMF / GROUPS;  // 18 MFMAs in 6 groups of 3
+  static_assert(NMF % GROUPS == 0 && NPIECE <= GROUPS + 1, "piece / MFMA interleave");
+  // both halves run the same MFMA stream (one code path: a wave-group branch around the MFMAs makes hipcc shuffle and spill the accumulators);
+  // only the small DMA-issue blocks in between are conditional on the half the wave belongs to
+  auto mfma_dma = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM], int ns, bool mine) {
+    static_for<GROUPS>([&](auto gc) {
+      constexpr int gi = decltype(gc)::value;
+      if (mine) {
+        issue_one(ns, gc);
+        if constexpr (gi == GROUPS - 1 && NPIECE > GROUPS) issue_one(ns, std::integral_constant<int, GROUPS>{});
+      }
+      static_for<PER>([&](auto tc) {
+        constexpr int idx = gi * PER + decltype(tc)::value;
+        constexpr int j = idx / FM, i = idx - j * FM;
+        acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  auto step_stagger = [&](int kt) {
+    step_top(kt);
+    Pack8 af0[FM], wf0[FN];
+    read_set(af0, wf0, stage, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    int ns = stage + 2;
+    ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+    const bool early = wave < NWAVES / 2;
+    mfma_dma(wfp, afp, ns, early);
+    read_set(afp, wfp, stage, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_dma(wf0, af0, ns, !early);
+    advance_src();
+    if (resid_in_loop && kt == 1) prefetch_resid();
+    stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
+  };
+  {
+    int kt = 0;
+    step_block(kt++);
+#ifndef G3_ONLY_BLOCK
+    if (p.variant != 0)
+      for (; kt + 2 < nk; ++kt) step_stagger(kt);
+#endif
+    for (; kt < nk; ++kt) step_block(kt);
   }
 #pragma unroll
   for (int j = 0; j < FN; ++j)
@@ -243,13 +338,25 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
   }
 #endif
+#ifdef G_STAMP
+  st_c2 = __builtin_amdgcn_s_memtime();
+#endif
+  // all FN bias vectors of this lane in ONE batch, issued before the barrier: hipcc otherwise emits load -> s_waitcnt vmcnt(0) -> use per
+  // column group, i.e. nine serialized L2 / HBM latencies at the tail of the tile (stamped: 7.4k cycles of epilogue with the global stores
+  // ablated; the fragment registers of the K loop are free by now)
+  f32x4 bvs[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * g);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   T* ctile = reinterpret_cast<T*>(smem);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int nl = 16 * j + 4 * g;
-    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+    const f32x4 bv = bvs[j];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int ml = wave * WTM + 16 * i + l15;
@@ -257,7 +364,9 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[r];
+#ifndef G_ABL_NOGELU
         if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+#endif
         if (EPI == EPI_BIAS_SILU) v = silu(v);
         float_to_elem4<T>(o, r, v);
       }
@@ -266,6 +375,12 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   }
   float* gwave = reinterpret_cast<float*>(smem + BM * CS * sizeof(T)) + wave * BN;  // behind the C tile; one private copy per wave: no block barrier
   if (gate_lds && lane < CPR) {
+    if (p.gate_mod) {
+      float gm[8];
+      unpack8<T>(gmod, gm);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gpre[e] += gm[e];
+    }
     *reinterpret_cast<f32x4*>(gwave + lane * 8) = (f32x4){gpre[0], gpre[1], gpre[2], gpre[3]};
     *reinterpret_cast<f32x4*>(gwave + lane * 8 + 4) = (f32x4){gpre[4], gpre[5], gpre[6], gpre[7]};
   }
@@ -313,9 +428,21 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
       }
       gstore16(rp, pack8<T>(h));
     } else {
+#ifdef G_ABL_NOSTORE
+      if (v.u[0] == 0x12345678u)  // ablation build (wrong results): the epilogue without its global stores
+#endif
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }
   }
+#ifdef G_STAMP
+  // diagnostic build only (see gemm2w.h): the buffer rides in gate_mod, which the epilogue does not read while gate_table is null
+  if (!p.gate_table && p.gate_mod && wave == 0 && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_c3 = __builtin_amdgcn_s_memtime(), st_r3 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<T*>(p.gate_mod)) + 8 * blockIdx.x;
+    dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0;
+  }
+#endif
 }
 
 }  // namespace ecad

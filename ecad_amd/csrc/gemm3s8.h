@@ -143,18 +143,31 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
   }
+  // weight scales, biases and row scales of this lane in ONE batch (gemm3s.h: hipcc otherwise serializes a load -> wait -> use round trip per vector)
+  f32x4 svs[FN], bvs[FN];
+  float sams[FM];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    svs[j] = *reinterpret_cast<const f32x4*>(q.sw + n0 + 16 * j + 4 * g);
+    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * g);
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int mi = m0 + wave * WTM + 16 * i + l15;
+    sams[i] = q.sa[mi < p.M ? mi : p.M - 1];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   T* ctile = reinterpret_cast<T*>(smem);
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int mi = m0 + wave * WTM + 16 * i + l15;
-    const float sam = q.sa[mi < p.M ? mi : p.M - 1];
+    const float sam = sams[i];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int nl = 16 * j + 4 * g;
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(q.sw + n0 + nl);
-      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+      const f32x4 sv = svs[j];
+      const f32x4 bv = bvs[j];
       const int ml = wave * WTM + 16 * i + l15;
       Pack4 o;
 #pragma unroll
@@ -301,18 +314,31 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w8_kernel(const Gemm8Args<T> 
       for (int i = 0; i < FM; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
   }
+  f32x4 svs[FN], bvs[FN];  // one batch of loads, as in the 256 x 144 kernel above
+  float sams[FM];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    svs[j] = *reinterpret_cast<const f32x4*>(q.sw + n0 + wn * 144 + 16 * j + 4 * g);
+    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 144 + 16 * j + 4 * g);
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int ml = wm * 64 + 16 * i + l15;
+    sams[i] = q.sa[m0 + ml < p.M ? m0 + ml : p.M - 1];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   T* ctile = reinterpret_cast<T*>(smem);
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int ml = wm * 64 + 16 * i + l15;
-    const float sam = q.sa[m0 + ml < p.M ? m0 + ml : p.M - 1];
+    const float sam = sams[i];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int nl = wn * 144 + 16 * j + 4 * g;
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(q.sw + n0 + nl);
-      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+      const f32x4 sv = svs[j];
+      const f32x4 bv = bvs[j];
       Pack4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -116,11 +116,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   }
   // epilogue: bias in fp32, round, C tile through LDS, 16-byte row stores (+ residual)
   T* ctile = reinterpret_cast<T*>(smem);
+  f32x4 bvs[FN];  // one batch of loads (gemm3s.h: hipcc otherwise serializes a load -> wait -> use round trip per column group)
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + 16 * j + 4 * g);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int nl = wn * 64 + 16 * j + 4 * g;
-    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+    const f32x4 bv = bvs[j];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int ml = wm * 64 + 16 * i + l15;

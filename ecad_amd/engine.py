@@ -264,14 +264,16 @@ class EcadEngine:
     GEMM_KERNELS = {"tile144": 0, "persistent": 1, "wide288": 2, "tile128": 3}
     GEMM_SITES = {"qkv": 0, "attn1_out": 1, "attn2_q": 2, "attn2_out": 3, "ff1": 4, "ff2": 5, "text_kv": 6, "caption": 7, "small": 8, "attn1_kv": 9}
 
-    def op_gemm_ex(self, kernel: str, site: str, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None):
-        """``op_gemm`` on a named kernel / call-site instantiation (``ecad_op_gemm_ex``); ``a`` and ``out`` may be column slices (row stride > width)."""
+    def op_gemm_ex(self, kernel: str, site: str, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None,
+                   sched: int | None = None):
+        """``op_gemm`` on a named kernel / call-site instantiation (``ecad_op_gemm_ex``); ``a`` and ``out`` may be column slices (row stride > width).
+        ``sched``: force K-loop schedule variant 0 / 1 (default: the engine's own, env ECAD_GEMM_SCHED)."""
         M, K = a.shape
         N = w.shape[0]
         if out is None and epi != 3:
             out = torch.empty((M, N), device=self.device, dtype=self.dtype)
         self._chk(
-            self.lib.ecad_op_gemm_ex(self._h, self.GEMM_KERNELS[kernel], self.GEMM_SITES[site], epi, a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(out), M, N, K,
+            self.lib.ecad_op_gemm_ex(self._h, self.GEMM_KERNELS[kernel] | (0 if sched is None else (int(sched) + 1) << 8), self.GEMM_SITES[site], epi, a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(out), M, N, K,
                                      a.stride(0), out.stride(0) if out is not None else 0, _ptr(resid), _ptr(gate_table), _ptr(gate_mod),
                                      int(gate_mod_stride), int(rows_per_batch), _stream_ptr())
         )

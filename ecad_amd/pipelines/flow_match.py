@@ -42,9 +42,9 @@ def flow_match_sigmas(num_steps: int, image_seq_len: int, scheduler_config: dict
 
 
 def model_scalars(sigmas: np.ndarray, guidance_scale: float, dtype: torch.dtype):
-    """(timesteps_x1000 [steps] float32 numpy, guidance_x1000 float): what the transformer sees after `timestep / 1000` is handed
-    over in the model dtype and multiplied by 1000 in that dtype (flux_transformer_2d_edited.py:270-274)."""
+    """(timesteps_x1000 [steps] float32 numpy, guidance_x1000 float): what the transformer sees.  FluxPipeline [ext] casts the timestep to the
+    latents' dtype first, divides by 1000 in that dtype, and the model multiplies by 1000 in that dtype (flux_transformer_2d_edited.py:270-274)."""
     t = torch.from_numpy(sigmas[:-1].copy()) * 1000.0
-    t_in = (t / 1000.0).to(dtype)
+    t_in = t.to(dtype) / 1000.0
     g = torch.tensor([guidance_scale], dtype=torch.float32).to(dtype)
     return (t_in * 1000).float().numpy(), float((g * 1000).float()[0])

@@ -313,14 +313,14 @@ def flow_match_sigmas(num_steps: int, image_seq_len: int, base_seq_len=256, max_
 
 
 def model_scalars(sigmas: np.ndarray, guidance_scale: float, dtype: torch.dtype | None):
-    """The (timestep * 1000, guidance * 1000) values the transformer sees: the pipeline hands over
-    `t / 1000` and the guidance scale in the model dtype and the model multiplies by 1000 in that dtype
-    (flux_transformer_2d_edited.py:270-274)."""
+    """The (timestep * 1000, guidance * 1000) values the transformer sees.  diffusers 0.30.3 FluxPipeline.__call__ [ext] casts the scheduler's
+    timestep to the latents' dtype FIRST (`timestep = t.expand(B).to(latents.dtype)`) and hands over `timestep / 1000`, still in that dtype; the model
+    multiplies by 1000 in that dtype (flux_transformer_2d_edited.py:270-274): three roundings, reproduced here one by one."""
     t = torch.from_numpy(sigmas[:-1].copy()) * 1000.0  # scheduler.timesteps (fp32)
     g = torch.tensor([guidance_scale], dtype=torch.float32)
     if dtype is None:
         return t.clone(), g * 1000.0
-    t_in = (t / 1000.0).to(dtype)
+    t_in = t.to(dtype) / 1000.0  # computed and rounded in `dtype`
     return (t_in * 1000).float(), (g.to(dtype) * 1000).float()
 
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 
 #ifdef G_STAMP
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long st_c1 = 0, st_c2 = 0;
+  unsigned long long st_c1 = 0, st_c2 = 0, st_ca = 0, st_cb = 0;
 #endif
   issue(0);
 #ifndef G2_NO_XBAR
@@ -218,9 +218,11 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     step_block(kt++);
     // measured NEGATIVE on this kernel (variant 2 selects it for A/B): with a 2-stage ring the pieces the late half issues in the second half of a
     // step have half a step to land before the vmcnt(0) at the next barrier -- wide K,V 44.6 -> 49.2 us, FF1 92.6 -> 100.8 us.  The block
-    // schedule stays the default here; the staggered one is what gemm3s.h (3 stages) runs.
+    // schedule stays the default here; the staggered one is what gemm3s.h (3 stages) runs (-DG2_STAGGER_AB compiles it in here).
+#ifdef G2_STAGGER_AB
     if (p.variant == 2)
       for (; kt + 1 < nk; ++kt) step_stagger(kt);
+#endif
     for (; kt < nk; ++kt) step_block(kt);
   }
 #pragma unroll
@@ -293,11 +295,19 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+#ifdef G_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st_ca = __builtin_amdgcn_s_memtime();
+#endif
 
-  // ---- epilogue 1: this wave's 64 x 144 block into the row-major C tile
+  // ---- epilogue: bias / activation / rounding of the wave's 64 x 144 block into the row-major C tile, one barrier (rows are shared by the two
+  // column-half waves), then wave w streams rows 32w .. 32w+31 out in 16-byte chunks.  Stamped (cycles per tile, 256 WGs): wait for the slowest
+  // wave + bias 2.9k, accumulators -> LDS 3.3k (FF1 with GELU: 11.0k), LDS -> global 7.1k (the CU's store path moves ~25 B per clock).
+  // Measured NEGATIVE (-DG2_EPI_SLABS): the same in three column slabs so that the VALU works on slab s+1 while the stores of slab s drain --
+  // a wave that issues stores into a full queue stalls, so nothing overlaps and two more barriers are paid: wide K,V 44.6 -> 54 us, FF1 92.6 -> 101 us.
   T* ctile = reinterpret_cast<T*>(smem);
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
+  auto convert = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     const int nl = wn * 144 + 16 * j + 4 * g;
     const f32x4 bv = bvs[j];
 #pragma unroll
@@ -315,17 +325,10 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
       }
       *reinterpret_cast<u32x2*>(ctile + ml * G2_CS + nl) = o.u;
     }
-  }
-  __syncthreads();  // rows are shared by the two column-half waves
-
-  // ---- epilogue 2: wave w streams rows 32w .. 32w+31, 36 chunks of 16 bytes per row
-  constexpr int CPR = G2_BN / 8;
-  constexpr int CHUNKS = 32 * CPR;  // 1152 = 18 per lane
-  for (int id = lane; id < CHUNKS; id += 64) {
-    const int rl = id / CPR, cchunk = id - rl * CPR;
-    const int ml = wave * 32 + rl;
+  };
+  auto store_chunk = [&](int ml, int cchunk) {
     const int m = m0 + ml;
-    if (m >= p.M) continue;
+    if (m >= p.M) return;
     const int n = n0 + cchunk * 8;
     Pack8 v = lds_read16(ctile + ml * G2_CS + cchunk * 8);
     if (EPI == EPI_BIAS_CACHE_RESID) {
@@ -358,14 +361,47 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #endif
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }
+  };
+#ifdef G2_EPI_SLABS
+  constexpr int SLABS = 3, JS = FN / SLABS;      // 3 fragment columns per slab and column half
+  constexpr int SCH = JS * 2;                    // 16-byte chunks per row, slab and column half: 6
+  static_assert(FN % SLABS == 0 && (32 * 2 * SCH) % 64 == 0, "slab geometry");
+  static_for<SLABS>([&](auto sc) {
+    constexpr int sb = decltype(sc)::value;
+    static_for<JS>([&](auto jj) { convert(std::integral_constant<int, sb * JS + decltype(jj)::value>{}); });
+    __syncthreads();
+#ifdef G_STAMP
+    if (sb == SLABS - 1) st_cb = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int it = 0; it < 32 * 2 * SCH / 64; ++it) {  // 6 chunks per lane and slab
+      const int id = lane + it * 64;
+      const int rl = id / (2 * SCH), cc = id - rl * (2 * SCH);
+      const int cchunk = (cc < SCH ? 0 : 144 / 8 - SCH) + sb * SCH + cc;  // column half 0: chunks [6s, 6s+6), half 1: 18 + [6s, 6s+6)
+      store_chunk(wave * 32 + rl, cchunk);
+    }
+  });
+#else
+  static_for<FN>([&](auto jc) { convert(jc); });
+  __syncthreads();  // rows are shared by the two column-half waves
+#ifdef G_STAMP
+  st_cb = __builtin_amdgcn_s_memtime();
+#endif
+  // wave w streams rows 32w .. 32w+31, 36 chunks of 16 bytes per row
+  constexpr int CPR = G2_BN / 8;
+  constexpr int CHUNKS = 32 * CPR;  // 1152 = 18 per lane
+  for (int id = lane; id < CHUNKS; id += 64) {
+    const int rl = id / CPR, cchunk = id - rl * CPR;
+    store_chunk(wave * 32 + rl, cchunk);
   }
+#endif
 #ifdef G_STAMP
   // diagnostic build only: cycles of prologue / K loop / epilogue and the in-kernel clock, per workgroup, into a buffer riding in the unused gate_mod slot
   if (EPI != EPI_BIAS_CACHE_RESID && p.gate_mod && wave == 0 && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st_c3 = __builtin_amdgcn_s_memtime(), st_r3 = __builtin_amdgcn_s_memrealtime();
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<T*>(p.gate_mod)) + 8 * blockIdx.x;
-    dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0;
+    dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0; dbg[6] = st_ca - st_c2; dbg[7] = st_cb - st_ca;
   }
 #endif
 }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   const int nk = p.K / GEMM_BK;
 #ifdef G_STAMP
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long st_c1 = 0, st_c2 = 0;
+  unsigned long long st_c1 = 0, st_c2 = 0, st_ca = 0, st_cb = 0;
 #endif
   issue(0);
   if (nk > 1) issue(1);
@@ -160,6 +160,23 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   const bool resid_in_loop = nk >= 3;
 #endif
   if (!resid_in_loop) prefetch_resid();
+  // All FN bias vectors of this lane in ONE batch of loads: hipcc otherwise emits load -> s_waitcnt vmcnt(0) -> use per column group, nine
+  // serialized L2 / HBM latencies at the tail of the tile (stamped: 7.4k cycles of epilogue with the global stores ablated, 5.0k batched).
+  // Plain epilogues (registers to spare) fetch them two K-steps before the end, so not even one latency is left; the residual epilogue
+  // (256 VGPRs in the loop) fetches them right after it.
+  f32x4 bvs[FN];
+  auto load_bias = [&]() {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * g);
+    }
+  };
+#ifndef G3_NO_XBAR
+  const bool bias_in_loop = EPI != EPI_BIAS_CACHE_RESID && nk >= 2;
+#else
+  const bool bias_in_loop = false;
+#endif
   int stage = 0;
 #ifndef G3_NO_XBAR
   // second fragment set of a step consumed after the NEXT step's barrier: the matrix pipe has a full group to chew on while the barrier
@@ -213,6 +230,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
       issue(ns);
     }
     if (resid_in_loop && kt == 1) prefetch_resid();
+    if (bias_in_loop && kt == nk - 2) load_bias();
     __builtin_amdgcn_sched_barrier(0);
     if (kt > 0) mfma_all(wfp, afp);
     __builtin_amdgcn_sched_barrier(0);
@@ -227,16 +245,22 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   // group of 3 MFMAs, waves 0-3 (the older half) beside the MFMAs carried over from the last step, waves 4-7 (their SIMD partners) beside the
   // MFMAs of this step's first fragment set: whenever one wave of a SIMD sits in a DMA issue, the other has MFMAs to feed.
   constexpr int NPIECE = A_INST + B_INST_MAX;                   // 7 slots (the last one only on the waves that own an 18th W piece)
-  constexpr int NMF = FM * FN, GROUPS = 6, PER = NMF / GROUPS;  // 18 MFMAs in 6 groups of 3
+#ifndef G3_STAG_GROUPS
+#define G3_STAG_GROUPS 6
+#endif
+  constexpr int NMF = FM * FN, GROUPS = G3_STAG_GROUPS, PER = NMF / GROUPS;  // 18 MFMAs in 6 groups of 3 (9 groups of 2: -DG3_STAG_GROUPS=9)
   static_assert(NMF % GROUPS == 0 && NPIECE <= GROUPS + 1, "piece / MFMA interleave");
+  constexpr int LASTP = NPIECE > GROUPS ? GROUPS - 1 : NPIECE - 1;  // group that carries the last regular piece
   // both halves run the same MFMA stream (one code path: a wave-group branch around the MFMAs makes hipcc shuffle and spill the accumulators);
   // only the small DMA-issue blocks in between are conditional on the half the wave belongs to
   auto mfma_dma = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM], int ns, bool mine) {
     static_for<GROUPS>([&](auto gc) {
       constexpr int gi = decltype(gc)::value;
-      if (mine) {
-        issue_one(ns, gc);
-        if constexpr (gi == GROUPS - 1 && NPIECE > GROUPS) issue_one(ns, std::integral_constant<int, GROUPS>{});
+      if constexpr (gi < NPIECE) {
+        if (mine) {
+          issue_one(ns, gc);
+          if constexpr (gi == GROUPS - 1 && NPIECE > GROUPS) issue_one(ns, std::integral_constant<int, GROUPS>{});
+        }
       }
       static_for<PER>([&](auto tc) {
         constexpr int idx = gi * PER + decltype(tc)::value;
@@ -253,7 +277,11 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     __builtin_amdgcn_sched_barrier(0);
     int ns = stage + 2;
     ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+#ifdef G3_STAG_REV
+    const bool early = wave >= NWAVES / 2;
+#else
     const bool early = wave < NWAVES / 2;
+#endif
     mfma_dma(wfp, afp, ns, early);
     read_set(afp, wfp, stage, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -341,17 +369,18 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
 #ifdef G_STAMP
   st_c2 = __builtin_amdgcn_s_memtime();
 #endif
-  // all FN bias vectors of this lane in ONE batch, issued before the barrier: hipcc otherwise emits load -> s_waitcnt vmcnt(0) -> use per
-  // column group, i.e. nine serialized L2 / HBM latencies at the tail of the tile (stamped: 7.4k cycles of epilogue with the global stores
-  // ablated; the fragment registers of the K loop are free by now)
-  f32x4 bvs[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * g);
-  }
+  if (!bias_in_loop) load_bias();
   __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
+  // The C tile (and the per-wave gate copies behind it) is staged in LDS rows that only their own wave writes and reads, so the only hazard
+  // is the operand ring underneath.  When the last K-step reads stage 2 (nk % 3 == 0: every K of the model) the tile lies in stages 0 and 1,
+  // which nobody touches after the last step's barrier: no workgroup barrier at all, and a wave that leaves the loop early streams its rows out
+  // while the others still multiply (stamped: 1.3-2k cycles of waiting for the slowest wave gone).  Otherwise: one barrier, as before.
+  const bool private_epi = nk >= 2 && (nk - 1) % G3_STAGES == 2 && (BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float)) <= 2 * STAGE_BYTES;
+  if (!private_epi) __syncthreads();
+#ifdef G_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st_ca = __builtin_amdgcn_s_memtime();
+#endif
   T* ctile = reinterpret_cast<T*>(smem);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -385,6 +414,9 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     *reinterpret_cast<f32x4*>(gwave + lane * 8 + 4) = (f32x4){gpre[4], gpre[5], gpre[6], gpre[7]};
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef G_STAMP
+  st_cb = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
   for (int it = 0; it < NCH; ++it) {
     const int id = lane + it * 64;
@@ -440,7 +472,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st_c3 = __builtin_amdgcn_s_memtime(), st_r3 = __builtin_amdgcn_s_memrealtime();
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<T*>(p.gate_mod)) + 8 * blockIdx.x;
-    dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0;
+    dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0; dbg[6] = st_ca - st_c2; dbg[7] = st_cb - st_ca;
   }
 #endif
 }

@@ -37,5 +37,5 @@ for kernel, site, epi, M, N, K in CASES:
     span = ((v[:, 4] + v[:, 3]).max() - t0) / 100.0
     clock = med[5] / (med[3] / 100.0) / 1e3
     steps = K // 64
-    print(f"{kernel}/{site} M={M} N={N} K={K} epi={epi}: WGs {len(v)}  prologue {med[0]:.0f}  loop {med[1]:.0f} ({med[1] / steps:.0f}/step)  epilogue {med[2]:.0f} cycles;"
+    print(f"{kernel}/{site} M={M} N={N} K={K} epi={epi}: WGs {len(v)}  prologue {med[0]:.0f}  loop {med[1]:.0f} ({med[1] / steps:.0f}/step)  epilogue {med[2]:.0f} cycles (skew + bias {med[6]:.0f}, acc -> LDS {med[7]:.0f}, LDS -> global {med[2] - med[6] - med[7]:.0f});"
           f"  WG wall {med[3] / 100:.2f} us, clock {clock:.3f} GHz, kernel span {span:.1f} us, starts: median {start.median():.1f} us max {start.max():.1f} us")

@@ -262,19 +262,11 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   const int l15 = lane & 15, g = lane >> 4;
   // ---- epilogue 1: wave's 64 x BN/2 block -> row-major C tile in LDS (bias, activation, rounding)
   T* ctile = reinterpret_cast<T*>(smem);
-  // all FN bias vectors of this lane in ONE batch: hipcc otherwise emits load -> s_waitcnt vmcnt(0) -> use per column group, FN serialized
-  // L2 / HBM latencies at the tail of every tile (gemm3s.h has the stamps)
-  f32x4 bvs[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * (BN / 2) + 16 * j + 4 * g);
-  }
-  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int nl = wn * (BN / 2) + 16 * j + 4 * g;
-    const f32x4 bv = bvs[j];
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int ml = wm * 64 + 16 * i + l15;

@@ -159,25 +159,17 @@ __global__ __launch_bounds__(512) void fgemm8_kernel(const FGemm8Args<T> q) {
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     stage = stage + 1 >= STAGES ? 0 : stage + 1;
   }
-  // de-scale: lane (l15, g) holds row l15 of fragment row-block i, columns 4g .. 4g+3 of fragment column-block j.  Scales in ONE batch of loads
-  // (gemm3s.h: hipcc otherwise serializes a load -> wait -> use round trip per vector)
-  f32x4 svs[FN];
-  float sams[FM];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) svs[j] = *reinterpret_cast<const f32x4*>(q.sw + n0 + wn * (BN / 2) + 16 * j + 4 * g);
+  __syncthreads();
+  // de-scale: lane (l15, g) holds row l15 of fragment row-block i, columns 4g .. 4g+3 of fragment column-block j
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm * 64 + 16 * i + l15;
-    sams[i] = q.sa[m < p.M ? m : p.M - 1];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
+    const float sam = q.sa[m < p.M ? m : p.M - 1];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(q.sw + n0 + wn * (BN / 2) + 16 * j + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] *= sams[i] * svs[j][r];
+      for (int r = 0; r < 4; ++r) acc[i][j][r] *= sam * sv[r];
     }
   }
   fgemm_epilogue<T, BN, EPI>(p, smem, m0, n0, acc);

@@ -286,6 +286,12 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #ifdef G_STAMP
   st_c2 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef G2_BREAK_TILE
+  // deliberately wrong build for checking the parity net (never shipped): tile column 1 loses one 16-column fragment of its second column half
+  if (tn == 1 && wn == 1)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
   // all FN bias vectors of this lane in ONE batch before the barrier (see gemm3s.h: hipcc otherwise serializes nine load -> wait -> use round trips)
   f32x4 bvs[FN];
 #pragma unroll

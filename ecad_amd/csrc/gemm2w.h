@@ -175,7 +175,11 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   // of 4 MFMAs -- waves 0-3 beside the first 36 MFMAs of the step, waves 4-7 (their SIMD partners) beside the last 28
   auto step_stagger = [&](int kt) {
     const int stage = kt & 1, nst = stage ^ 1;
+#ifdef G2_STAGGER_ALL_EARLY
+    const bool early = true;  // every wave spreads its pieces over the first 36 MFMAs of the step (no offset between SIMD partners)
+#else
     const bool early = wave < G2_NW / 2;
+#endif
     step_top(kt);
     Pack8 af0[FM], wf0[FN];
     read_set0(af0, wf0, stage);

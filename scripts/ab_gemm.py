@@ -22,6 +22,8 @@ CASES = [  # name, kernel, site, epi, M, N, K
 
 
 def main():
+    import os
+    VAR = tuple(int(v) for v in os.environ.get("AB_SCHEDS", "0,1").split(","))
     only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
     eng = EcadEngine(num_layers=1, max_batch=2, dtype=torch.float16)
     for name, kernel, site, epi, M, N, K in CASES:
@@ -39,18 +41,18 @@ def main():
         bias = torch.randn(N, device="cuda") * 0.1
         gate = torch.randn(N, device="cuda") * 0.1 if epi == 3 else None
         reps = max(24, 2 * nsets)
-        res = {0: [], 1: []}
+        res = {v: [] for v in VAR}
         # the two schedules must agree bit for bit (same MFMA order per accumulator)
         a, w, out, resid = sets[0]
         o = []
-        for v in (0, 1):
+        for v in VAR:
             r = torch.zeros_like(out) if epi == 3 else None
             c = torch.empty_like(out)
             eng.op_gemm_ex(kernel, site, epi, a, w, bias, resid=r, gate_table=gate, rows_per_batch=256, out=c, sched=v)
             o.append((c.clone(), None if r is None else r.clone()))
         same = torch.equal(o[0][0], o[1][0]) and (o[0][1] is None or torch.equal(o[0][1], o[1][1]))
         for rnd in range(4):
-            for v in (0, 1):
+            for v in VAR:
                 for i in range(nsets):
                     a, w, out, resid = sets[i]
                     eng.op_gemm_ex(kernel, site, epi, a, w, bias, resid=resid, gate_table=gate, rows_per_batch=256, out=out, sched=v)
@@ -64,7 +66,7 @@ def main():
                 torch.cuda.synchronize()
                 res[v].append(s.elapsed_time(e) / reps)
         line = f"{name:5s} {kernel}/{site} M={M} N={N} K={K} epi={epi} sets={nsets} bit-identical={same}:"
-        for v in (0, 1):
+        for v in VAR:
             ms = sorted(res[v])[len(res[v]) // 2]
             line += f"  sched{v}: {ms * 1e3:7.1f} us {2.0 * M * N * K / ms / 1e9:6.0f} TF (min {min(res[v]) * 1e3:.1f})"
         print(line, flush=True)

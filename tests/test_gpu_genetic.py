@@ -62,3 +62,33 @@ def test_multi_gpu_trainer_one_rank(tmp_path, monkeypatch, capsys):
     out = capsys.readouterr().out
     assert "generation 2:" in out and "evaluated on 1 rank(s)" in out
     assert len(list((tmp_path / "b/mg/gen_002/candidates").glob("cand_*/scores.json"))) == 4
+
+
+def test_config4_population_72_one_generation_and_resume(tmp_path, monkeypatch, capsys):
+    """BASELINE config 4 at its real population: the 72 seed candidates of schedules/population_initialization (tests/golden/ga_seed_population.npz), full
+    depth (28 blocks, 20 steps), evaluated by the sharded trainer -- on the one GPU a test has, i.e. shard size 72 instead of 9; the per-rank code is the
+    same.  The uncached reference run and the 72 candidates alternate on one engine: the plan-set cache must serve the reference's plans and graph
+    every time (1 + 72 lowerings, not 2 x 72).  Then one more generation resumed from the files."""
+    import time
+
+    from ecad_amd.genetic import train_nsga2_multi_gpu as M
+    from ecad_amd.genetic.population_io_manager import PixArtPopulationIOManager
+
+    base = ["train_nsga2_multi_gpu", "--name", "c4", "--populations-dir", str(tmp_path / "p"), "--benchmarks-dir", str(tmp_path / "b"), "--population-size", "72",
+            "--images", "2"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", base + ["--seed-population", str(GOLD / "ga_seed_population.npz"), "--generations", "1"])
+    t0 = time.time()
+    M.main()
+    dt = time.time() - t0
+    out = capsys.readouterr().out
+    assert "generation 1: 72 candidates" in out
+    print(f"population 72, one generation on one rank: {dt:.1f} s ({72 / dt:.1f} candidates/s incl. engine set-up)")
+    mgr = PixArtPopulationIOManager.from_json(tmp_path / "p/c4/gen_002/manager_config.json")
+    F = mgr.load_evaluation_scores(1)
+    assert F.shape == (72, 2) and np.isfinite(F).all() and (F[:, 0] >= 0).all() and F[:, 1].min() < F[:, 1].max() <= 5.71379613696 + 1e-9
+    assert (tmp_path / "p/c4/gen_002/checkpoint.pkl").exists() and len(list((tmp_path / "p/c4/gen_002/candidates").glob("cand_*.json"))) == 72
+    monkeypatch.setattr(sys, "argv", base + ["--load-from", str(tmp_path / "p/c4/gen_002/manager_config.json"), "--generations", "1"])
+    M.main()
+    assert "generation 2: 72 candidates" in capsys.readouterr().out and (tmp_path / "p/c4/gen_003/checkpoint.pkl").exists()

@@ -324,14 +324,23 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     for (int i = 0; i < FM; ++i) {
       const int ml = wm * 64 + 16 * i + l15;
       Pack4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv[r];
-#ifndef G_ABL_NOGELU
-        if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+#if !defined(G_ABL_NOGELU) && !defined(G2_SCALAR_GELU)
+      if constexpr (EPI == EPI_BIAS_GELU) {
+        const f32x2 v01 = gelu_tanh2((f32x2){acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]});
+        const f32x2 v23 = gelu_tanh2((f32x2){acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]});
+        float_to_elem4<T>(o, 0, v01[0]); float_to_elem4<T>(o, 1, v01[1]); float_to_elem4<T>(o, 2, v23[0]); float_to_elem4<T>(o, 3, v23[1]);
+      } else
 #endif
-        if (EPI == EPI_BIAS_SILU) v = silu(v);
-        float_to_elem4<T>(o, r, v);
+      {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] + bv[r];
+#ifndef G_ABL_NOGELU
+          if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+#endif
+          if (EPI == EPI_BIAS_SILU) v = silu(v);
+          float_to_elem4<T>(o, r, v);
+        }
       }
       *reinterpret_cast<u32x2*>(ctile + ml * G2_CS + nl) = o.u;
     }

@@ -290,6 +290,11 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     if (resid_in_loop && kt == 1) prefetch_resid();
     stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
   };
+  // Measured NEGATIVE and removed (round 2): a ping-pong schedule -- every K-step as phase A (both fragment sets -> registers, DMA issue, wait) and
+  // phase B (the 36 MFMAs) with a barrier after each, waves 4-7 one barrier behind waves 0-3 so that every SIMD has one wave in A and one in B.
+  // Bit-identical results, 2177 cycles per K-step against 1740 staggered / 1810 block: a wave's phase A alone takes ~1100 cycles (22 fragment reads,
+  // 6-7 DMA pieces, their waits) -- twice its 576 cycles of MFMA -- so the phases cannot balance; interleaving each wave's own DMA issues with its
+  // own MFMAs (step_stagger above) is what hides them.
   {
     int kt = 0;
     step_block(kt++);

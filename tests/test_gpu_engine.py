@@ -273,6 +273,31 @@ def test_baseline_batch16_properties():
     assert rel_l2(one, a[idx : idx + 1]) < 1e-6 or torch.equal(one, a[idx : idx + 1])
 
 
+def test_paper_latency_configuration_batch100():
+    """The configuration the reference's published latency was measured at (ours_fast.json:2943-2947: batch 100 -> transformer batch 200, M = 51 200 rows,
+    ~15 GB of engine memory): runs through the whole-loop graph, is deterministic, and sample i of the batch of 100 is bit for bit the sample run in a
+    batch of 4 with the same prompt and latent (rows of a batch never see each other)."""
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    bits = bits_from_schedule_json(root / "schedules/schedules_in_paper/pixart_alpha_256/ours_fast.json")
+    eng, w, cfg = make_pair(28, bits, max_batch=200)
+    inp, enc, mask = cfg_inputs(100)
+    solver = DPMSolverPP2M(20)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(20)], dtype=np.float32)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    a = eng.run_schedule(*args, use_graph=True)
+    b = eng.run_schedule(*args, use_graph=True)
+    assert a.shape == (100, 4, 32, 32) and torch.isfinite(a).all() and torch.equal(a, b)
+    st = eng.stats()
+    assert st["cache_arena_bytes"] == 84 * 200 * 256 * 1152 * 2 and st["graph_captures"] == 1
+    idx = [7, 42, 63, 99]
+    sel = torch.tensor(idx + [100 + i for i in idx])
+    few = eng.run_schedule(enc[sel].cuda(), mask[sel].cuda(), inp["latents"][idx].cuda(), solver.timesteps, coefs, 4.5, use_graph=True)
+    assert torch.equal(few, a[idx])
+    eng.close()
+
+
 def test_sigma_1024_geometry_step_parity():
     """BASELINE config 3 geometry (PixArt-Sigma 1024x1024: N = 4096 image tokens, T = 300 text tokens, sincos table with
     interpolation_scale 2): multi-chunk attention (32 key chunks self, 3 cross) and the M = 8192-row GEMMs vs the oracle."""

@@ -273,6 +273,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
     if (const char* l = getenv("ECAD_GEMM_SCHED")) gemm_variant = atoi(l);
+    if (const char* l = getenv("ECAD_FUSE_ATTN")) fuse_attn = atoi(l) != 0;
     if (const char* l = getenv("ECAD_PLAN_CACHE")) plan_lru_cap = (size_t)(atoi(l) > 0 ? atoi(l) : 0);
     custom_mask.assign((size_t)cfg.num_layers * 3, 0);
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
@@ -582,7 +583,7 @@ template <typename T> class EngineT : public EngineBase {
   std::string make_key() const {
     std::string k((const char*)bits.data(), bits.size());
     k.append((const char*)custom_mask.data(), custom_mask.size());
-    const int geo[8] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0};
+    const int geo[9] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0};
     k.append((const char*)geo, sizeof geo);
     return k;
   }
@@ -745,6 +746,19 @@ template <typename T> class EngineT : public EngineBase {
         pend.push_back(Pending{io_out, B.sst + 2 * D, mod_s + 2 * D});
       } else if (ex[0]) {
         emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, true, cb ? cb + 0 * D : nullptr, cb ? cb + 1 * D : nullptr);
+        const double attn1_flops = 4.0 * Bt * (double)NH * N * (double)N * DH;
+        // attention in the tail of the Q projection (gemm3s_attn.h): the K,V columns first (wide tiles), then one launch that projects Q for
+        // (sample, two heads) and runs their attention on the spot -- no attention launch, no Q round trip through HBM
+        const bool fuse1 = fuse_attn && !fp8 && DH == 72 && split_qkv && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0;
+        if (fuse1) {
+          push_gemm(ops, mk_gemm(KC_GEMM_KV1, EPI_BIAS, xn, B.w_qkv + (size_t)D * D, B.b_qkv + D, qkv + D, M, 2 * D, D, D, 3 * D), true);
+          Op<T> q = mk_gemm(KC_GEMM_QKV, EPI_BIAS_ATTN, xn, B.w_qkv, B.b_qkv, qkv, M, D, D, D, 3 * D);
+          q.g.att_k = qkv + D; q.g.att_v = qkv + 2 * D; q.g.att_out = attn_o; q.g.att_bias = nullptr; q.g.att_ldk = 3 * D; q.g.att_ldo = D; q.g.att_nk = N;
+          q.g.att_scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+          q.flops += attn1_flops; q.bytes += 3.0 * M * (double)D * sizeof(T) - (double)M * D * sizeof(T);  // + K, V, O; the Q tile never leaves the CU
+          ops.push_back(q);
+          a8_src = nullptr;
+        } else {
         if (split_qkv && (2 * D) % G2_BN == 0) {
           // Q columns on 256x144 tiles (256 tiles) + K,V columns on 256x288 tiles (256 tiles): the wide tiles move 32 % fewer
           // L2->LDS bytes per flop, and both launches fill the chip exactly once
@@ -756,8 +770,9 @@ template <typename T> class EngineT : public EngineBase {
         Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0;
         a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
-        a.flops = 4.0 * Bt * (double)NH * N * (double)N * DH; a.bytes = 4.0 * M * (double)D * sizeof(T);
+        a.flops = attn1_flops; a.bytes = 4.0 * M * (double)D * sizeof(T);
         ops.push_back(a);
+        }
         push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, live(b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
         if (live(b, 0)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 4ll * M * D * D; st.linear_macs_executed += 4ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)N * D;
@@ -771,13 +786,24 @@ template <typename T> class EngineT : public EngineBase {
         pend.push_back(Pending{io_out, nullptr, nullptr});
       } else if (ex[1]) {
         emit_replay(ops, pend, M, mstride);
+        const double attn2_flops = 4.0 * Bt * (double)NH * N * (double)Tt * DH;
+        const bool fuse2 = fuse_attn && !fp8 && DH == 72 && N % G3_BM == 0;
+        if (fuse2) {  // cross-attention in the tail of its query projection: K / V = the hoisted text K/V of this block, mask bias per key
+          Op<T> q = mk_gemm(KC_GEMM_Q2, EPI_BIAS_ATTN_TAIL, h, B.w_q2, B.b_q2, qc, M, D, D, D, D);
+          q.g.att_k = kv2 + (size_t)b * 2 * D; q.g.att_v = kv2 + (size_t)b * 2 * D + D; q.g.att_out = attn_o; q.g.att_bias = bias_buf; q.g.att_ldk = ldkv; q.g.att_ldo = D;
+          q.g.att_nk = Tt; q.g.att_scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+          q.flops += attn2_flops; q.bytes += 2.0 * Mt * (double)D * sizeof(T);
+          ops.push_back(q);
+          a8_src = nullptr;
+        } else {
         push_gemm(ops, mk_gemm(KC_GEMM_Q2, EPI_BIAS, h, B.w_q2, B.b_q2, qc, M, D, D, D, D));
         Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_CROSS; a.attn_masked = true;
         a.a.q = qc; a.a.k = kv2 + (size_t)b * 2 * D; a.a.v = kv2 + (size_t)b * 2 * D + D; a.a.out = attn_o; a.a.bias = bias_buf;
         a.a.ldq = D; a.a.ldk = a.a.ldv = ldkv; a.a.ldo = D; a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = Tt; a.a.dh = DH;
         a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
-        a.flops = 4.0 * Bt * (double)NH * N * (double)Tt * DH; a.bytes = (2.0 * M + 2.0 * Mt) * D * sizeof(T);
+        a.flops = attn2_flops; a.bytes = (2.0 * M + 2.0 * Mt) * D * sizeof(T);
         ops.push_back(a);
+        }
         push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, live(b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
         if (live(b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
@@ -936,6 +962,7 @@ template <typename T> class EngineT : public EngineBase {
   // kernel for long K with a plain tile count (FF2); 8 mixed waves for the N = 1152 RMW epilogues and QKV.
   // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
   int gemm_impl_cls[KC_COUNT];
+  bool fuse_attn = true;  // attention in the tail of the query projection when the geometry allows (env ECAD_FUSE_ATTN=0: separate launches)
   int gemm_variant = 1;  // K-loop schedule (GemmArgs::variant); env ECAD_GEMM_SCHED=0: the round-1 schedule
   bool g2_attr[4][KC_COUNT] = {};
   bool split_qkv = true;  // env ECAD_SPLIT_QKV=0 keeps the single 3D-wide launch
@@ -969,8 +996,25 @@ template <typename T> class EngineT : public EngineBase {
     hipLaunchKernelGGL((pgemm_kernel<T, EPI, TAG>), dim3(grid), dim3(512), PG_LDS_BYTES, s, g);
     return ECAD_OK;
   }
+  // query projection with its attention in the tail (gemm3s_attn.h): gemm3s only, tiles inside one sample, two 72-wide heads per tile
+  bool g3a_attr[2] = {};
+  template <int EPI, int TAG> int launch_g3_attn(const GemmArgs<T>& g, hipStream_t s) {
+    if (g.N % G3_BN || g.rows_per_batch % G3_BM || g.M % G3_BM || DH != 72 || !g.att_k || !g.att_v || !g.att_out || g.att_nk < 1 || g.att_ldo % 4 || g.att_ldk % 8)
+      return fail(ECAD_E_UNSUPPORTED, "fused attention needs 256-row tiles inside one sample and head_dim 72");
+    if (EPI == EPI_BIAS_ATTN && g.att_nk % G3A_KC) return fail(ECAD_E_UNSUPPORTED, "fused self-attention needs a key count that is a multiple of 128");
+    if (!g3a_attr[EPI - EPI_BIAS_ATTN]) {
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+      g3a_attr[EPI - EPI_BIAS_ATTN] = true;
+    }
+    const int tiles3 = (g.M / G3_BM) * (g.N / G3_BN);
+    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
+    return ECAD_OK;
+  }
   int launch_gemm(int epi, int cls, const GemmArgs<T>& g, hipStream_t s) {
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
+    if (epi == EPI_BIAS_ATTN && cls == KC_GEMM_QKV) return launch_g3_attn<EPI_BIAS_ATTN, KC_GEMM_QKV>(g, s);
+    if (epi == EPI_BIAS_ATTN_TAIL && cls == KC_GEMM_Q2) return launch_g3_attn<EPI_BIAS_ATTN_TAIL, KC_GEMM_Q2>(g, s);
+    if (epi == EPI_BIAS_ATTN || epi == EPI_BIAS_ATTN_TAIL) return fail(ECAD_E_INVALID, "fused attention epilogue on call site %d", cls);
     if (g.N % PG_BN == 0) {
 #define G144(E, C) if (epi == E && cls == C) return launch_pg<E, C>(g, s)
       G144(EPI_BIAS, KC_GEMM_QKV); G144(EPI_BIAS, KC_GEMM_KV1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT1); G144(EPI_BIAS, KC_GEMM_Q2); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT2);

@@ -19,7 +19,8 @@
 
 namespace ecad {
 
-enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_BIAS_CACHE_RESID = 3 };
+enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_BIAS_CACHE_RESID = 3,
+               EPI_BIAS_ATTN = 4, EPI_BIAS_ATTN_TAIL = 5 };  // gemm3s.h only: the tile is a query projection, attention runs in its tail (gemm3s_attn.h)
 
 template <typename T> struct GemmArgs {
   const T* A;
@@ -33,6 +34,14 @@ template <typename T> struct GemmArgs {
   int rows_per_batch;       // image tokens per sample (row -> b)
   int M, N, K;
   int lda, ldw, ldc, ldr;
+  // EPI_BIAS_ATTN / EPI_BIAS_ATTN_TAIL: keys / values of the tile's sample (rows b * att_nk + key, row stride att_ldk, head h at column h * 72),
+  // additive per-key bias [Bt][att_nk] (TAIL), output rows [M][att_ldo]
+  const T* att_k;
+  const T* att_v;
+  T* att_out;
+  const float* att_bias;
+  int att_ldk, att_ldo, att_nk;
+  float att_scale_log2e;
   int variant;  // K-loop schedule of gemm3s.h / gemm2w.h: 0 = every wave issues its LDS-DMA pieces in one block after the barrier (round 1),
                 // 1 = staggered: pieces interleaved one per MFMA group, waves 0-3 in the first half of the step, waves 4-7 in the second
 };

@@ -6,6 +6,7 @@
 #pragma once
 #include "common.h"
 #include "gemm.h"
+#include "gemm3s_attn.h"
 
 namespace ecad {
 
@@ -376,6 +377,10 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
 #endif
   if (!bias_in_loop) load_bias();
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (EPI == EPI_BIAS_ATTN || EPI == EPI_BIAS_ATTN_TAIL) {  // the tile is a query projection: its attention runs here (gemm3s_attn.h)
+    g3_attention_epilogue<T, EPI == EPI_BIAS_ATTN_TAIL>(p, smem, m0, tn, acc, bvs);
+    return;
+  }
   // The C tile (and the per-wave gate copies behind it) is staged in LDS rows that only their own wave writes and reads, so the only hazard
   // is the operand ring underneath.  When the last K-step reads stage 2 (nk % 3 == 0: every K of the model) the tile lies in stages 0 and 1,
   // which nobody touches after the last step's barrier: no workgroup barrier at all, and a wave that leaves the loop early streams its rows out

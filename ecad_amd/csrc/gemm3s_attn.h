@@ -1,0 +1,228 @@
+// gemm3s_attn.h -- attention fused into the tail of the query projection (epilogues EPI_BIAS_ATTN / EPI_BIAS_ATTN_TAIL of gemm3s.h).
+//
+// A 256 x 144 tile of the Q projection of a PixArt block is exactly one attention work item pair: 256 query rows of ONE sample (N % 256 == 0)
+// times the 144 columns of TWO heads (d_h 72).  The stand-alone attention kernels of the alpha-256 shapes are latency chains, not throughput
+// kernels (stamped: 26k cycles per (sample, head) item for ~4k cycles of MFMA + softmax work: global loads of Q, K, V -> LDS -> barriers -> ...,
+// twice per CU, 25-31 us per launch for 4.5-9.7 GFLOP), and the Q they read was written to HBM by the GEMM a few microseconds earlier.  Here the
+// workgroup that has just produced the Q tile keeps it in LDS, stages the K / V rows of its sample and heads, and runs the attention of
+// attention128.h (same fragment layouts, same operation order: S^T = K Q^T strips in registers, exp2'd P straight into O^T = V^T P^T, ones column
+// for the denominator, running-max rescale across key chunks) for its 32 query rows per wave -- one launch, no Q round trip through HBM.
+//   self-attention  (cached_transformer_block.py:231-239 -> Attention.forward [ext]): K, V = columns [D, 3D) of the fused QKV buffer, written by the
+//                   wide K,V GEMM that now runs BEFORE this launch; Nk = tokens per sample
+//   cross-attention (:282-288): K, V = the hoisted text K/V of the block, Nk = text tokens, additive mask bias (TAIL)
+// Output rows go to the attention-output buffer the out-projection reads, as the stand-alone kernel's do.
+#pragma once
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+
+namespace ecad {
+
+constexpr int G3A_DH = 72, G3A_KC = 128;
+constexpr int G3A_Q_BYTES = 256 * 152 * 2;                                   // the C tile of gemm3s.h (CS = 152), i.e. the Q tile
+constexpr int G3A_KV_OFF = (G3A_Q_BYTES + 1023) & ~1023;                     // K / V staging behind it
+constexpr int G3A_LDS_BYTES = G3A_KV_OFF + attn_lds_bytes<G3A_KC, G3A_DH>();  // 78848 + 47616: inside the 3 x 51200 ring of gemm3s.h
+
+// Called by every thread of the workgroup after the K loop.  `ring_free`: false => the caller has NOT yet synchronised the workgroup after the last
+// K-step (other waves may still read operand stage 2).  acc / bvs: the wave's 32 x 144 accumulators and bias vectors (gemm3s.h layout).
+template <typename T, bool TAIL>
+ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, int tn, const f32x4 (&acc)[2][9], const f32x4 (&bvs)[9]) {
+  constexpr int DH = G3A_DH, KC = G3A_KC, KS = AttCfg<DH>::KS, VS = AttCfg<DH>::VS, ND = AttCfg<DH>::ND, KSTEPS = AttCfg<DH>::KSTEPS, NCH = AttCfg<DH>::NCH;
+  constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0), CS = 152, FN = 9, FM = 2;
+  constexpr int MAXL = (KC * NCH * 2 + 511) / 512;  // 5 staging loads per thread and chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  T* qtile = reinterpret_cast<T*>(smem);
+  T* Ks = reinterpret_cast<T*>(smem + G3A_KV_OFF);
+  T* Vs = Ks + KC * KS;
+  float* bias_s = reinterpret_cast<float*>(Vs + KC * VS);
+  const int b = m0 / p.rows_per_batch;  // the tile lies inside one sample (checked on the host)
+  const int nkc = (p.att_nk + KC - 1) / KC;
+  const T* Kg = p.att_k + (size_t)b * p.att_nk * p.att_ldk;
+  const T* Vg = p.att_v + (size_t)b * p.att_nk * p.att_ldk;
+
+  Pack8 stg[MAXL];
+  auto load_stage = [&](int hd, int kc) {
+    const int h = 2 * tn + hd;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      int id = tid + i * 512;
+      stg[i].u = (u32x4){0, 0, 0, 0};
+      if (id < 2 * KC * NCH) {
+        const bool isv = id >= KC * NCH;
+        id = isv ? id - KC * NCH : id;
+        const int key = id / NCH, c = id - key * NCH;
+        const int gk = kc * KC + key;
+        if (gk < p.att_nk) stg[i] = gload16((isv ? Vg : Kg) + (size_t)gk * p.att_ldk + (size_t)h * DH + c * 8);
+      }
+    }
+  };
+  auto store_stage = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      int id = tid + i * 512;
+      if (id < 2 * KC * NCH) {
+        const bool isv = id >= KC * NCH;
+        id = isv ? id - KC * NCH : id;
+        const int key = id / NCH, c = id - key * NCH;
+        T* dst = isv ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
+        *reinterpret_cast<u32x4*>(dst) = stg[i].u;
+      }
+    }
+    if (TAIL) {
+      for (int i = tid; i < KC; i += 512) {
+        const int gk = kc * KC + i;
+        float bv = ATT_NEG;
+        if (gk < p.att_nk) bv = p.att_bias ? p.att_bias[(size_t)b * p.att_nk + gk] * 1.4426950408889634f : 0.f;
+        bias_s[i] = bv;
+      }
+    }
+  };
+
+  load_stage(0, 0);  // in flight while the Q tile is converted
+  __syncthreads();   // every wave is out of the K loop: the operand ring is free
+  // Q tile: bias, rounding to the storage type (what the stand-alone path writes to and reads back from HBM), row-major [256][152]
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nl = 16 * j + 4 * g;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wave * 32 + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) float_to_elem4<T>(o, r, acc[i][j][r] + bvs[j][r]);
+      *reinterpret_cast<u32x2*>(qtile + ml * CS + nl) = o.u;
+    }
+  }
+  // K / V staging area: zero (the padding columns of K and V must be zero), ones column of V (softmax denominator by the PV MFMAs)
+  for (int i = tid; i < KC * (KS + VS) / 8; i += 512) reinterpret_cast<u32x4*>(Ks)[i] = (u32x4){0, 0, 0, 0};
+  __syncthreads();
+  for (int i = tid; i < KC; i += 512) Vs[i * VS + DH] = (T)1.0f;
+
+  for (int hd = 0; hd < 2; ++hd) {
+    const int h = 2 * tn + hd;
+    f32x4 oacc[2][ND];
+    float m_run[2] = {ATT_NEG, ATT_NEG};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // query fragments of this head from the wave's own rows of the Q tile (B operand: lane (l15, g) holds 8 consecutive d of query row l15)
+    Pack8 qfr[2][KSTEPS];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        qfr[r][ks].u = (u32x4){0, 0, 0, 0};
+        if (32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = lds_read16(qtile + (wave * 32 + r * 16 + l15) * CS + hd * DH + 32 * ks + 8 * g);
+      }
+    for (int kc = 0; kc < nkc; ++kc) {
+      __syncthreads();  // every wave finished reading the previous chunk (first chunk: the zero fill and the ones column are in place)
+      store_stage(kc);
+      __syncthreads();
+      if (kc + 1 < nkc) load_stage(hd, kc + 1);
+      else if (hd == 0) load_stage(1, 0);
+
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        const T* Kh = Ks + half * 64 * KS;
+        const T* Vh = Vs + half * 64 * VS;
+        f32x4 s[2][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          s[0][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          s[1][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            const Pack8 kf = lds_read16(Kh + (16 * f + l15) * KS + 32 * ks + 8 * g);
+            s[0][f] = mfma16<T>(kf, qfr[0][ks], s[0][f]);
+            s[1][f] = mfma16<T>(kf, qfr[1][ks], s[1][f]);
+          }
+        }
+        float m_new[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float mt = ATT_NEG;
+          if (TAIL) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + half * 64 + 16 * f + 4 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                s[r][f][e] = s[r][f][e] * p.att_scale_log2e + bv[e];
+                mt = fmaxf(mt, s[r][f][e]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[r][f][e]);
+            mt *= p.att_scale_log2e;
+          }
+          mt = fmaxf(mt, __shfl_xor(mt, 16));
+          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          m_new[r] = fmaxf(m_run[r], mt);
+          const float alpha = fast_exp2(m_run[r] - m_new[r]);
+          m_run[r] = m_new[r];
+#pragma unroll
+          for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oacc[r][nd][e] *= alpha;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Pack8 pf[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float p0, p1;
+              if (TAIL) {
+                p0 = fast_exp2(s[r][2 * s2][e] - m_new[r]);
+                p1 = fast_exp2(s[r][2 * s2 + 1][e] - m_new[r]);
+              } else {
+                p0 = fast_exp2(__builtin_fmaf(s[r][2 * s2][e], p.att_scale_log2e, -m_new[r]));
+                p1 = fast_exp2(__builtin_fmaf(s[r][2 * s2 + 1][e], p.att_scale_log2e, -m_new[r]));
+              }
+              float_to_elem<T>(pf[r], e, p0);
+              float_to_elem<T>(pf[r], 4 + e, p1);
+            }
+          const int krow = 32 * s2 + 4 * g + (l15 >> 2);
+          const int dcol = 4 * (l15 & 3);
+#pragma unroll
+          for (int nd = 0; nd < ND; ++nd) {
+            const Pack4 lo = lds_read_tr16(Vh + krow * VS + 16 * nd + dcol);
+            const Pack4 hi = lds_read_tr16(Vh + (krow + 16) * VS + 16 * nd + dcol);
+            Pack8 vf;
+            vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
+            oacc[0][nd] = mfma16<T>(vf, pf[0], oacc[0][nd]);
+            oacc[1][nd] = mfma16<T>(vf, pf[1], oacc[1][nd]);
+          }
+        }
+      }
+    }
+    // denominator = O^T row DH (the ones column), normalise, round, store the wave's 32 rows of this head
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      constexpr int DL = DH & 15;
+      const float den = __shfl(oacc[r][DH >> 4][DL & 3], l15 + 16 * (DL >> 2));
+      const float inv = 1.0f / den;
+      const int m = m0 + wave * 32 + r * 16 + l15;
+      if (m < p.M) {
+        T* orow = p.att_out + (size_t)m * p.att_ldo + (size_t)h * DH;
+#pragma unroll
+        for (int nd = 0; nd < NDO; ++nd) {
+          if (16 * nd + 4 * g + 4 <= DH) {
+            Pack4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) float_to_elem4<T>(o, e, oacc[r][nd][e] * inv);
+            *reinterpret_cast<u32x2*>(orow + 16 * nd + 4 * g) = o.u;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace ecad

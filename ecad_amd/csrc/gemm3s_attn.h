@@ -47,14 +47,16 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
 #pragma unroll
     for (int i = 0; i < MAXL; ++i) {
       int id = tid + i * 512;
-      stg[i].u = (u32x4){0, 0, 0, 0};
-      if (id < 2 * KC * NCH) {
-        const bool isv = id >= KC * NCH;
-        id = isv ? id - KC * NCH : id;
-        const int key = id / NCH, c = id - key * NCH;
-        const int gk = kc * KC + key;
-        if (gk < p.att_nk) stg[i] = gload16((isv ? Vg : Kg) + (size_t)gk * p.att_ldk + (size_t)h * DH + c * 8);
-      }
+      // branch-free: lanes without a piece and rows past the end read the chunk's first row (always there) and are dropped / zeroed in store_stage.
+      // A load under a lane-dependent branch makes the compiler give up counting: it then waits vmcnt(0) at the next use of ANY earlier load --
+      // here the bias vectors the Q tile needs at once, i.e. the K / V latency this prefetch is meant to hide.
+      const bool has = id < 2 * KC * NCH;
+      const bool isv = id >= KC * NCH;
+      id = isv ? id - KC * NCH : id;
+      const int key = id / NCH, c = id - key * NCH;
+      const bool ok = has && kc * KC + key < p.att_nk;
+      const int gk = ok ? kc * KC + key : kc * KC;
+      stg[i] = gload16((isv ? Vg : Kg) + (size_t)gk * p.att_ldk + (size_t)h * DH + (ok ? c * 8 : 0));
     }
   };
   auto store_stage = [&](int kc) {
@@ -66,7 +68,7 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
         id = isv ? id - KC * NCH : id;
         const int key = id / NCH, c = id - key * NCH;
         T* dst = isv ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
-        *reinterpret_cast<u32x4*>(dst) = stg[i].u;
+        *reinterpret_cast<u32x4*>(dst) = kc * KC + key < p.att_nk ? stg[i].u : (u32x4){0, 0, 0, 0};
       }
     }
     if (TAIL) {

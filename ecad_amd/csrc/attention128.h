@@ -167,12 +167,16 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
           mt = fmaxf(mt, __shfl_xor(mt, 16));
           mt = fmaxf(mt, __shfl_xor(mt, 32));
           m_new[r] = fmaxf(m_run[r], mt);
-          const float alpha = fast_exp2(m_run[r] - m_new[r]);
+          // the running maximum stops growing after the first chunks of a long key sequence: alpha == exp2(0) == 1.0 exactly for every lane then, and
+          // skipping the rescale of the 2 x ND accumulator fragments is bit-identical (wave-uniform branch)
+          if (__builtin_amdgcn_ballot_w64(m_new[r] > m_run[r]) != 0) {
+            const float alpha = fast_exp2(m_run[r] - m_new[r]);
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) oacc[r][nd][e] *= alpha;
+          }
           m_run[r] = m_new[r];
-#pragma unroll
-          for (int nd = 0; nd < ND; ++nd)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) oacc[r][nd][e] *= alpha;
         }
         // ---- O^T += V^T P^T: k slot (g, j) of 32-key step s2 <-> key 32 s2 + (j < 4 ? 4g + j : 16 + 4g + j - 4)
 #pragma unroll

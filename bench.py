@@ -38,6 +38,10 @@ BATCH = 16
 NUM_STEPS = 20
 GUIDANCE = 4.5
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+# What a register-only loop of back-to-back 16x16x32 f16 MFMAs sustains on all 256 CUs with random operands (scripts/probe_mfma_shape_power.hip, ~1 s runs:
+# 2.03 PFLOP/s at an in-kernel clock of 2.03 GHz; 2.43 PFLOP/s at 2.38 GHz with near-constant operands): the power cap, not the issue rate, is the ceiling a
+# GEMM on random data can approach.  Context only: `peak` and `frac` stay on the guide's 2.5 PFLOP/s.
+SUSTAINED_MFMA_RANDOM_TFLOPS = 2030.0
 PEAK_HBM_GBS = 8000.0
 
 torch = None  # imported by the rank processes only: the launcher parent never loads it
@@ -456,6 +460,8 @@ def main():
                 "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_MFMA_TFLOPS,
+                "power_capped_mfma_tflops_random_operands": SUSTAINED_MFMA_RANDOM_TFLOPS,
+                "frac_of_power_capped": achieved / SUSTAINED_MFMA_RANDOM_TFLOPS,
                 "traffic": pmc.get(dom, {}).get("hbm_bytes_per_launch"),
                 "traffic_source": pmc_file,
                 "kernel_sources_stamp": stamp,

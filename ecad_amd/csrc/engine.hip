@@ -284,6 +284,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
       if (strcmp(gi, "persistent") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
+      if (strcmp(gi, "tile128") == 0) tile128_mode = 2;
       if (strcmp(gi, "wide") == 0) gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_SMALL] = 2;
     }
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
@@ -962,6 +963,7 @@ template <typename T> class EngineT : public EngineBase {
   // kernel for long K with a plain tile count (FF2); 8 mixed waves for the N = 1152 RMW epilogues and QKV.
   // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
   int gemm_impl_cls[KC_COUNT];
+  int tile128_mode = 0;  // 2: every GEMM with N % 128 == 0 on the 128 x 128 kernel (ECAD_GEMM=tile128)
   bool fuse_attn = true;  // attention in the tail of the query projection when the geometry allows (env ECAD_FUSE_ATTN=0: separate launches)
   int gemm_variant = 1;  // K-loop schedule (GemmArgs::variant); env ECAD_GEMM_SCHED=0: the round-1 schedule
   bool g2_attr[4][KC_COUNT] = {};
@@ -1010,12 +1012,18 @@ template <typename T> class EngineT : public EngineBase {
     hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
     return ECAD_OK;
   }
+  // Few rows (batch 1-2: M = 512-1024) leave most CUs without a 256-row tile: 2 x 8 tiles for an N = 1152 GEMM at batch 1.  The 128 x 128 kernel of
+  // gemm.h covers the same problem with 2.25-4.5 x as many workgroups: opt-in (env ECAD_GEMM=tile128), measured +8 % at batch 1 and 2, nothing at
+  // batch 4 -- a batch of 1, 2 or 4 images takes the same 56-58 ms, the chain of 2 149 dependent launches at ~26 us each (18-72 K-steps of ~0.8 us
+  // whatever the tile count), not the tile count, is what small batches wait for.  Off by default so that the small-batch engine tests keep
+  // exercising the kernels the headline configuration runs.
+  bool use_tile128(const GemmArgs<T>& g) const { return tile128_mode == 2 && g.N % 128 == 0; }
   int launch_gemm(int epi, int cls, const GemmArgs<T>& g, hipStream_t s) {
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
     if (epi == EPI_BIAS_ATTN && cls == KC_GEMM_QKV) return launch_g3_attn<EPI_BIAS_ATTN, KC_GEMM_QKV>(g, s);
     if (epi == EPI_BIAS_ATTN_TAIL && cls == KC_GEMM_Q2) return launch_g3_attn<EPI_BIAS_ATTN_TAIL, KC_GEMM_Q2>(g, s);
     if (epi == EPI_BIAS_ATTN || epi == EPI_BIAS_ATTN_TAIL) return fail(ECAD_E_INVALID, "fused attention epilogue on call site %d", cls);
-    if (g.N % PG_BN == 0) {
+    if (g.N % PG_BN == 0 && !use_tile128(g)) {
 #define G144(E, C) if (epi == E && cls == C) return launch_pg<E, C>(g, s)
       G144(EPI_BIAS, KC_GEMM_QKV); G144(EPI_BIAS, KC_GEMM_KV1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT1); G144(EPI_BIAS, KC_GEMM_Q2); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT2);
       G144(EPI_BIAS_GELU, KC_GEMM_FF1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_FF2); G144(EPI_BIAS, KC_GEMM_TEXTKV);

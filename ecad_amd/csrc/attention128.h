@@ -11,11 +11,15 @@
 // of attention.h: self-attention 9.1 -> 7.1 ms per alpha-256 batch, 256 -> 185 ms per Sigma-1024 batch.  Ablation on the FLUX shape (scripts/bench_flux_attn.py, 795 us): without the staging + barriers 508 us, without the K fragment reads 575,
 // without the V reads 704, without the PV MFMAs 737, without the exp2s 787 -- the waves run the S / softmax / PV phases in lockstep
 // behind the per-chunk barriers, so LDS, MFMA and VALU time add up instead of overlapping.  Measured null or negative on top of this
-// kernel: skipping the accumulator rescale when no running maximum moved (+-0); K/V chunks by LDS-DMA into a double-buffered,
+// kernel: K/V chunks by LDS-DMA into a double-buffered,
 // source-swizzled tile with one barrier per chunk and an all-ones MFMA for the denominator (-1 %: kept out of the tree); handing
 // each XCD a contiguous run of work items so the 18 query blocks of a (sample, head) share one L2 (+9 % time on FLUX, +13 % on
 // Sigma-1024: the CUs of an XCD then request the same K/V lines at the same moment); 4-wave workgroups on 128-query items, two per
 // CU (33 -> 52 us per alpha-256 self-attention launch: twice the K/V staging per query row outweighs the decoupled barriers).
+// Round 2: the accumulator rescale is skipped when no lane's running maximum grew (wave-uniform branch, exact: alpha == 1.0): +-0 on the PixArt shapes as
+// measured before, -2.7 % on FLUX-1024's 4608-key attention (273 -> 265 ms per batch), kept.  Three more rewrites were measured slower there (output stores
+// deferred behind the next item's Q prefetch; LDS-transposed 16-byte output stores; all K fragments of a 64-key unit requested before the first MFMA) and a
+// fixed s_setprio split between the two waves of a SIMD changed nothing (gemm3s_attn.h).
 #pragma once
 #include "attention.h"
 #include "common.h"

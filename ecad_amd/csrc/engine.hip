@@ -1077,6 +1077,9 @@ template <typename T> class EngineT : public EngineBase {
   int ln16 = 1;  // 16 lanes per row (D = 1152: 9 chunks per lane), ln16 rows per lane group: 16.2 -> 15.3 us per launch at 1 row, 18.3 at 2, 25.7 at 4
                  // (the pass is bound by the number of loads in flight, not by bandwidth); env ECAD_LN16=0: one wave per row
   int launch_ln(const FlushArgs& f, hipStream_t s) {
+#ifdef ECAD_ABL_NOLN  // timing ablation only (wrong results): what the LayerNorm launches without pending replays cost end to end
+    if (f.n_src == 0) return ECAD_OK;
+#endif
     const int cpr = f.D / 8;
     const int grid = (f.M + 3) / 4;
     if (f.D % 8) return fail(ECAD_E_INVALID, "D %% 8 != 0");

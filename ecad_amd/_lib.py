@@ -132,6 +132,7 @@ SIGNATURES = {
     "ecad_op_gemm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I64, _I, _P]),
     "ecad_op_gemm_ex": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I64, _I64, _P, _P, _P, _I64, _I, _P]),
     "ecad_op_attention_ex": (_I, [_P, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
+    "ecad_op_qproj_attention": (_I, [_P, _I, _P, _P, _P, _P, _P, _I64, _P, _P, _I, _I, _I, _P]),
     "ecad_op_ln_modulate": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _I64, _I, _P]),
     "ecad_op_cache_accumulate": (_I, [_P, _P, _I, _I, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _I64, _I, _P]),
     "ecad_op_attention": (_I, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),

@@ -85,6 +85,8 @@ struct EngineBase {
                       const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t st) = 0;
   virtual int op_gemm_ex(int kernel, int site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int64_t lda, int64_t ldc,
                          void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t st) = 0;
+  virtual int op_qproj_attention(int site, const void* x, const void* wq, const float* bq, const void* k, const void* v, int64_t ld_kv, const float* key_bias, void* out,
+                                 int Bt_, int n_tokens, int n_keys, hipStream_t st) = 0;
   virtual int op_attention_ex(int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H,
                               int Nq, int Nk, int dh, const float* bias, hipStream_t st) = 0;
   virtual int op_ln(const void* x, void* y, int M, int D, const float* tsh, const float* tsc, const void* msh, const void* msc, int64_t mstride,
@@ -1439,6 +1441,23 @@ template <typename T> class EngineT : public EngineBase {
   }
   // The kernel is named by the caller: the per-class choice table is overridden for this one launch and restored, so the instantiation is
   // exactly the one the engine's call site `site` launches.  Refuses (never substitutes) when the kernel cannot run the shape.
+  int op_qproj_attention(int site, const void* x, const void* wq, const float* bq, const void* k, const void* v, int64_t ld_kv, const float* key_bias, void* out, int Bt_,
+                         int n_tokens, int n_keys, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    const bool tail = site == KC_GEMM_Q2;
+    if (site != KC_GEMM_QKV && !tail) return fail(ECAD_E_INVALID, "call_site %d: the fused launch exists for the self- (0) and cross-attention (2) query projections", site);
+    if (DH != G3A_DH || D % G3_BN || n_tokens % G3_BM || Bt_ < 1 || n_keys < 1 || (!tail && (n_keys != n_tokens || n_keys % G3A_KC)))
+      return fail(ECAD_E_UNSUPPORTED, "fused query projection + attention needs d_h 72, n_tokens %% 256 == 0 (self: keys == tokens); got d_h %d, %d tokens, %d keys", DH, n_tokens, n_keys);
+    GemmArgs<T> g{};
+    g.A = (const T*)x; g.W = (const T*)wq; g.bias = bq; g.C = nullptr; g.M = Bt_ * n_tokens; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.ldr = D;
+    g.rows_per_batch = n_tokens; g.variant = gemm_variant;
+    g.att_k = (const T*)k; g.att_v = (const T*)v; g.att_out = (T*)out; g.att_bias = tail ? key_bias : nullptr; g.att_ldk = (int)ld_kv; g.att_ldo = D; g.att_nk = n_keys;
+    g.att_scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+    const int rc = launch_gemm(tail ? EPI_BIAS_ATTN_TAIL : EPI_BIAS_ATTN, site, g, s);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return ECAD_OK;
+  }
   int op_gemm_ex(int kernel, int site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int Nn, int K, int64_t lda, int64_t ldc, void* resid,
                  const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, hipStream_t s) override {
     HIPCHK(hipSetDevice(dev));
@@ -1585,6 +1604,10 @@ int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const flo
 int ecad_op_gemm_ex(EcadEngine* e, int kernel, int call_site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int64_t lda, int64_t ldc,
                     void* resid, const float* gate_table, const void* gate_mod, int64_t gate_mod_stride, int rows_per_batch, void* stream) {
   ENG(e); return E->op_gemm_ex(kernel, call_site, epi, A, W, bias, out, M, N, K, lda, ldc, resid, gate_table, gate_mod, gate_mod_stride, rows_per_batch, (hipStream_t)stream);
+}
+int ecad_op_qproj_attention(EcadEngine* e, int call_site, const void* x, const void* wq, const float* bq, const void* k, const void* v, int64_t ld_kv, const float* key_bias,
+                            void* out, int Bt, int n_tokens, int n_keys, void* stream) {
+  ENG(e); return E->op_qproj_attention(call_site, x, wq, bq, k, v, ld_kv, key_bias, out, Bt, n_tokens, n_keys, (hipStream_t)stream);
 }
 int ecad_op_attention_ex(EcadEngine* e, int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream) {
   ENG(e); return E->op_attention_ex(kernel, q, ldq, k, ldk, v, ldv, out, ldo, B, H, Nq, Nk, dh, bias, (hipStream_t)stream);

@@ -293,6 +293,16 @@ class EcadEngine:
         self._chk(self.lib.ecad_op_cache_accumulate(self._h, h.data_ptr(), M, D, n, arr(srcs), arr(gate_tables), arr(gate_mods), int(mod_stride), int(rows_per_batch), _stream_ptr()))
         return h
 
+    def op_qproj_attention(self, site: str, x, wq, bq, k, v, Bt: int, n_tokens: int, n_keys: int, key_bias=None):
+        """``ecad_op_qproj_attention``: the query projection of a block with the attention of its rows in the GEMM tail (the production launch on the
+        256 / 1024 / 4096-token geometries).  site: "qkv" (self-attention) | "attn2_q" (cross-attention, additive ``key_bias`` [Bt, n_keys]).  k / v: [Bt*n_keys, ld]
+        views (column slices of a fused buffer allowed: head h at column h * 72 of the view)."""
+        out = torch.empty((Bt * n_tokens, wq.shape[0]), device=self.device, dtype=self.dtype)
+        assert k.stride(0) == v.stride(0)
+        self._chk(self.lib.ecad_op_qproj_attention(self._h, self.GEMM_SITES[site], x.data_ptr(), wq.data_ptr(), _ptr(bq), k.data_ptr(), v.data_ptr(), k.stride(0), _ptr(key_bias),
+                                                   out.data_ptr(), Bt, n_tokens, n_keys, _stream_ptr()))
+        return out
+
     def op_attention(self, q, k, v, B, H, Nq, Nk, dh, bias=None, kernel: str = "auto"):
         """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer).  kernel: auto | generic (attention.h) | shared (attention128.h)."""
         out = torch.empty((B * Nq, H * dh), device=self.device, dtype=self.dtype)

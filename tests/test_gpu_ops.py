@@ -272,6 +272,53 @@ def test_attention_generic_kernel(dtype_name, dh, Nq, Nk, masked):
         assert torch.equal(auto, out)
 
 
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("kind,Bt,Ntok,Nk", [("self", 3, 256, 256), ("self", 2, 1024, 1024), ("self", 1, 4096, 4096), ("cross", 3, 256, 120), ("cross", 2, 1024, 300),
+                                            ("cross", 2, 256, 1)])
+def test_query_projection_with_attention_in_its_tail(dtype_name, kind, Bt, Ntok, Nk):
+    """gemm3s_attn.h through ecad_op_qproj_attention: the launch the engine uses for attention on the 256 / 1024 / 4096-token geometries -- the Q projection
+    (256 x 144 tiles = one sample x two heads) with softmax(Q K^T / sqrt(72) + bias) V of its rows in the GEMM tail.  Reference: fp32 projection of the
+    rounded inputs, Q rounded to the storage type (the value the separate launches pass through HBM), fp32 attention.  Judged per 256 x 144 output tile
+    (= per workgroup), worst tile.  Self: K / V are column slices of a fused [M, 3D] buffer as the engine lays it out; cross: a [Bt*T, 2D] slice of a wider
+    buffer, ragged key counts, additive -10000 mask, one sample with a single live key."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    H, dh = 16, 72
+    D = H * dh
+    x = _r((Bt * Ntok, D), dt, 1.0, 1)
+    wq = _r((D, D), dt, 0.03, 2)
+    bq = (_r((D,), torch.float32, 0.1, 3)).float()
+    if kind == "self":
+        buf = _r((Bt * Ntok, 3 * D), dt, 1.0, 4)
+        k, v, bias, site = buf[:, D : 2 * D], buf[:, 2 * D :], None, "qkv"
+    else:
+        buf = _r((Bt * Nk, 4 * D), dt, 1.0, 4)  # wider than [K | V]: the row stride is not 2 D
+        k, v, site = buf[:, D : 2 * D], buf[:, 2 * D : 3 * D], "attn2_q"
+        lens = torch.tensor([Nk, max(1, Nk // 3), 1][:Bt])
+        bias = ((1 - (torch.arange(Nk)[None] < lens[:, None]).float()) * -10000.0).cuda()
+    out = eng.op_qproj_attention(site, x, wq, bq, k, v, Bt, Ntok, Nk, key_bias=bias)
+    q = (x.float() @ wq.float().t() + bq).to(dt)
+    ref = _attn_ref(q, k, v, Bt, H, Ntok, Nk, dh, bias)
+    assert torch.isfinite(out).all()
+    assert within(tile_rel_l2(out, ref), ATT_TOL[dtype_name])
+    # and it is the same arithmetic as projection + attention as two launches
+    q2 = eng.op_gemm_ex("tile144", site, 0, x, wq, bq)
+    two = eng.op_attention(q2, k, v, Bt, H, Ntok, Nk, dh, bias=bias, kernel="shared")
+    assert torch.equal(out, two)
+
+
+def test_query_projection_with_attention_refuses_other_geometries():
+    eng = small_engine("float16")
+    D = 1152
+    x = _r((240, D), torch.float16, 1.0, 1)
+    wq = _r((D, D), torch.float16, 0.03, 2)
+    kv = _r((240, 2 * D), torch.float16, 1.0, 3)
+    with pytest.raises(ValueError, match="n_tokens % 256"):
+        eng.op_qproj_attention("qkv", x, wq, None, kv[:, :D], kv[:, D:], 1, 240, 240)
+    with pytest.raises(ValueError, match="query projections"):
+        eng.op_qproj_attention("ff1", x, wq, None, kv[:, :D], kv[:, D:], 1, 240, 240)
+
+
 @pytest.mark.parametrize("T", [120, 300, 1])
 def test_cross_attention_masked(T):
     """-10000 additive bias on discarded text tokens (pixart_transformer_2d_edited.py:282-289)."""

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "final_layer.h"
 #include "gemm2w.h"
 #include "gemm3s.h"
 #include "gemm3s8.h"
@@ -99,7 +100,7 @@ struct EngineBase {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Op {
-  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE, COMB, CUSTOM } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE, COMB, CUSTOM, FINAL } kind;
   int cls = KC_MISC;
   int epi = 0;
   GemmArgs<T> g{};
@@ -276,6 +277,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
     if (const char* l = getenv("ECAD_GEMM_SCHED")) gemm_variant = atoi(l);
     if (const char* l = getenv("ECAD_FUSE_ATTN")) fuse_attn = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_FUSE_FINAL")) fuse_final = atoi(l) != 0;
     if (const char* l = getenv("ECAD_PLAN_CACHE")) plan_lru_cap = (size_t)(atoi(l) > 0 ? atoi(l) : 0);
     custom_mask.assign((size_t)cfg.num_layers * 3, 0);
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
@@ -586,7 +588,7 @@ template <typename T> class EngineT : public EngineBase {
   std::string make_key() const {
     std::string k((const char*)bits.data(), bits.size());
     k.append((const char*)custom_mask.data(), custom_mask.size());
-    const int geo[9] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0};
+    const int geo[10] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0};
     k.append((const char*)geo, sizeof geo);
     return k;
   }
@@ -829,11 +831,21 @@ template <typename T> class EngineT : public EngineBase {
       }
     }
     // --- _create_output: norm_out, modulate with scale_shift_table[2, D] + embedded_timestep, proj_out, unpatchify
+    const size_t n_before = ops.size();
+    const size_t n_pend = pend.size();
     emit_ln(ops, pend, M, sst_out, sst_out + D, emb_s, emb_s, estride, mstride);
-    ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, xn, w_proj, b_proj, proj, M, PROJ_PAD, D, D, PROJ_PAD));
-    {
-      Op<T> o; o.kind = Op<T>::UNPATCH; o.cls = KC_MISC; o.p0 = proj; o.p2 = noise; o.call_out = bind_call;
-      ops.push_back(o);
+    if (fuse_final && D == 1152 && P * P * COUT == 32 && ops.size() > n_before && ops.back().kind == Op<T>::LN && !ops.back().f.y8) {
+      // one launch for replays + norm_out + modulate + proj_out + unpatchify (final_layer.h); the hidden states are not written back
+      Op<T>& o = ops.back();
+      o.kind = Op<T>::FINAL; o.cls = KC_GEMM_SMALL; o.p2 = noise; o.call_out = bind_call;
+      o.flops = 2.0 * M * 32.0 * D;
+      o.bytes = ((1.0 + (n_pend > 6 ? 0 : n_pend)) * M * (double)D + 32.0 * D + (double)M * 32) * sizeof(T);
+    } else {
+      ops.push_back(mk_gemm(KC_GEMM_SMALL, EPI_BIAS, xn, w_proj, b_proj, proj, M, PROJ_PAD, D, D, PROJ_PAD));
+      {
+        Op<T> o; o.kind = Op<T>::UNPATCH; o.cls = KC_MISC; o.p0 = proj; o.p2 = noise; o.call_out = bind_call;
+        ops.push_back(o);
+      }
     }
     // per-step reference overhead the calflops model counts (patch conv, t-embed, caption, proj_out)
     const int64_t per_sample_over = (int64_t)Tt * ((int64_t)CAP * D + (int64_t)D * D) + (int64_t)N * 16 * D + (256ll * D + 7ll * D * D) + (int64_t)N * D * 32;
@@ -966,6 +978,7 @@ template <typename T> class EngineT : public EngineBase {
   // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
   int gemm_impl_cls[KC_COUNT];
   int tile128_mode = 0;  // 2: every GEMM with N % 128 == 0 on the 128 x 128 kernel (ECAD_GEMM=tile128)
+  bool fuse_final = true;  // replays + norm_out + modulate + proj_out + unpatchify as one launch (final_layer.h; env ECAD_FUSE_FINAL=0: separate launches)
   bool fuse_attn = true;  // attention in the tail of the query projection when the geometry allows (env ECAD_FUSE_ATTN=0: separate launches)
   int gemm_variant = 1;  // K-loop schedule (GemmArgs::variant); env ECAD_GEMM_SCHED=0: the round-1 schedule
   bool g2_attr[4][KC_COUNT] = {};
@@ -1163,6 +1176,12 @@ template <typename T> class EngineT : public EngineBase {
         hipLaunchKernelGGL((comb_mod_kernel<T>), dim3(steps, L), dim3(256), 0, s, blk[0].sst, (int64_t)(L > 1 ? blk[1].sst - blk[0].sst : 0), (const T*)mod_all, comb, L, D);
         break;
       case Op<T>::MASKBIAS: hipLaunchKernelGGL(mask_bias_kernel, dim3((o.i0 + 255) / 256), dim3(256), 0, s, (const uint8_t*)o.p0, (float*)o.p2, o.i0); break;
+      case Op<T>::FINAL: {
+        FinalProj fq{};
+        fq.w = w_proj; fq.bias = b_proj; fq.out = o.call_out ? call_out : o.p2; fq.gh = Hl / P; fq.gw = Wl / P; fq.P = P; fq.Cout = COUT;
+        hipLaunchKernelGGL((final_layer_kernel<T, 36>), dim3((o.f.M + 15) / 16), dim3(256), 0, s, o.f, fq);
+        break;
+      }
       case Op<T>::UNPATCH: {
         T* dst = o.call_out ? (T*)call_out : (T*)o.p2;
         const int total = Bt * COUT * Hl * Wl;

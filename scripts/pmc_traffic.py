@@ -40,6 +40,8 @@ def classify(name: str) -> str | None:
         return "attn_cross" if masked.group(1) in ("1", "true") else "attn_self"
     if "patch_embed" in name:
         return "patch_embed"
+    if "final_layer_kernel" in name:
+        return "step_tail"
     return None
 
 

@@ -314,13 +314,14 @@ def test_attention_fused_into_the_query_projection_is_the_same_arithmetic(monkey
     assert torch.equal(outs["1"][1], outs["0"][1])
 
 
-@pytest.mark.parametrize("dtype,tol,hw", [(torch.float16, 6e-5, (32, 32)), (torch.bfloat16, 2e-4, (32, 32)), (torch.float16, 6e-5, (24, 40))])
+@pytest.mark.parametrize("dtype,tol,hw", [(torch.float16, 6e-5, (32, 32)), (torch.bfloat16, 2e-4, (32, 32)), (torch.float16, 6e-5, (24, 40)), (torch.float16, 6e-5, (18, 18))])
 def test_step_tail_in_one_launch(monkeypatch, dtype, tol, hw):
     """final_layer.h: pending cache replays + norm_out + modulate + proj_out + unpatchify (pixart_transformer_2d_edited.py:338-371) as one launch instead of
     LayerNorm kernel + padded GEMM + unpatchify.  Same formulas, same order of the replayed sources, same roundings to the storage type; only the summation
     order of the LayerNorm statistics and of the 1152-deep dot products differs, so the paths agree far inside one rounding (and every oracle parity test of
     this file runs with the fusion on, its default).  The random schedule leaves the last block's sub-layers cached at some steps (replays folded into the
-    launch) and executed at others.  (24, 40): 240 tokens per sample -- a workgroup's 16 rows straddle two samples; ragged tiles upstream."""
+    launch) and executed at others.  (24, 40): 240 tokens per sample -- a workgroup's 16 rows straddle two samples; ragged tiles upstream.  (18, 18): 81 tokens, M = 324 -- the last
+    workgroup owns 4 real rows."""
     from ecad_amd.engine import EcadEngine
 
     layers, steps, B = 2, 6, 2

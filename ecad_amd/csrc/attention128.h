@@ -20,6 +20,12 @@
 // measured before, -2.7 % on FLUX-1024's 4608-key attention (273 -> 265 ms per batch), kept.  Three more rewrites were measured slower there (output stores
 // deferred behind the next item's Q prefetch; LDS-transposed 16-byte output stores; all K fragments of a 64-key unit requested before the first MFMA) and a
 // fixed s_setprio split between the two waves of a SIMD changed nothing (gemm3s_attn.h).
+// Late round 2, by ablation on the FLUX shape (771 us per launch): staging compiled out 491, barriers compiled out 712, ONLY the next chunk's global loads
+// compiled out 615 -- asynchronous loads that cost 22 %: their address arithmetic (division by the pieces per row, att_row, 64-bit multiplies, 8 times per
+// thread and chunk) was VALU time taken from the softmax.  Now: d_h 128 derives every piece's offsets from the thread id with one multiply-add on a
+// wave-uniform chunk base (771 -> 700 us; FLUX-1024 end to end 2.03-2.09 -> 2.17 images/s on the A/B box), d_h 72 uses a uniform base + 32-bit offsets
+// (-1.3 %; per-thread offset ARRAYS were slower there: 979 -> 1126 us on the Sigma-1024 shape).  A double-buffered image with the stores between the two
+// 64-key units and one barrier per chunk was slower again (771 -> 796, 979 -> 1046).
 #pragma once
 #include "attention.h"
 #include "common.h"
@@ -57,38 +63,98 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
   __syncthreads();
   for (int i = tid; i < KC; i += 512) Vs[i * VS + DH] = (T)1.0f;
 
-  // staging ids run over [K chunks | V chunks]; for d_h = 128 a thread owns one chunk column of 4 K rows and 4 V rows
+  // staging ids run over [K chunks | V chunks]; for d_h = 128 a thread owns one chunk column of 4 K rows and 4 V rows.  Everything that depends on the
+  // thread only -- which key and 16-byte piece, its byte offset from the chunk's first row in global memory, its address in the LDS image -- is computed
+  // once: stamped by ablation, the per-chunk address arithmetic of the 8 loads (a division by the pieces per row, att_row, 64-bit multiplies) cost 22 % of the
+  // kernel on the FLUX shape and the stores' another part of their 16 %, all of it VALU time taken from the softmax.
   Pack8 stg[MAXL];
+  // d_h 128: 16 pieces per row, so piece i of a thread is row (tid >> 4) + 32 (i & 3), column piece tid & 15, K for i < 4 and V for i >= 4 -- affine in i,
+  // nothing to keep.  d_h 72 (9 pieces per row, no such pattern) keeps the per-chunk arithmetic: per-thread offset arrays measured SLOWER there (Sigma-1024
+  // shape 979 -> 1126 us per launch).
+  constexpr bool AFFINE = NCH == 16 && MAXL == 8;
+  const unsigned a_g0k = (unsigned)(((size_t)(tid >> 4) * p.ldk + (tid & 15) * 8) * sizeof(T)), a_g0v = (unsigned)(((size_t)(tid >> 4) * p.ldv + (tid & 15) * 8) * sizeof(T));
+  const unsigned a_l0k = (unsigned)(((tid >> 4) * KS + (tid & 15) * 8) * sizeof(T)), a_l0v = (unsigned)((KC * KS + (tid >> 4) * VS + (tid & 15) * 8) * sizeof(T));
+  auto isv = [&](int i) -> bool { return i >= 4; };
+  auto keyi = [&](int i) -> int { return (tid >> 4) + 32 * (i & 3); };
+  auto goff = [&](int i) -> unsigned {
+    return i >= 4 ? a_g0v + (unsigned)(i & 3) * (unsigned)(32 * p.ldv * (int)sizeof(T)) : a_g0k + (unsigned)(i & 3) * (unsigned)(32 * p.ldk * (int)sizeof(T));
+  };
+  auto loff = [&](int i) -> unsigned {
+    return i >= 4 ? a_l0v + (unsigned)(i & 3) * (unsigned)(32 * VS * (int)sizeof(T)) : a_l0k + (unsigned)(i & 3) * (unsigned)(32 * KS * (int)sizeof(T));
+  };
   auto load_stage = [&](int item, int kc) {
     const int bh = item / nqb;
     const int h = bh % p.H, b = bh / p.H;
+    if constexpr (AFFINE) {
+      const int k0 = kc * KC;
+      // rows of a chunk are consecutive in memory, except that a chunk which straddles the [text | image] boundary of the FLUX layout (seg_t; never for
+      // the shapes of the models) continues `jump` rows further on: one wave-uniform correction
+      const size_t row0 = att_row(b, k0, p.Nk, p.seg_t, p.seg_bt);
+      const bool straddle = p.seg_t != 0 && k0 < p.seg_t && k0 + KC > p.seg_t;
+      const long jump = straddle ? (long)att_row(b, p.seg_t, p.Nk, p.seg_t, p.seg_bt) - (long)(row0 + (size_t)(p.seg_t - k0)) : 0;
+      const char* kb = reinterpret_cast<const char*>(K + row0 * p.ldk + (size_t)h * DH);  // wave-uniform
+      const char* vb = reinterpret_cast<const char*>(V + row0 * p.ldv + (size_t)h * DH);
+      const int left = p.Nk - k0, first_after = p.seg_t - k0;
 #pragma unroll
-    for (int i = 0; i < MAXL; ++i) {
-      int id = tid + i * 512;
-      stg[i].u = (u32x4){0, 0, 0, 0};
-      if (id < 2 * KC * NCH) {
-        const bool isv = id >= KC * NCH;
-        id = isv ? id - KC * NCH : id;
-        const int key = id / NCH, c = id - key * NCH;
-        const int gk = kc * KC + key;
-        if (!TAIL || gk < p.Nk) {
-          const size_t grow = att_row(b, gk, p.Nk, p.seg_t, p.seg_bt);
-          const T* base = isv ? V + grow * p.ldv : K + grow * p.ldk;
-          stg[i] = gload16(base + (size_t)h * DH + c * 8);
+      for (int i = 0; i < MAXL; ++i) {
+        const bool ok = !TAIL || keyi(i) < left;
+        // branch-free: rows past the end read the chunk's first bytes and drop them (a load under a lane-dependent branch makes hipcc wait vmcnt(0))
+        const char* src = (isv(i) ? vb : kb) + (ok ? goff(i) : 0u);
+        if (straddle && ok && keyi(i) >= first_after) src += jump * (long)((isv(i) ? p.ldv : p.ldk) * (int)sizeof(T));
+        const Pack8 v = gload16(src);
+        stg[i].u = ok ? v.u : (u32x4){0, 0, 0, 0};
+      }
+    } else if (p.seg_t == 0) {
+      // PixArt layout (rows of a sample consecutive): wave-uniform chunk base + a 32-bit per-lane offset instead of a 64-bit row computation per load
+      const size_t row0 = (size_t)b * p.Nk + (size_t)kc * KC;
+      const T* kb = K + row0 * p.ldk + (size_t)h * DH;
+      const T* vb = V + row0 * p.ldv + (size_t)h * DH;
+      const int left = p.Nk - kc * KC;
+#pragma unroll
+      for (int i = 0; i < MAXL; ++i) {
+        int id = tid + i * 512;
+        stg[i].u = (u32x4){0, 0, 0, 0};
+        if (id < 2 * KC * NCH) {
+          const bool v = id >= KC * NCH;
+          id = v ? id - KC * NCH : id;
+          const int key = id / NCH, c = id - key * NCH;
+          if (!TAIL || key < left) stg[i] = gload16((v ? vb : kb) + (unsigned)(key * (v ? p.ldv : p.ldk) + c * 8));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXL; ++i) {
+        int id = tid + i * 512;
+        stg[i].u = (u32x4){0, 0, 0, 0};
+        if (id < 2 * KC * NCH) {
+          const bool v = id >= KC * NCH;
+          id = v ? id - KC * NCH : id;
+          const int key = id / NCH, c = id - key * NCH;
+          const int gk = kc * KC + key;
+          if (!TAIL || gk < p.Nk) {
+            const size_t grow = att_row(b, gk, p.Nk, p.seg_t, p.seg_bt);
+            const T* base = v ? V + grow * p.ldv : K + grow * p.ldk;
+            stg[i] = gload16(base + (size_t)h * DH + c * 8);
+          }
         }
       }
     }
   };
   auto store_stage = [&](int item, int kc) {
+    if constexpr (AFFINE) {
 #pragma unroll
-    for (int i = 0; i < MAXL; ++i) {
-      int id = tid + i * 512;
-      if (id < 2 * KC * NCH) {
-        const bool isv = id >= KC * NCH;
-        id = isv ? id - KC * NCH : id;
-        const int key = id / NCH, c = id - key * NCH;
-        T* dst = isv ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
-        *reinterpret_cast<u32x4*>(dst) = stg[i].u;
+      for (int i = 0; i < MAXL; ++i) *reinterpret_cast<u32x4*>(att_smem + loff(i)) = stg[i].u;
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXL; ++i) {
+        int id = tid + i * 512;
+        if (id < 2 * KC * NCH) {
+          const bool v = id >= KC * NCH;
+          id = v ? id - KC * NCH : id;
+          const int key = id / NCH, c = id - key * NCH;
+          T* dst = v ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
+          *reinterpret_cast<u32x4*>(dst) = stg[i].u;
+        }
       }
     }
     if (TAIL) {

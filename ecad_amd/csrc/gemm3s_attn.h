@@ -44,6 +44,8 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
   Pack8 stg[MAXL];
   auto load_stage = [&](int hd, int kc) {
     const int h = 2 * tn + hd;
+    const T* kbase = Kg + (size_t)kc * KC * p.att_ldk + (size_t)h * DH;
+    const T* vbase = Vg + (size_t)kc * KC * p.att_ldk + (size_t)h * DH;
 #pragma unroll
     for (int i = 0; i < MAXL; ++i) {
       int id = tid + i * 512;
@@ -55,8 +57,8 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
       id = isv ? id - KC * NCH : id;
       const int key = id / NCH, c = id - key * NCH;
       const bool ok = has && kc * KC + key < p.att_nk;
-      const int gk = ok ? kc * KC + key : kc * KC;
-      stg[i] = gload16((isv ? Vg : Kg) + (size_t)gk * p.att_ldk + (size_t)h * DH + (ok ? c * 8 : 0));
+      // wave-uniform chunk base + a 32-bit per-lane offset (the 64-bit row arithmetic per load was VALU time taken from the softmax: attention128.h)
+      stg[i] = gload16((isv ? vbase : kbase) + (ok ? (unsigned)(key * p.att_ldk + c * 8) : 0u));
     }
   };
   auto store_stage = [&](int kc) {

@@ -74,6 +74,17 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
   constexpr bool AFFINE = NCH == 16 && MAXL == 8;
   const unsigned a_g0k = (unsigned)(((size_t)(tid >> 4) * p.ldk + (tid & 15) * 8) * sizeof(T)), a_g0v = (unsigned)(((size_t)(tid >> 4) * p.ldv + (tid & 15) * 8) * sizeof(T));
   const unsigned a_l0k = (unsigned)(((tid >> 4) * KS + (tid & 15) * 8) * sizeof(T)), a_l0v = (unsigned)((KC * KS + (tid >> 4) * VS + (tid & 15) * 8) * sizeof(T));
+  unsigned l_arr[AFFINE ? 1 : MAXL];  // d_h 72: the LDS address of each piece, computed once (the global side keeps its per-chunk arithmetic, see above)
+  if constexpr (!AFFINE) {
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      int id = tid + i * 512;
+      const bool v = id >= KC * NCH;
+      id = v ? id - KC * NCH : id;
+      const int key = id / NCH, c = id - key * NCH;
+      l_arr[i] = (unsigned)((v ? KC * KS + key * VS + c * 8 : key * KS + c * 8) * sizeof(T));
+    }
+  }
   auto isv = [&](int i) -> bool { return i >= 4; };
   auto keyi = [&](int i) -> int { return (tid >> 4) + 32 * (i & 3); };
   auto goff = [&](int i) -> unsigned {
@@ -146,16 +157,8 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
       for (int i = 0; i < MAXL; ++i) *reinterpret_cast<u32x4*>(att_smem + loff(i)) = stg[i].u;
     } else {
 #pragma unroll
-      for (int i = 0; i < MAXL; ++i) {
-        int id = tid + i * 512;
-        if (id < 2 * KC * NCH) {
-          const bool v = id >= KC * NCH;
-          id = v ? id - KC * NCH : id;
-          const int key = id / NCH, c = id - key * NCH;
-          T* dst = v ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
-          *reinterpret_cast<u32x4*>(dst) = stg[i].u;
-        }
-      }
+      for (int i = 0; i < MAXL; ++i)
+        if (tid + i * 512 < 2 * KC * NCH) *reinterpret_cast<u32x4*>(att_smem + l_arr[i]) = stg[i].u;
     }
     if (TAIL) {
       const int b = (item / nqb) / p.H;

@@ -61,18 +61,23 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
       stg[i] = gload16((isv ? vbase : kbase) + (ok ? (unsigned)(key * p.att_ldk + c * 8) : 0u));
     }
   };
-  auto store_stage = [&](int kc) {
+  // LDS address and key of each of this thread's pieces: computed once, not per chunk (attention128.h: -2.3 % on the 32-chunk Sigma-1024 shape)
+  unsigned l_arr[MAXL];
+  int k_arr[MAXL];
 #pragma unroll
-    for (int i = 0; i < MAXL; ++i) {
-      int id = tid + i * 512;
-      if (id < 2 * KC * NCH) {
-        const bool isv = id >= KC * NCH;
-        id = isv ? id - KC * NCH : id;
-        const int key = id / NCH, c = id - key * NCH;
-        T* dst = isv ? Vs + key * VS + c * 8 : Ks + key * KS + c * 8;
-        *reinterpret_cast<u32x4*>(dst) = kc * KC + key < p.att_nk ? stg[i].u : (u32x4){0, 0, 0, 0};
-      }
-    }
+  for (int i = 0; i < MAXL; ++i) {
+    int id = tid + i * 512;
+    const bool isv = id >= KC * NCH;
+    id = isv ? id - KC * NCH : id;
+    const int key = id / NCH, c = id - key * NCH;
+    k_arr[i] = key;
+    l_arr[i] = (unsigned)(G3A_KV_OFF + (isv ? KC * KS + key * VS + c * 8 : key * KS + c * 8) * (int)sizeof(T));
+  }
+  auto store_stage = [&](int kc) {
+    const int left = p.att_nk - kc * KC;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i)
+      if (tid + i * 512 < 2 * KC * NCH) *reinterpret_cast<u32x4*>(smem + l_arr[i]) = k_arr[i] < left ? stg[i].u : (u32x4){0, 0, 0, 0};
     if (TAIL) {
       for (int i = tid; i < KC; i += 512) {
         const int gk = kc * KC + i;

@@ -34,6 +34,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 SCHEDULE = ROOT / "schedules/schedules_in_paper/pixart_alpha_256/ours_fast.json"
+SIGMA1024_SCHEDULE = ROOT / "schedules/sigma_cache_schedules/transfer_256_to_1024/ours_fast_256_to_1024.json"
 BATCH = 16
 NUM_STEPS = 20
 GUIDANCE = 4.5
@@ -197,15 +198,21 @@ def main_stub(args, world, rank):
     sleeping stand-in for the hot path.  The line says it is a stub in `metric`, `data` and `config.workload`; nothing here is a measurement."""
     import torch.distributed as dist
 
-    if world > 1:
+    grouped = world > 1 or os.environ.get("ECAD_FORCE_DIST", "0") == "1"  # same switch as the GPU run: a group of one rank still runs the collectives
+    if grouped:
+        if world == 1:
+            from ecad_amd.distributed import single_rank_rendezvous_env
+
+            single_rank_rendezvous_env()
         dist.init_process_group("gloo")
     per_step = 0.02 * (1 + rank)  # rank r is (r + 1) x slower: the reported time must be the slowest rank's
-    elapsed = timed_steps(lambda: time.sleep(per_step), args.steps, lambda: None, dist if world > 1 else None, torch.device("cpu"))
+    elapsed = timed_steps(lambda: time.sleep(per_step), args.steps, lambda: None, dist if grouped else None, torch.device("cpu"))
     if rank == 0:
         res = {"metric": "STUB rank bookkeeping (no GPU work)", **whole_job(world, args.batch or BATCH, args.steps, elapsed), "warmup": args.warmup, "dtype": "none", "data": "stub",
-               "config": {"workload": "stub: sleep(0.02 s x (rank + 1)) per step", "batch_per_gpu": args.batch or BATCH}}
+               "config": {"workload": "stub: sleep(0.02 s x (rank + 1)) per step", "batch_per_gpu": args.batch or BATCH,
+                          "process_group": f"gloo, world {world}" if grouped else None}}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -272,14 +279,30 @@ def main_flux(args, world, rank, device, dist):
             d = mf[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             gem = [v for k, v in mf.items() if k.startswith("gemm")]
+            # HBM bytes per launch by PMC: only from a committed profile stamped with this workload, dtype and kernel sources (scripts/pmc_traffic.py; the
+            # joint attention out-projection and FF2 share a kernel symbol and grid, so their traffic is one merged class)
+            pmc, pmc_file, stamp = stamped_traffic(f"flux1024_b{B}", "fp8" if args.fp8 else "bf16")
+
+            def traffic_of(cls):
+                e = pmc.get(cls) or (pmc.get("gemm_joint_attn_out+ff2") if cls in ("gemm_joint_attn_out", "gemm_joint_ff2") else None)
+                return e.get("hbm_bytes_per_launch") if e else None
+
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS,
-                               "traffic": None, "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "flops_per_launch": d["flops"] / d["launches"],
+                               "traffic": traffic_of(dom), "traffic_source": pmc_file, "kernel_sources_stamp": stamp,
+                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "flops_per_launch": d["flops"] / d["launches"],
                                "avg_launch_ms": d["ms"] / d["launches"], "launches_measured": d["launches"],
                                "all_gemm_tflops": sum(v["flops"] for v in gem) / (sum(v["ms"] for v in gem) * 1e-3) / 1e12}
+            at = mf.get("attn_joint")
+            if at:
+                tf = at["flops"] / (at["ms"] * 1e-3) / 1e12
+                res["attention"] = {"kernel": "attn_joint", "achieved": tf, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TFLOPS, "avg_launch_ms": at["ms"] / at["launches"],
+                                    "launches_measured": at["launches"], "ms_per_batch": at["ms"], "flops_per_launch": at["flops"] / at["launches"],
+                                    "algorithmic_bytes_per_launch": at["bytes"] / at["launches"], "traffic": traffic_of("attn_joint"), "traffic_source": pmc_file}
+            res["tflops_by_class"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["launches"] and v["flops"] > 0 and v["ms"] > 0}
             res["time_breakdown_ms_per_batch"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
             res["time_breakdown_ms_per_batch"]["_sum"] = round(sum(v["ms"] for v in prof.values()), 3)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -289,18 +312,22 @@ SECONDARY = {
     "alpha256_batch1_latency": ["--batch", "1", "--steps", "20", "--warmup", "3"],
     "alpha256_batch100_paper_latency_config": ["--batch", "100", "--steps", "3", "--warmup", "1"],
     "alpha256_fp8_block_gemms": ["--fp8", "--steps", "5", "--warmup", "1"],
-    "sigma1024_batch4": ["--workload", "sigma1024", "--steps", "3", "--warmup", "1"],
-    "flux1024_batch2_bf16": ["--workload", "flux1024", "--steps", "2", "--warmup", "1"],
+    "sigma1024_batch4": ["--workload", "sigma1024", "--steps", "3", "--warmup", "1", "--roofline"],
+    "flux1024_batch2_bf16": ["--workload", "flux1024", "--steps", "2", "--warmup", "1", "--roofline"],
+    "flux1024_batch2_fp8": ["--workload", "flux1024", "--fp8", "--steps", "2", "--warmup", "1", "--roofline"],  # BASELINE config 5 names fp8 MFMA
 }
 
 
 def run_secondary(names: list[str]) -> dict:
     out = {}
     for name in names:
-        cmd = [sys.executable, str(Path(__file__).resolve())] + SECONDARY[name] + ["--no-cpu-baseline", "--no-roofline", "--no-decode-tail", "--no-secondary"]
+        roof = "--roofline" in SECONDARY[name]  # configs 3 and 5 carry their own compact roofline (dominant MFMA class by HIP events in the child)
+        cmd = [sys.executable, str(Path(__file__).resolve())] + [a for a in SECONDARY[name] if a != "--roofline"] + ["--no-cpu-baseline", "--no-decode-tail", "--no-secondary"]
+        if not roof:
+            cmd.append("--no-roofline")
         t0 = time.time()
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ECAD_FORCE_DIST")})
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not lines:
                 out[name] = {"error": (p.stderr or p.stdout)[-400:]}
@@ -308,6 +335,13 @@ def run_secondary(names: list[str]) -> dict:
             d = json.loads(lines[-1])
             out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"], "workload": d["config"]["workload"],
                          "ms_per_image": d["config"].get("ms_per_image"), "whole_job_mfma_fraction": d["config"].get("whole_job_mfma_fraction"), "wall_s": round(time.time() - t0, 1)}
+            if "roofline" in d:
+                r = d["roofline"]
+                out[name]["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_measured", "flops_per_launch",
+                                                               "algorithmic_bytes_per_launch", "traffic", "traffic_source", "all_gemm_tflops")}
+                if "attention" in d:
+                    out[name]["attention"] = d["attention"]
+                out[name]["time_breakdown_ms_per_batch"] = d.get("time_breakdown_ms_per_batch")
         except Exception as e:  # a secondary number must never take the headline line down
             out[name] = {"error": repr(e)[-400:]}
         log(f"secondary {name}: {out[name].get('value', out[name].get('error'))}")
@@ -353,11 +387,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    forced = world == 1 and os.environ.get("ECAD_FORCE_DIST", "0") == "1"  # RCCL readiness on a 1-GPU box: the group, barrier and MAX all-reduce at world 1
+    if world > 1 or forced:
         import torch.distributed as dist
 
+        if forced:
+            from ecad_amd.distributed import single_rank_rendezvous_env
+
+            single_rank_rendezvous_env()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        log(f"process group: nccl (RCCL), world {dist.get_world_size()}" + (" [ECAD_FORCE_DIST]" if forced else ""))
 
     if args.workload == "flux1024":
         return main_flux(args, world, rank, device, dist)
@@ -369,9 +409,11 @@ def main():
     log('imports done')
     batch, schedule = args.batch or BATCH, SCHEDULE
     side, text_tokens, sample_size, interp = 32, 120, 32, None
-    if args.workload == "sigma1024":  # PixArt-Sigma 1024x1024, batch 4, T = 300; schedule transferred from sigma_256/ours_fast
-        batch, side, text_tokens, sample_size, interp = args.batch or 4, 128, 300, 128, 2
-        schedule = ROOT / "schedules/schedules_in_paper/pixart_sigma_256/ours_fast.json"
+    if args.workload == "sigma1024":  # BASELINE config 3: PixArt-Sigma 1024x1024, batch 4, T = 300; the authored 256 -> 1024 transfer of the paper's Sigma ours_fast
+        schedule = SIGMA1024_SCHEDULE
+        scfg = json.loads(schedule.read_text())["config"]  # the geometry comes from the file's config block, as the image generator reads it
+        assert scfg["transformer_weights"] == "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" and scfg["height"] == scfg["width"] == 1024
+        batch, side, text_tokens, sample_size, interp = args.batch or 4, scfg["height"] // 8, 300, 128, 2
     headline = args.workload == "alpha256" and batch == BATCH and not args.fp8
     sched = PixArtCacheSchedule.from_json(schedule)
     bits = sched.to_numpy()
@@ -413,7 +455,8 @@ def main():
             workload = f"PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch={batch} (CFG batch {2 * batch}), 1xMI355X per rank"
         else:
             metric = "images/sec at fixed schedule (PixArt-Sigma 1024, 20-step, sigma ours_fast transfer) [secondary]"
-            workload = f"PixArt-Sigma 1024x1024 geometry (N=4096, T=300), 20 steps, pixart_sigma_256/ours_fast.json transferred, batch={batch} (CFG batch {2 * batch}), 1xMI355X per rank"
+            workload = (f"PixArt-Sigma 1024x1024 geometry (N=4096, T=300), 20 steps, {SIGMA1024_SCHEDULE.relative_to(ROOT)} (256 -> 1024 transfer of "
+                        f"pixart_sigma_256/ours_fast.json), batch={batch} (CFG batch {2 * batch}), 1xMI355X per rank")
         res = {
             "metric": metric,
             **job,
@@ -432,6 +475,7 @@ def main():
                 "reference_equivalent_tflop_per_image": flop_per_image / 1e12,
                 "whole_job_mfma_fraction": value / world * flop_per_image / 1e12 / PEAK_MFMA_TFLOPS,
                 "published_reference_a6000_images_per_s": 11.89,
+                "process_group": (f"nccl (RCCL), world {world}" + (" [ECAD_FORCE_DIST]" if forced else "")) if dist is not None else None,
             },
         }
         if not args.no_roofline:
@@ -495,10 +539,9 @@ def main():
             # decoder.  Extra keys, never in `value`.
             from PIL import Image
 
-            from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
+            from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
 
-            torch.manual_seed(0)
-            vae = HipVaeDecoder.from_torch(AutoencoderKLDecoderOnly(), device=local_rank)  # random-init SD-VAE decoder on the native engine
+            vae = HipVaeDecoder.random_init(0, device=local_rank)  # random-init SD-VAE decoder geometry on the native engine
 
             def png_ready():
                 arr = vae.decode_to_uint8(one_batch(use_graph)).cpu().numpy()
@@ -528,7 +571,7 @@ def main():
             torch.cuda.empty_cache()
             res["secondary"] = run_secondary(names)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

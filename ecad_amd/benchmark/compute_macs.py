@@ -63,6 +63,9 @@ WEIGHTS_TO_GEOMETRY = {
     "PixArt-alpha/PixArt-XL-2-256x256": dict(tokens=256, size_embedder_macs=0),
     "PixArt-alpha/PixArt-Sigma-XL-2-256x256": dict(tokens=256, size_embedder_macs=0),
     "PixArt-alpha/PixArt-XL-2-1024-MS": dict(tokens=4096, size_embedder_macs=3 * (256 * 384 + 384 * 384)),
+    # not in the reference's table (it never annotated a Sigma-1024 file): same convention -- latent side x4, text length SEQ_LEN = 120, and the
+    # Sigma 1024-MS checkpoint has no micro-conditioning embedders (use_additional_conditions False)
+    "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS": dict(tokens=4096, size_embedder_macs=0),
 }
 DEFAULT_WEIGHTS = {"PixArtAlphaImageGenerator": "PixArt-alpha/PixArt-XL-2-256x256", "PixArtSigmaImageGenerator": "PixArt-alpha/PixArt-Sigma-XL-2-256x256"}
 

@@ -231,19 +231,19 @@ template <typename T> class EngineT : public EngineBase {
   bool batch_begun = false;
 
   ~EngineT() override {
-    hipSetDevice(dev);
-    if (graph_exec) hipGraphExecDestroy(graph_exec);
-    if (graph) hipGraphDestroy(graph);
+    (void)hipSetDevice(dev);  // teardown: nothing to report an error to
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
     for (auto& e : plan_lru) free_stash(e);
-    if (desc_dyn_dev) hipFree(desc_dyn_dev);
-    if (cap_stream) hipStreamDestroy(cap_stream);
-    for (auto e : ev_pool) hipEventDestroy(e);
-    if (warena) hipFree(warena);
-    if (ws) hipFree(ws);
-    for (void* q : w8allocs) hipFree(q);
-    if (a8) hipFree(a8);
-    if (sa8) hipFree(sa8);
-    if (desc_dev) hipFree(desc_dev);
+    if (desc_dyn_dev) (void)hipFree(desc_dyn_dev);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (warena) (void)hipFree(warena);
+    if (ws) (void)hipFree(ws);
+    for (void* q : w8allocs) (void)hipFree(q);
+    if (a8) (void)hipFree(a8);
+    if (sa8) (void)hipFree(sa8);
+    if (desc_dev) (void)hipFree(desc_dev);
   }
 
   // -------------------------------------------------------------------------------------------
@@ -445,7 +445,7 @@ template <typename T> class EngineT : public EngineBase {
     void* stage = nullptr;
     HIPCHK(hipMalloc(&stage, numel * esz));
     hipError_t e = hipMemcpy(stage, ptr, numel * esz, hipMemcpyDefault);
-    if (e != hipSuccess) { hipFree(stage); return fail(ECAD_E_HIP, "hipMemcpy of weight '%s' failed: %s", name, hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(stage); return fail(ECAD_E_HIP, "hipMemcpy of weight '%s' failed: %s", name, hipGetErrorString(e)); }
     const int grid = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
 #define CONV(SRC, DST) hipLaunchKernelGGL((convert_kernel<SRC, DST>), dim3(grid), dim3(256), 0, 0, (const SRC*)stage, (DST*)d.ptr, (size_t)numel)
     if (d.f32) {
@@ -455,7 +455,7 @@ template <typename T> class EngineT : public EngineBase {
     }
 #undef CONV
     e = hipDeviceSynchronize();
-    hipFree(stage);
+    (void)hipFree(stage);
     if (e != hipSuccess) return fail(ECAD_E_HIP, "weight conversion failed: %s", hipGetErrorString(e));
     d.loaded = true;
     finalized = false;
@@ -502,7 +502,7 @@ template <typename T> class EngineT : public EngineBase {
   }
   int build_fp8_weights() {
     if (D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
-    for (void* q : w8allocs) hipFree(q);
+    for (void* q : w8allocs) (void)hipFree(q);
     w8allocs.clear(); w8map.clear();
     const size_t d = D;
     int rc;
@@ -580,9 +580,9 @@ template <typename T> class EngineT : public EngineBase {
   // -------------------------------------------------------------------------------------------
   // plan-set cache
   static void free_stash(PlanStash& e) {
-    if (e.ge) hipGraphExecDestroy(e.ge);
-    if (e.g) hipGraphDestroy(e.g);
-    if (e.dd) hipFree(e.dd);
+    if (e.ge) (void)hipGraphExecDestroy(e.ge);
+    if (e.g) (void)hipGraphDestroy(e.g);
+    if (e.dd) (void)hipFree(e.dd);
     e.ge = nullptr; e.g = nullptr; e.dd = nullptr;
   }
   std::string make_key() const {
@@ -605,16 +605,16 @@ template <typename T> class EngineT : public EngineBase {
     plan_begin.clear(); plan_run.clear(); plan_step.clear(); desc_host.clear(); cur_key.clear();
     plan_lru.push_front(std::move(e));
     if (plan_lru.size() > plan_lru_cap) {
-      hipDeviceSynchronize();
+      (void)hipDeviceSynchronize();  // an evicted graph may still be in flight; a device error here resurfaces at the next checked call
       while (plan_lru.size() > plan_lru_cap) { free_stash(plan_lru.back()); plan_lru.pop_back(); }
     }
   }
   bool restore_plans(const std::string& key) {
     for (auto it = plan_lru.begin(); it != plan_lru.end(); ++it) {
       if (it->key != key) continue;
-      if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-      if (graph) { hipGraphDestroy(graph); graph = nullptr; }
-      if (desc_dev) { hipFree(desc_dev); desc_dev = nullptr; }
+      if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+      if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+      if (desc_dev) { (void)hipFree(desc_dev); desc_dev = nullptr; }
       PlanStash& e = *it;
       plan_begin = std::move(e.begin); plan_run = std::move(e.run); plan_step = std::move(e.step); desc_host = std::move(e.dh);
       desc_dev = e.dd; desc_cap = e.dcap; graph = e.g; graph_exec = e.ge; graph_guidance = e.gg; comb_live = e.comb;
@@ -628,7 +628,7 @@ template <typename T> class EngineT : public EngineBase {
   }
   void drop_all_plans() {
     plan_valid = false;
-    if (!plan_lru.empty()) hipDeviceSynchronize();
+    if (!plan_lru.empty()) (void)hipDeviceSynchronize();
     for (auto& e : plan_lru) free_stash(e);
     plan_lru.clear();
   }
@@ -921,7 +921,7 @@ template <typename T> class EngineT : public EngineBase {
     st = run_stats;
     // --- upload descriptors and patch pointers
     if (desc_host.size() > desc_cap) {
-      if (desc_dev) hipFree(desc_dev);
+      if (desc_dev) (void)hipFree(desc_dev);
       desc_cap = desc_host.size() + 1024;
       HIPCHK(hipMalloc((void**)&desc_dev, desc_cap * sizeof(SrcDesc)));
     }
@@ -929,8 +929,8 @@ template <typename T> class EngineT : public EngineBase {
     auto patch = [&](std::vector<Op<T>>& ops) { for (auto& o : ops) if (o.desc_off >= 0) o.f.srcs = desc_dev + o.desc_off; };
     patch(plan_run);
     for (auto& v : plan_step) patch(v);
-    if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-    if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
     st.graph_nodes = 0;
     plan_valid = true;
     ++plan_builds;
@@ -1338,8 +1338,8 @@ template <typename T> class EngineT : public EngineBase {
     HIPCHK(hipMemcpyAsync(lat_buf, latents, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (use_graph && !profiling) {
       if (!graph_exec || graph_guidance != guidance) {
-        if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-        if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+        if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
         HIPCHK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
         rc = run_ops(plan_run, cap_stream, guidance, false);
         hipError_t e = hipStreamEndCapture(cap_stream, &graph);
@@ -1348,7 +1348,7 @@ template <typename T> class EngineT : public EngineBase {
         HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
         ++graph_captures;
         size_t nn = 0;
-        hipGraphGetNodes(graph, nullptr, &nn);
+        HIPCHK(hipGraphGetNodes(graph, nullptr, &nn));
         st.graph_nodes = (int)nn;
         graph_guidance = guidance;
       }
@@ -1467,6 +1467,9 @@ template <typename T> class EngineT : public EngineBase {
     if (site != KC_GEMM_QKV && !tail) return fail(ECAD_E_INVALID, "call_site %d: the fused launch exists for the self- (0) and cross-attention (2) query projections", site);
     if (DH != G3A_DH || D % G3_BN || n_tokens % G3_BM || Bt_ < 1 || n_keys < 1 || (!tail && (n_keys != n_tokens || n_keys % G3A_KC)))
       return fail(ECAD_E_UNSUPPORTED, "fused query projection + attention needs d_h 72, n_tokens %% 256 == 0 (self: keys == tokens); got d_h %d, %d tokens, %d keys", DH, n_tokens, n_keys);
+    // the K / V staging reads 16-byte chunks (gload16): base pointers on 16 bytes, row stride a multiple of 8 elements
+    if (!x || !wq || !k || !v || !out || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)out & 15) || ld_kv < D || ld_kv % 8)
+      return fail(ECAD_E_INVALID, "fused query projection + attention: x / wq / k / v / out must be 16-byte aligned and ld_kv (%lld) a multiple of 8 >= %d", (long long)ld_kv, D);
     GemmArgs<T> g{};
     g.A = (const T*)x; g.W = (const T*)wq; g.bias = bq; g.C = nullptr; g.M = Bt_ * n_tokens; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.ldr = D;
     g.rows_per_batch = n_tokens; g.variant = gemm_variant;
@@ -1545,12 +1548,15 @@ template <typename T> class EngineT : public EngineBase {
     for (int i = 0; i < n_src; ++i) d[i] = SrcDesc{srcs[i], gts ? gts[i] : nullptr, gms ? gms[i] : nullptr};
     SrcDesc* dd = nullptr;
     HIPCHK(hipMalloc((void**)&dd, sizeof(SrcDesc) * (n_src + 1)));
-    hipMemcpy(dd, d.data(), sizeof(SrcDesc) * n_src, hipMemcpyHostToDevice);
+    {
+      const hipError_t ce = hipMemcpy(dd, d.data(), sizeof(SrcDesc) * n_src, hipMemcpyHostToDevice);
+      if (ce != hipSuccess) { (void)hipFree(dd); return fail(ECAD_E_HIP, "hipMemcpy of the replay descriptors failed: %s", hipGetErrorString(ce)); }
+    }
     FlushArgs f{};
     f.h = hh; f.srcs = dd; f.n_src = n_src; f.M = M; f.D = Dd; f.mod_stride = mstride; f.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     launch_replay(f, s);
     hipError_t e = hipStreamSynchronize(s);
-    hipFree(dd);
+    (void)hipFree(dd);
     if (e != hipSuccess) return fail(ECAD_E_HIP, "cache_accumulate failed: %s", hipGetErrorString(e));
     return ECAD_OK;
   }

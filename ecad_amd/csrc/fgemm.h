@@ -78,7 +78,7 @@ ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
   constexpr int A_INST = BM / 8 / NW;  // 4
   constexpr int B_INST = BN / 8 / NW;  // 4 (BN 256) or 2 (BN 128)
-  constexpr int CS = BN + 8;
+  [[maybe_unused]] constexpr int CS = BN + 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;
@@ -250,11 +250,8 @@ ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
 // bias / activation / rounding through the LDS C tile, then the row pass (plain store, gated residual, RoPE ...); shared with fgemm8.h
 template <typename T, int BN, int EPI>
 ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, f32x4 (&acc)[4][BN / 32]) {
-  constexpr int BM = 256, NW = 8, STAGES = fgemm_stages<BN>();
+  [[maybe_unused]] constexpr int BM = 256, NW = 8, STAGES = fgemm_stages<BN>();
   constexpr int FM = 4, FN = BN / 32;  // wave tile 64 x BN/2
-  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
-  constexpr int A_INST = BM / 8 / NW;  // 4
-  constexpr int B_INST = BN / 8 / NW;  // 4 (BN 256) or 2 (BN 128)
   constexpr int CS = BN + 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

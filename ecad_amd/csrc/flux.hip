@@ -206,24 +206,24 @@ template <typename T> class FluxT : public FluxBase {
   void* call_out = nullptr;
 
   ~FluxT() override {
-    hipSetDevice(dev);
-    if (graph_exec) hipGraphExecDestroy(graph_exec);
-    if (graph) hipGraphDestroy(graph);
-    if (cap_stream) hipStreamDestroy(cap_stream);
-    if (side_stream) hipStreamDestroy(side_stream);
-    if (ev_fork) hipEventDestroy(ev_fork);
-    if (ev_join) hipEventDestroy(ev_join);
-    if (a8_side) hipFree(a8_side);
-    if (sa8_side) hipFree(sa8_side);
-    for (auto e : ev_pool) hipEventDestroy(e);
-    if (warena) hipFree(warena);
-    if (ws) hipFree(ws);
-    if (desc_dev) hipFree(desc_dev);
-    for (void* q : w8allocs) hipFree(q);
-    if (a8) hipFree(a8);
-    if (sa8) hipFree(sa8);
-    if (xn8) hipFree(xn8);
-    if (sxn8) hipFree(sxn8);
+    (void)hipSetDevice(dev);  // teardown: nothing to report an error to
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (a8_side) (void)hipFree(a8_side);
+    if (sa8_side) (void)hipFree(sa8_side);
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (warena) (void)hipFree(warena);
+    if (ws) (void)hipFree(ws);
+    if (desc_dev) (void)hipFree(desc_dev);
+    for (void* q : w8allocs) (void)hipFree(q);
+    if (a8) (void)hipFree(a8);
+    if (sa8) (void)hipFree(sa8);
+    if (xn8) (void)hipFree(xn8);
+    if (sxn8) (void)hipFree(sxn8);
   }
 
   template <typename U> U* walloc(size_t n) {
@@ -411,7 +411,7 @@ template <typename T> class FluxT : public FluxBase {
     void* stage = nullptr;
     FHIPCHK(hipMalloc(&stage, numel * esz));
     hipError_t e = hipMemcpy(stage, ptr, numel * esz, hipMemcpyDefault);
-    if (e != hipSuccess) { hipFree(stage); return fail(ECAD_E_HIP, "hipMemcpy of weight '%s' failed: %s", name, hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(stage); return fail(ECAD_E_HIP, "hipMemcpy of weight '%s' failed: %s", name, hipGetErrorString(e)); }
     const int grid = (int)((numel + 255) / 256 < 8192 ? (numel + 255) / 256 : 8192);
 #define CONV(SRC, DST) hipLaunchKernelGGL((convert_kernel<SRC, DST>), dim3(grid), dim3(256), 0, 0, (const SRC*)stage, (DST*)d.ptr, (size_t)numel)
     if (d.f32) {
@@ -421,7 +421,7 @@ template <typename T> class FluxT : public FluxBase {
     }
 #undef CONV
     e = hipDeviceSynchronize();
-    hipFree(stage);
+    (void)hipFree(stage);
     if (e != hipSuccess) return fail(ECAD_E_HIP, "weight conversion failed: %s", hipGetErrorString(e));
     d.loaded = true;
     finalized = false;
@@ -451,7 +451,7 @@ template <typename T> class FluxT : public FluxBase {
     return ECAD_OK;
   }
   int build_fp8_weights() {
-    for (void* q : w8allocs) hipFree(q);
+    for (void* q : w8allocs) (void)hipFree(q);
     w8allocs.clear(); w8map.clear();
     const size_t d = D;
     int rc;
@@ -837,7 +837,7 @@ template <typename T> class FluxT : public FluxBase {
     }
     // descriptors -> device, patch pointers
     if (desc_host.size() > desc_cap) {
-      if (desc_dev) hipFree(desc_dev);
+      if (desc_dev) (void)hipFree(desc_dev);
       desc_cap = desc_host.size() + 1024;
       FHIPCHK(hipMalloc((void**)&desc_dev, desc_cap * sizeof(FluxSrc)));
     }
@@ -848,8 +848,8 @@ template <typename T> class FluxT : public FluxBase {
     };
     for (auto& p : plan_step) patch(p);
     patch(plan_run);
-    if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-    if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
     st.graph_nodes = 0;
     st.launches_per_batch = (int)plan_run.size() + (int)plan_begin.size();
 
@@ -1115,7 +1115,7 @@ template <typename T> class FluxT : public FluxBase {
         if (e != hipSuccess) return fail(ECAD_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
         FHIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
         size_t nn = 0;
-        hipGraphGetNodes(graph, nullptr, &nn);
+        FHIPCHK(hipGraphGetNodes(graph, nullptr, &nn));
         st.graph_nodes = (int)nn;
       }
       FHIPCHK(hipGraphLaunch(graph_exec, s));
@@ -1207,17 +1207,18 @@ template <typename T> class FluxT : public FluxBase {
     q.A8 = a8; q.W8 = w8; q.sa = sa; q.sw = sw; q.lda8 = K;
     q.e.bias = bias; q.e.C = (T*)out; q.e.M = M; q.e.N = Nn; q.e.K = K; q.e.ldc = Nn; q.e.k_split = K;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    FHIPCHK(hipEventCreate(&e0));
+    FHIPCHK(hipEventCreate(&e1));
     if (bn == 256) launch8<256>(epi, q, s); else launch8<128>(epi, q, s);
-    hipEventRecord(e0, s);
+    hipError_t err = hipEventRecord(e0, s);
     for (int i = 0; i < iters; ++i) { if (bn == 256) launch8<256>(epi, q, s); else launch8<128>(epi, q, s); }
-    hipEventRecord(e1, s);
-    hipError_t err = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = hipEventRecord(e1, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
     if (avg_us) *avg_us = iters > 0 ? ms * 1e3f / iters : 0.f;
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(a8); hipFree(w8); hipFree(sa); hipFree(sw);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a8); (void)hipFree(w8); (void)hipFree(sa); (void)hipFree(sw);
     if (err != hipSuccess) return fail(ECAD_E_HIP, "fp8 gemm failed: %s", hipGetErrorString(err));
     return ECAD_OK;
   }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   };
   // Staggered schedule (see gemm3s.h; K-steps 1 .. nk-2): one MFMA stream for all waves, the 9 LDS-DMA pieces of the next stage one per group
   // of 4 MFMAs -- waves 0-3 beside the first 36 MFMAs of the step, waves 4-7 (their SIMD partners) beside the last 28
-  auto step_stagger = [&](int kt) {
+  [[maybe_unused]] auto step_stagger = [&](int kt) {
     const int stage = kt & 1, nst = stage ^ 1;
 #ifdef G2_STAGGER_ALL_EARLY
     const bool early = true;  // every wave spreads its pieces over the first 36 MFMAs of the step (no offset between SIMD partners)

@@ -13,6 +13,7 @@ namespace ecad {
 constexpr int G3_BM = 256, G3_BN = 144, G3_STAGES = 3, G3_NW = 8;
 constexpr int G3_STAGE_BYTES = (G3_BM + G3_BN) * 128;
 constexpr int G3_LDS_BYTES = G3_STAGES * G3_STAGE_BYTES;
+static_assert(G3A_LDS_BYTES <= G3_LDS_BYTES, "the fused attention tail (Q tile + K/V staging + bias strip) must fit the operand ring: launch_g3_attn requests G3_LDS_BYTES only");
 
 template <typename T, int EPI, int TAG>
 __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p) {
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
 #endif
   constexpr int NMF = FM * FN, GROUPS = G3_STAG_GROUPS, PER = NMF / GROUPS;  // 18 MFMAs in 6 groups of 3 (9 groups of 2: -DG3_STAG_GROUPS=9)
   static_assert(NMF % GROUPS == 0 && NPIECE <= GROUPS + 1, "piece / MFMA interleave");
-  constexpr int LASTP = NPIECE > GROUPS ? GROUPS - 1 : NPIECE - 1;  // group that carries the last regular piece
+  [[maybe_unused]] constexpr int LASTP = NPIECE > GROUPS ? GROUPS - 1 : NPIECE - 1;  // group that carries the last regular piece
   // both halves run the same MFMA stream (one code path: a wave-group branch around the MFMAs makes hipcc shuffle and spill the accumulators);
   // only the small DMA-issue blocks in between are conditional on the half the wave belongs to
   auto mfma_dma = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM], int ns, bool mine) {

@@ -21,7 +21,8 @@ namespace ecad {
 constexpr int G3A_DH = 72, G3A_KC = 128;
 constexpr int G3A_Q_BYTES = 256 * 152 * 2;                                   // the C tile of gemm3s.h (CS = 152), i.e. the Q tile
 constexpr int G3A_KV_OFF = (G3A_Q_BYTES + 1023) & ~1023;                     // K / V staging behind it
-constexpr int G3A_LDS_BYTES = G3A_KV_OFF + attn_lds_bytes<G3A_KC, G3A_DH>();  // 78848 + 47616: inside the 3 x 51200 ring of gemm3s.h
+constexpr int G3A_LDS_BYTES = G3A_KV_OFF + attn_lds_bytes<G3A_KC, G3A_DH>();  // Q tile 77824 (on a 1 KiB boundary) + K / V staging + bias strip; gemm3s.h
+                                                                              // asserts that this fits the operand ring the launch requests (3 x 51200)
 
 // Called by every thread of the workgroup after the K loop.  `ring_free`: false => the caller has NOT yet synchronised the workgroup after the last
 // K-step (other waves may still read operand stage 2).  acc / bvs: the wave's 32 x 144 accumulators and bias vectors (gemm3s.h layout).

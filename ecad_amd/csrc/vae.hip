@@ -73,15 +73,16 @@ template <typename T> struct VaeT : VaeBase {
   size_t act_elems = 0;
   int cap_B = 0, cap_h = 0, cap_w = 0;
   bool finalized = false;
+  bool async_failed = false;  // an asynchronous call inside a void helper failed: decode() turns it into ECAD_E_HIP
 
   ~VaeT() override {
-    hipSetDevice(dev);
-    for (void* p : allocs) hipFree(p);
+    (void)hipSetDevice(dev);  // teardown: nothing to report an error to
+    for (void* p : allocs) (void)hipFree(p);
     free_acts();
   }
   void free_acts() {
     for (void* p : {(void*)bufA, (void*)bufB, (void*)bufC, (void*)bufD, (void*)gn_sums, (void*)gn_scale, (void*)gn_shift})
-      if (p) hipFree(p);
+      if (p) (void)hipFree(p);
     bufA = bufB = bufC = bufD = nullptr;
     gn_sums = gn_scale = gn_shift = nullptr;
   }
@@ -149,7 +150,7 @@ template <typename T> struct VaeT : VaeBase {
     void* stage = nullptr;
     VHIPCHK(hipMalloc(&stage, numel * esz));
     hipError_t e = hipMemcpy(stage, ptr, numel * esz, hipMemcpyDefault);
-    if (e != hipSuccess) { hipFree(stage); return fail(ECAD_E_HIP, "copy of '%s' failed: %s", name, hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(stage); return fail(ECAD_E_HIP, "copy of '%s' failed: %s", name, hipGetErrorString(e)); }
     const int grid = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
 #define DISPATCH(KERNEL, DST, ...)                                                                                   \
   if (dtype == ECAD_DTYPE_F16) hipLaunchKernelGGL((KERNEL<f16_t, DST>), dim3(grid), dim3(256), 0, 0, (const f16_t*)stage, (DST*)w.ptr, __VA_ARGS__);   \
@@ -161,7 +162,7 @@ template <typename T> struct VaeT : VaeBase {
     else { DISPATCH(vae_convert_kernel, float, (size_t)numel) }
 #undef DISPATCH
     e = hipDeviceSynchronize();
-    hipFree(stage);
+    (void)hipFree(stage);
     if (e != hipSuccess) return fail(ECAD_E_HIP, "conversion of '%s' failed: %s", name, hipGetErrorString(e));
     w.loaded = true;
     return ECAD_OK;
@@ -207,7 +208,7 @@ template <typename T> struct VaeT : VaeBase {
   }
   // statistics -> per-(image, channel) scale/shift in gn_scale / gn_shift
   void group_norm_stats(const T* x, const std::string& name, int B, int HW, int C, hipStream_t s) {
-    hipMemsetAsync(gn_sums, 0, (size_t)B * 32 * 2 * sizeof(float), s);
+    if (hipMemsetAsync(gn_sums, 0, (size_t)B * 32 * 2 * sizeof(float), s) != hipSuccess) async_failed = true;  // reported by decode()
     const int ppb = HW >= 16384 ? 512 : HW >= 4096 ? 256 : 64;
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, x, gn_sums, HW, C, 32, ppb);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, gn_sums, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
@@ -297,6 +298,7 @@ template <typename T> struct VaeT : VaeBase {
     hipLaunchKernelGGL((vae_conv_out_kernel<T>), dim3((H / CO_TH) * (Wd / CO_TW), B), dim3(256), 0, s, cur, gn_scale, gn_shift, W_<T>("decoder.conv_out.weight"),
                        W_<float>("decoder.conv_out.bias"), out, B, H, Wd);
     VHIPCHK(hipGetLastError());
+    if (async_failed) { async_failed = false; return fail(ECAD_E_HIP, "hipMemsetAsync of the GroupNorm sums failed"); }
     return ECAD_OK;
   }
 };

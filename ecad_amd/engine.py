@@ -196,8 +196,12 @@ class EcadEngine:
 
         def trampoline(_user, step, block, comp, _in, _out, Bt, N, D, _stream):
             try:
-                out = callback(step, block, comp, io_in[: Bt * N].view(Bt, N, D))
-                io_out[: Bt * N].copy_(out.reshape(Bt * N, D))
+                # The engine filled io_in and will consume io_out on the stream step() was given; everything the plug-in launches (its own torch ops,
+                # block_attn / block_ff / batch_context, the copy into io_out) has to be ordered on THAT stream, not on whatever torch's current one is.
+                # The plug-in sees a fresh tensor, as the reference's do: the next component overwrites io_in.
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(_stream or 0), device=self.device)):  # 0 = the null stream
+                    out = callback(step, block, comp, io_in[: Bt * N].view(Bt, N, D).clone())
+                    io_out[: Bt * N].copy_(out.reshape(Bt * N, D))
                 return 0
             except BaseException as e:  # noqa: BLE001  (re-raised by step() on this thread)
                 state["error"] = e

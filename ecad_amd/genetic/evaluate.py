@@ -32,13 +32,20 @@ def evaluate_population(X: np.ndarray, score_fn: Callable[[int, np.ndarray], flo
     n = len(X)
     mine = D.shard_range(n, world, rank)
     local = np.zeros((len(mine), 2), dtype=np.float64)
-    for k, c in enumerate(mine):
-        if macs_fn is None:
-            bits = np.asarray(X[c], dtype=np.bool_).reshape(steps, blocks, 3)
-            local[k] = [1.0 - score_fn(c, bits), total_macs_T(bits)]
-        else:
-            bits = np.asarray(X[c], dtype=np.bool_)
-            local[k] = [1.0 - score_fn(c, bits), macs_fn(bits)]
+    err = ""
+    try:
+        for k, c in enumerate(mine):
+            if macs_fn is None:
+                bits = np.asarray(X[c], dtype=np.bool_).reshape(steps, blocks, 3)
+                local[k] = [1.0 - score_fn(c, bits), total_macs_T(bits)]
+            else:
+                bits = np.asarray(X[c], dtype=np.bool_)
+                local[k] = [1.0 - score_fn(c, bits), macs_fn(bits)]
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    # one flag exchange that EVERY rank enters before the all-gather: a rank whose scoring raised must not leave the others waiting in it
+    if D.any_rank_failed(bool(err)):
+        raise RuntimeError("candidate evaluation failed on " + (f"this rank ({rank}): {err}" if err else "another rank"))
     return D.gather_fitness(local, n)
 
 

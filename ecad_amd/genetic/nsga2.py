@@ -70,6 +70,18 @@ class NSGA2:
         self.X = self.F = self.G = None  # survivors
         self._pending = None
 
+    def __setstate__(self, state: dict) -> None:
+        """Checkpoints are whole dill pickles of this object (``train_nsga2_base.py``'s ``save_algorithm`` pattern): one written before
+        ``mutation_prob_var`` existed must still resume.  It gets pymoo's default and a warning, because the mutation rate it was
+        written under (per-bit ``mutation_prob``) differs from the one it continues with."""
+        self.__dict__.update(state)
+        if "mutation_prob_var" not in state:
+            import warnings
+
+            self.mutation_prob_var = min(0.5, 1.0 / self.n_var)
+            warnings.warn(f"NSGA2 checkpoint predates mutation_prob_var: resuming with pymoo's default {self.mutation_prob_var:.3g} per bit "
+                          f"(it was written under a per-bit rate of {self.mutation_prob})", RuntimeWarning, stacklevel=2)
+
     def setup(self, X0: np.ndarray | None = None) -> None:
         self._pending = (self.rng.random((self.pop_size, self.n_var)) < 0.5) if X0 is None else np.asarray(X0, dtype=np.bool_)
         self.n_gen = 1

@@ -8,7 +8,9 @@ Same on-disk contract and the same resumable cycle as ``train_nsga2_single_gpu.p
 ``gen_XXX/manager_config.json`` + ``gen_XXX/checkpoint.pkl`` written after every generation; ``--load-from <manager_config.json>`` resumes, and a run
 started by either trainer can be continued by the other); evaluation happens in-process on every rank instead of three serial subprocesses.
 Rank 0 owns ask/tell and the files; ranks exchange a 3-integer header (error flag, generation, rows), the bit matrix (broadcast) and 2 float64
-per candidate (all-gather).  A failure on rank 0 reaches every rank through the header, so the job exits instead of hanging in a collective.
+per candidate (all-gather).  Failures reach every rank instead of hanging a collective: rank 0's ask / open errors through the header in front of the
+bit matrix, an exception inside any rank's scoring through a one-integer MAX all-reduce that every rank enters in front of the all-gather (evaluate.py), rank 0's tell / ask / file errors
+through a second header behind them.
 """
 from __future__ import annotations
 
@@ -77,16 +79,23 @@ def sharded_search(rank: int, world: int, open_fn, n_var: int, generations: int,
         if err:
             raise RuntimeError(f"rank 0 failed before generation broadcast{': ' + msg if msg else ''}")
         X = D.broadcast_population(X, (rows, n_var))
-        F = evaluate(X)
+        F = evaluate(X)  # evaluate_population: a scoring failure on any rank raises on every rank (flag exchange in front of its all-gather)
+        hdr, msg = [0, gen, rows], ""
         if rank == 0:
-            for i in range(len(X)):
-                mgr.write_evaluation(i, 1.0 - F[i, 0], X[i], gen)
-            Xd, Fd, Gd = mgr.ask()
-            algo.tell(Xd, Fd, Gd)
-            mgr.generation_num = algo.n_gen
-            mgr.save_population(algo.ask(), algo.n_gen)
-            checkpoint_manager_and_algorithm(mgr, algo)
-            print(f"generation {gen}: {rows} candidates, best (1-score) {Fd[:, 0].min():.4f}, min TMACs {Fd[:, 1].min():.3f}, evaluated on {world} rank(s)")
+            try:
+                for i in range(len(X)):
+                    mgr.write_evaluation(i, 1.0 - F[i, 0], X[i], gen)
+                Xd, Fd, Gd = mgr.ask()
+                algo.tell(Xd, Fd, Gd)
+                mgr.generation_num = algo.n_gen
+                mgr.save_population(algo.ask(), algo.n_gen)
+                checkpoint_manager_and_algorithm(mgr, algo)
+                print(f"generation {gen}: {rows} candidates, best (1-score) {Fd[:, 0].min():.4f}, min TMACs {Fd[:, 1].min():.3f}, evaluated on {world} rank(s)")
+            except Exception as e:  # noqa: BLE001
+                hdr, msg = [1, gen, rows], f"{type(e).__name__}: {e}"
+        # status of rank 0's tell / ask / file section: without it a failure there left the other ranks in the next generation's broadcast
+        if D.broadcast_ints(hdr, 3)[0]:
+            raise RuntimeError(f"rank 0 failed after evaluating generation {gen}{': ' + msg if msg else ''}")
     D.barrier()
     return mgr, algo
 

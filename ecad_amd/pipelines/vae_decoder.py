@@ -1,134 +1,77 @@
-"""AutoencoderKL decoder (the SD / sd-vae-ft-ema architecture PixArt-alpha ships with), in plain PyTorch.
-
-The decode tail is OUTSIDE the native hot path ("stays PyTorch/MIOpen"); it exists so the
-"PNG-ready" latency -- what the reference's 84.09 ms/image contains (``pipelines/pass_through.py:382-396`` inside the
-timed region of ``pixart_image_generator.py:405-438``) -- can be reported next to the latents-out number.  Module and
-parameter names follow diffusers' ``AutoencoderKL`` [ext] (``decoder.conv_in``, ``decoder.mid_block.resnets.0.norm1``,
-``decoder.up_blocks.1.upsamplers.0.conv`` ...), so a real ``vae/diffusion_pytorch_model.safetensors`` loads by key.
-Without a checkpoint the weights are random-init: timing is representative, pixels are not.
+"""Decode tail on the native engine: ``HipVaeDecoder`` (``ecad_vae_*`` in include/ecad_hip.h, ``csrc/vae.hip``) -- AutoencoderKL decoder + uint8
+postprocess, what ``self.vae.decode(latents / scaling_factor)`` + ``image_processor.postprocess(.., "pil")`` are in the reference's timed region
+(``pipelines/pass_through.py:382-396`` inside ``pixart_image_generator.py:405-438``).  Weights load by diffusers' ``AutoencoderKL`` key names
+(``decoder.conv_in.weight``, ``decoder.mid_block.resnets.0.norm1.weight``, ``decoder.up_blocks.1.upsamplers.0.conv.weight`` ...), so a real
+``vae/diffusion_pytorch_model.safetensors`` loads as is; without a checkpoint ``synthetic_vae_state_dict`` fills the same table with random values
+(timing is representative, pixels are not).  The PyTorch module this decoder is checked against lives in ``oracle/vae_ref.py`` (tests only).
 """
 from __future__ import annotations
 
+import math
 from types import SimpleNamespace
 
 import torch
-import torch.nn as nn
-import torch.nn.functional as F
 
 
-class ResnetBlock2D(nn.Module):
-    def __init__(self, cin: int, cout: int, groups: int = 32, eps: float = 1e-6):
-        super().__init__()
-        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
-        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
-        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
-        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
-        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+def vae_state_dict_shapes(latent_channels: int = 4, use_post_quant_conv: bool = True, block_out_channels=(128, 256, 512, 512), layers_per_block: int = 2) -> dict[str, tuple]:
+    """name -> shape of every decoder-side parameter of diffusers' AutoencoderKL [ext] (SD VAE: 49.5 M parameters with post_quant_conv)."""
+    out: dict[str, tuple] = {}
 
-    def forward(self, x):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = self.conv2(F.silu(self.norm2(h)))
-        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+    def conv(name, cin, cout, k):
+        out[name + ".weight"], out[name + ".bias"] = (cout, cin, k, k), (cout,)
 
+    def norm(name, ch):
+        out[name + ".weight"], out[name + ".bias"] = (ch,), (ch,)
 
-class AttentionBlock(nn.Module):
-    def __init__(self, ch: int, groups: int = 32, eps: float = 1e-6):
-        super().__init__()
-        self.group_norm = nn.GroupNorm(groups, ch, eps=eps)
-        self.to_q, self.to_k, self.to_v = nn.Linear(ch, ch), nn.Linear(ch, ch), nn.Linear(ch, ch)
-        self.to_out = nn.ModuleList([nn.Linear(ch, ch)])
+    def resnet(name, cin, cout):
+        norm(name + ".norm1", cin)
+        conv(name + ".conv1", cin, cout, 3)
+        norm(name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cin, cout, 1)
 
-    def forward(self, x):
-        b, c, h, w = x.shape
-        t = self.group_norm(x).view(b, c, h * w).transpose(1, 2)
-        o = F.scaled_dot_product_attention(self.to_q(t)[:, None], self.to_k(t)[:, None], self.to_v(t)[:, None])[:, 0]
-        return x + self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
-
-
-class _Mid(nn.Module):
-    def __init__(self, ch):
-        super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch), ResnetBlock2D(ch, ch)])
-        self.attentions = nn.ModuleList([AttentionBlock(ch)])
-
-    def forward(self, x):
-        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
-
-
-class _Upsampler(nn.Module):
-    def __init__(self, ch):
-        super().__init__()
-        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
-
-    def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+    if use_post_quant_conv:
+        conv("post_quant_conv", latent_channels, latent_channels, 1)
+    rev = list(reversed(block_out_channels))
+    conv("decoder.conv_in", latent_channels, rev[0], 3)
+    resnet("decoder.mid_block.resnets.0", rev[0], rev[0])
+    norm("decoder.mid_block.attentions.0.group_norm", rev[0])
+    for lin in ("to_q", "to_k", "to_v", "to_out.0"):
+        out[f"decoder.mid_block.attentions.0.{lin}.weight"], out[f"decoder.mid_block.attentions.0.{lin}.bias"] = (rev[0], rev[0]), (rev[0],)
+    resnet("decoder.mid_block.resnets.1", rev[0], rev[0])
+    prev = rev[0]
+    for i, ch in enumerate(rev):
+        for j in range(layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else ch, ch)
+        if i < len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", ch, ch, 3)
+        prev = ch
+    norm("decoder.conv_norm_out", rev[-1])
+    conv("decoder.conv_out", rev[-1], 3, 3)
+    return out
 
 
-class _UpBlock(nn.Module):
-    def __init__(self, cin, cout, upsample: bool, n: int = 3):
-        super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout) for i in range(n)])
-        self.upsamplers = nn.ModuleList([_Upsampler(cout)]) if upsample else None
-
-    def forward(self, x):
-        for r in self.resnets:
-            x = r(x)
-        return x if self.upsamplers is None else self.upsamplers[0](x)
-
-
-class Decoder(nn.Module):
-    def __init__(self, latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512)):
-        super().__init__()
-        rev = list(reversed(block_out_channels))  # 512, 512, 256, 128
-        self.conv_in = nn.Conv2d(latent_channels, rev[0], 3, padding=1)
-        self.mid_block = _Mid(rev[0])
-        blocks, prev = [], rev[0]
-        for i, ch in enumerate(rev):
-            blocks.append(_UpBlock(prev, ch, upsample=i < len(rev) - 1))
-            prev = ch
-        self.up_blocks = nn.ModuleList(blocks)
-        self.conv_norm_out = nn.GroupNorm(32, rev[-1], eps=1e-6)
-        self.conv_out = nn.Conv2d(rev[-1], out_channels, 3, padding=1)
-
-    def forward(self, z):
-        x = self.mid_block(self.conv_in(z))
-        for b in self.up_blocks:
-            x = b(x)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
-
-
-class AutoencoderKLDecoderOnly(nn.Module):
-    """``vae.decode(latents / scaling_factor, return_dict=False)[0]`` surface the pipeline uses."""
-
-    def __init__(self, scaling_factor: float = 0.18215, latent_channels: int = 4, use_post_quant_conv: bool = True, shift_factor: float = 0.0):
-        super().__init__()
-        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1) if use_post_quant_conv else None
-        self.decoder = Decoder(latent_channels)
-        self.config = SimpleNamespace(scaling_factor=scaling_factor, latent_channels=latent_channels, use_post_quant_conv=use_post_quant_conv, shift_factor=shift_factor)
-
-    @classmethod
-    def flux(cls) -> "AutoencoderKLDecoderOnly":
-        """Geometry of the FLUX.1 VAE [ext]: 16 latent channels, no post_quant_conv, scaling 0.3611, shift 0.1159."""
-        return cls(scaling_factor=0.3611, latent_channels=16, use_post_quant_conv=False, shift_factor=0.1159)
-
-    @torch.no_grad()
-    def decode(self, z: torch.Tensor, return_dict: bool = False):
-        p = next(self.parameters())
-        z = z.to(p.dtype).contiguous(memory_format=torch.channels_last)
-        x = self.decoder(self.post_quant_conv(z) if self.post_quant_conv is not None else z)
-        return (x,)
-
-    @classmethod
-    def random_init(cls, seed: int = 0, device="cuda", dtype=torch.float16, **kw) -> "AutoencoderKLDecoderOnly":
-        torch.manual_seed(seed)
-        return cls(**kw).to(device=device, dtype=dtype).to(memory_format=torch.channels_last).eval()
+def synthetic_vae_state_dict(seed: int = 0, latent_channels: int = 4, use_post_quant_conv: bool = True, device="cpu", dtype=torch.float32) -> dict[str, torch.Tensor]:
+    """Random weights with torch's default Conv / Linear statistics (uniform in +-1/sqrt(fan_in)); GroupNorm affine = identity."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = {}
+    for name, shape in vae_state_dict_shapes(latent_channels, use_post_quant_conv).items():
+        if "norm" in name:
+            t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+        else:
+            wshape = shape if name.endswith("weight") else vae_state_dict_shapes(latent_channels, use_post_quant_conv)[name[: -len("bias")] + "weight"]
+            bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
+            t = (torch.rand(shape, generator=g) * 2.0 - 1.0) * bound
+        sd[name] = t.to(device=device, dtype=dtype)
+    return sd
 
 
 class HipVaeDecoder:
     """The same decoder on the native engine (``ecad_vae_*`` in include/ecad_hip.h): latents in, uint8 NHWC RGB out.
 
-    ``decode_to_uint8`` is what the pipeline uses for ``output_type="pil"``; ``from_torch`` copies the weights of a
-    PyTorch ``AutoencoderKLDecoderOnly`` (or any state dict with diffusers' AutoencoderKL keys).
+    ``decode_to_uint8`` is what the pipeline uses for ``output_type="pil"``; ``from_torch`` copies the weights of any module that has diffusers'
+    AutoencoderKL ``config`` fields and ``state_dict()`` keys; ``random_init`` is the no-checkpoint stand-in (bench.py's PNG-ready rate).
     """
 
     def __init__(self, scaling_factor: float = 0.18215, dtype: torch.dtype = torch.float16, device: int = 0, latent_channels: int = 4,
@@ -164,7 +107,14 @@ class HipVaeDecoder:
         return self
 
     @classmethod
-    def from_torch(cls, module: "AutoencoderKLDecoderOnly", device: int = 0, dtype: torch.dtype = torch.float16) -> "HipVaeDecoder":
+    def random_init(cls, seed: int = 0, device: int = 0, dtype: torch.dtype = torch.float16, flux: bool = False) -> "HipVaeDecoder":
+        """SD-VAE geometry (PixArt) or the FLUX.1 VAE geometry [ext] (16 latent channels, no post_quant_conv, scaling 0.3611, shift 0.1159)."""
+        kw = dict(scaling_factor=0.3611, latent_channels=16, use_post_quant_conv=False, shift_factor=0.1159) if flux else {}
+        dec = cls(dtype=dtype, device=device, **kw)
+        return dec.load_state_dict(synthetic_vae_state_dict(seed, dec.config.latent_channels, dec.config.use_post_quant_conv))
+
+    @classmethod
+    def from_torch(cls, module, device: int = 0, dtype: torch.dtype = torch.float16) -> "HipVaeDecoder":
         c = module.config
         return cls(c.scaling_factor, dtype, device, c.latent_channels, getattr(c, "use_post_quant_conv", True), getattr(c, "shift_factor", 0.0) or 0.0).load_state_dict(module.state_dict())
 

@@ -202,7 +202,7 @@ int ecad_op_attention_ex(EcadEngine* e, int kernel, const void* q, int64_t ldq, 
 /* The production launch of attention on the 256 / 1024 / 4096-token geometries (csrc/gemm3s_attn.h): the query projection of a block with the
  * attention of its rows run in the GEMM tail.   out[b*n_tokens + i, h*72 .. +71] = softmax_j((x Wq^T + bq)[i, h] . k[b, j, h] / sqrt(72) + key_bias[b, j]) v[b, j, h]
  * = attn.to_q + scaled_dot_product_attention of Attention.forward [ext] behind cached_transformer_block.py:231-239 (self; call_site ECAD_SITE_QKV, key_bias
- * ignored, n_keys = n_tokens) and :282-288 (cross; call_site ECAD_SITE_ATTN2_Q, key_bias = additive mask or null, any n_keys).  x [Bt*n_tokens, D]; wq [D, D];
+ * ignored, n_keys = n_tokens) and :282-288 (cross; call_site ECAD_SITE_Q2, key_bias = additive mask or null, any n_keys).  x [Bt*n_tokens, D]; wq [D, D];
  * bq fp32 [D]; k / v: row (b*n_keys + j), head h at column h*72, row stride ld_kv elements; out [Bt*n_tokens, D].  D = heads x 72, n_tokens % 256 == 0 (self:
  * also a multiple of 128 keys), else ECAD_E_UNSUPPORTED -- the engine then runs the projection and ecad_op_attention as separate launches, and so can the caller. */
 int ecad_op_qproj_attention(EcadEngine* e, int call_site, const void* x, const void* wq, const float* bq, const void* k, const void* v, int64_t ld_kv,

@@ -89,10 +89,10 @@ def main():
     print(f"flux {a.grid * 16}x{a.grid * 16} batch {B}: {ms:.1f} ms per batch = {B / ms * 1e3:.3f} images/s; reference-equivalent {tflop / B:.1f} TFLOP/image -> {tflop / ms * 1e3:.0f} TFLOP/s whole job")
     if a.decode_tail:
         from ecad_amd.pipelines.flux import FluxPipeline
-        from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
+        from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
 
         torch.manual_seed(0)
-        vae = HipVaeDecoder.from_torch(AutoencoderKLDecoderOnly.flux(), dtype=torch.bfloat16)
+        vae = HipVaeDecoder.random_init(0, dtype=torch.bfloat16, flux=True)
         lat = FluxPipeline._unpack_latents(run(True).bfloat16(), a.grid * 16, a.grid * 16)
         for _ in range(2):
             img = vae.decode_to_uint8(lat)

@@ -4,9 +4,9 @@ import sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
+from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
 torch.manual_seed(0)
-vae = HipVaeDecoder.from_torch(AutoencoderKLDecoderOnly())
+vae = HipVaeDecoder.random_init(0)
 lat = torch.randn(16, 4, 32, 32, device="cuda") * 0.18215
 for _ in range(3): vae.decode_to_uint8(lat)
 torch.cuda.synchronize()

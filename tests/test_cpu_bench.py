@@ -42,6 +42,14 @@ def test_single_rank_default_and_explicit():
     assert d["config"]["batch_per_gpu"] == 4 and abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1000.0)) / d["value"] < 1e-9
 
 
+def test_forced_process_group_at_world_one():
+    """ECAD_FORCE_DIST=1: a single rank still creates the process group and runs barrier + MAX all-reduce through it (gloo here, RCCL in
+    tests/test_gpu_bench_contract.py) -- the switch that lets a 1-GPU box exercise the collective path."""
+    d = _line(_run(["--gpus", "1", "--stub", "--steps", "2"], env_extra={"ECAD_FORCE_DIST": "1"}))
+    assert d["n_gpus"] == 1 and d["config"]["process_group"] == "gloo, world 1" and 20.0 <= d["ms_per_step"] < 40.0
+    assert _line(_run(["--stub", "--steps", "1"]))["config"]["process_group"] is None
+
+
 def test_gpus_flag_contradicting_torchrun_environment_is_refused():
     p = _run(["--gpus", "4", "--stub"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE=1" in (p.stderr + p.stdout)

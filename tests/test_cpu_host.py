@@ -179,7 +179,9 @@ def test_ecad_import_alias_resolves_to_native_host_side():
 
 
 def test_vae_decoder_shapes_and_diffusers_key_names():
-    from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly
+    """The product's weight table (names + shapes the HIP decoder loads by) against the checker module's state_dict(), both geometries."""
+    from ecad_amd.pipelines.vae_decoder import synthetic_vae_state_dict, vae_state_dict_shapes
+    from oracle.vae_ref import AutoencoderKLDecoderOnly
 
     vae = AutoencoderKLDecoderOnly().eval()
     keys = set(vae.state_dict())
@@ -192,6 +194,11 @@ def test_vae_decoder_shapes_and_diffusers_key_names():
     assert 49e6 < n < 50e6  # SD VAE decoder + post_quant_conv ~49.5 M parameters
     img = vae.decode(torch.randn(1, 4, 8, 8))[0]
     assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()
+    for module, kw in ((vae, {}), (AutoencoderKLDecoderOnly.flux(), dict(latent_channels=16, use_post_quant_conv=False))):
+        assert {k: tuple(v.shape) for k, v in module.state_dict().items()} == vae_state_dict_shapes(**kw)
+    sd = synthetic_vae_state_dict(0)
+    vae.load_state_dict(sd)  # strict: same keys, same shapes
+    assert float(sd["decoder.conv_in.weight"].abs().max()) <= 1.0 / 6.0 and float(sd["decoder.conv_norm_out.weight"].min()) == 1.0
 
 
 def test_compute_macs_cli_geometry_follows_the_weights(tmp_path, capsys):

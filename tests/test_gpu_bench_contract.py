@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _bench(*args):
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+def _bench(*args, env=None):
+    import os
+
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT, env={**os.environ, **(env or {})})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -44,3 +46,34 @@ def test_bench_line_contract():
 def test_gpus_1_explicit_and_secondary_workload_lines_are_labelled():
     d = _bench("--gpus", "1", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-decode-tail")
     assert d["n_gpus"] == 1 and "[secondary: batch 2]" in d["metric"] and "cpu_baseline" not in d and "secondary" not in d
+
+
+def test_rccl_process_group_at_world_one():
+    """RCCL readiness on the one GPU a test box has (ECAD_FORCE_DIST=1): bench.py creates the `nccl` process group at world size 1 and its timed
+    region runs the barrier and the MAX all-reduce through it; the NSGA-II plumbing of ecad_amd/distributed.py (all-gather of the fitness rows,
+    broadcast of the bit matrix / header, error-flag all-reduce) runs on device buffers through RCCL as well.  Both in fresh child processes: the
+    parent never touches the GPU before them, nothing is exec'd."""
+    d = _bench("--gpus", "1", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-decode-tail", env={"ECAD_FORCE_DIST": "1"})
+    assert d["n_gpus"] == 1 and d["config"]["process_group"] == "nccl (RCCL), world 1 [ECAD_FORCE_DIST]" and d["value"] > 0
+    code = (
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "from ecad_amd import distributed as D\n"
+        "rank, world, local = D.init()\n"
+        "assert dist.is_initialized() and dist.get_backend() == 'nccl' and (rank, world) == (0, 1)\n"
+        "assert D._comm_device().type == 'cuda'\n"
+        "F = np.arange(18, dtype=np.float64).reshape(9, 2)\n"
+        "assert np.array_equal(D.gather_fitness(F, 9), F)\n"
+        "X = np.random.default_rng(0).random((9, 1680)) < 0.5\n"
+        "assert np.array_equal(D.broadcast_population(X, X.shape), X)\n"
+        "assert D.broadcast_ints([0, 7, 9], 3) == [0, 7, 9]\n"
+        "assert D.max_over_ranks(0.125) == 0.125 and D.any_rank_failed(False) is False and D.any_rank_failed(True) is True\n"
+        "from ecad_amd.genetic.evaluate import evaluate_population\n"
+        "R = evaluate_population(X, lambda c, bits: -float(bits.mean()))\n"
+        "assert R.shape == (9, 2) and np.all(R[:, 0] > 1.0)\n"
+        "D.barrier(); dist.destroy_process_group(); print('RCCL-WORLD-1-OK')\n"
+    )
+    import os
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env={**env, "ECAD_FORCE_DIST": "1", "PYTHONPATH": str(ROOT)})
+    assert out.returncode == 0 and "RCCL-WORLD-1-OK" in out.stdout, out.stderr[-2000:]

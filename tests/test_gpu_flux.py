@@ -259,6 +259,53 @@ def test_forced_recompute_and_all_cached_steps_are_exact_replays():
     assert torch.equal(res[0][0], res[0][1])  # recomputing everything on the same inputs is deterministic too
 
 
+def test_flux_1024_full_size_properties():
+    """BASELINE config 5 at its full size -- FLUX.1-dev geometry, 19 joint + 38 single blocks, 1024 x 1024 (N = 4096 + T = 512), batch 2, bf16, the
+    paper's schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json -- cannot be checked against the fp32 CPU oracle in seconds (the reduced-depth
+    full-width test below covers the arithmetic), so the size-independent properties: determinism, hipGraph == eager bit for bit, sample 1 of the
+    batch == that sample run alone (rows of a batch never see each other), and the engine's Linear MAC count == the closed form that reproduces the
+    reference's own `metrics.total_macs` of this file (batch 2 there too: 376.6 TMACs)."""
+    import json
+    from pathlib import Path
+
+    from ecad_amd.pipelines.flow_match import flow_match_sigmas, model_scalars
+    from ecad_amd.schedulers.cache_scheduler.flux_cache_schedule import FluxCacheSchedule
+    from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import FluxTransformer2DEdited, synthetic_state_dict
+    from oracle.schedule_ref import flux_bits_from_schedule_json, flux_mac_model
+
+    path = Path(__file__).resolve().parents[1] / "schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json"
+    B, grid, T = 2, 64, 512
+    sched = FluxCacheSchedule.from_json(path)
+    model = FluxTransformer2DEdited(guidance_embeds=True, max_batch=B, max_image_tokens=grid * grid, max_text_tokens=T, torch_dtype=torch.bfloat16, device=0)
+    eng = model.engine
+    model.load_state_dict(synthetic_state_dict(model.config, 0, device="cuda:0", dtype=torch.bfloat16))
+    bf, bs = sched.to_device_bits()
+    of, os_ = flux_bits_from_schedule_json(path)
+    assert np.array_equal(np.asarray(bf, bool), of) and np.array_equal(np.asarray(bs, bool), os_)  # product bit layout == oracle's reading of the file
+    eng.set_schedule(bf, bs)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    enc = (torch.randn(B, T, 4096, generator=g, device="cuda") * 0.1).bfloat16()
+    pooled = (torch.randn(B, 768, generator=g, device="cuda") * 0.5).bfloat16()
+    lat0 = torch.randn(B, grid * grid, 64, generator=g, device="cuda")
+    sig = flow_match_sigmas(sched.num_inference_steps, grid * grid)
+    tm, gm = model_scalars(sig, 5.0, torch.bfloat16)
+
+    def run(rows, graph):
+        x = lat0[rows].clone()
+        eng.run_schedule(x, enc[rows], pooled[rows], grid, grid, tm, gm, sig, use_graph=graph)
+        torch.cuda.synchronize()
+        return x
+
+    both = slice(0, B)
+    a, b, c = run(both, True), run(both, True), run(both, False)
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+    st = eng.stats()
+    want = int(flux_mac_model(resolve_executed(of), resolve_executed(os_), tokens=grid * grid, batch=2).sum())  # the reference counts at batch 2
+    assert 2 * st["linear_macs_reference"] == want == json.loads(path.read_text())["metrics"]["total_macs"]  # the engine's figure is per sample
+    one = run(slice(1, 2), False)
+    assert torch.equal(one, a[1:2])
+
+
 def test_flux_errors():
     from ecad_amd.flux_engine import EcadFluxEngine
 

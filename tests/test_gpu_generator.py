@@ -119,6 +119,52 @@ def test_alpha_1024_ms_schedule_runs_micro_conditioned(embedding_dir):
     gen.free_diffusion_pipeline()
 
 
+def test_sigma_1024_schedule_file_through_the_sigma_generator(tmp_path):
+    """BASELINE config 3 as a workload a user can name: the authored schedule file (a 256 -> 1024 transfer of the paper's Sigma `ours_fast`,
+    scripts/transfer_schedule.py) carries config.transformer_weights = PixArt-Sigma-XL-2-1024-MS, height / width 1024 and image_generator =
+    PixArtSigmaImageGenerator; `get_image_generator_type_from_config` -> PixArtSigmaImageGenerator (pixart_sigma_image_generator.py:1-38) ->
+    PixArtSigmaPipeline -> engine at N = 4096, T = 300, sincos interpolation_scale 2, no micro-conditioning.  The whole-loop graph and the per-step
+    forward() path agree; the engine's Linear MACs equal the closed form at this run's text length."""
+    from ecad_amd.benchmark.compute_macs import macs_per_step
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type_from_config
+
+    path = ROOT / "schedules/sigma_cache_schedules/transfer_256_to_1024/ours_fast_256_to_1024.json"
+    data = json.loads(path.read_text())
+    src = json.loads((ROOT / "schedules/schedules_in_paper/pixart_sigma_256/ours_fast.json").read_text())
+    assert data["cache_schedule"] == src["cache_schedule"]  # a transfer keeps the schedule body (as flux_256_to_1024/* keep flux_256/*'s)
+    T = 300
+    g = torch.Generator().manual_seed(3)
+    neg_mask = torch.zeros(1, T, dtype=torch.int64)
+    neg_mask[:, :2] = 1
+    mask = torch.zeros(1, T, dtype=torch.int64)
+    mask[:, :211] = 1
+    torch.save({"prompt_embeds": torch.randn(1, T, 4096, generator=g) * 0.1, "prompt_attention_mask": mask,
+                "negative_prompt_embeds": torch.randn(1, T, 4096, generator=g) * 0.1, "negative_prompt_attention_mask": neg_mask}, tmp_path / "000__prompt_id:0.pt")
+    gen_type = get_image_generator_type_from_config(data["config"])
+    assert gen_type.__name__ == "PixArtSigmaImageGenerator"
+    gen = gen_type(schedule_path=path, max_batch=2)
+    assert gen.transformer_weights == "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" and (gen.height, gen.width) == (1024, 1024)
+    assert gen.cache_schedule.name == src["cache_schedule"]["name"] and gen.num_inference_steps == 20
+    gen.create_diffusion_pipeline()
+    tr = gen.diffusion_pipeline.transformer
+    assert type(gen.diffusion_pipeline).__name__ == "PixArtSigmaPipeline"
+    assert tr.config.sample_size == 128 and tr.config.interpolation_scale == 2 and not tr.use_additional_conditions
+    batch = next(iter(gen.load_and_batch_embeddings(tmp_path, 1)))
+    a = gen.generate_images(batch, images_per_prompt=1, output_type="latent")[0][0].float()
+    assert a.shape == (4, 128, 128) and torch.isfinite(a).all()
+    assert gen.cache_schedule.curr_step == 0
+    st = tr.engine.stats()
+    assert st["linear_macs_reference"] == int(macs_per_step(gen.cache_schedule.to_numpy(), tokens=4096, text_tokens=T, batch=2).sum())
+    gen.diffusion_pipeline.native_loop = False
+    b = gen.generate_images(batch, images_per_prompt=1, output_type="latent")[0][0].float()
+    rel = float((a - b).norm() / b.norm())
+    print(f"Sigma-1024 native loop vs per-step forward(): rel-L2 {rel:.2e}")
+    assert within(rel, 4e-3)
+    imgs = gen.generate_images(batch, images_per_prompt=1, output_type="pil")  # decode tail at 1024 x 1024
+    assert imgs[0][0].size == (1024, 1024)
+    gen.free_diffusion_pipeline()
+
+
 def test_pipeline_without_classifier_free_guidance(embedding_dir):
     """guidance_scale <= 1 (diffusers' do_classifier_free_guidance False): only the conditional half runs, through the per-step path.  With
     guidance 1 the CFG formula u + 1 * (c - u) collapses to c, so the CFG-doubled run at guidance 1 + 1e-6 must give the same latents."""

@@ -1,5 +1,5 @@
 """-m gpu: the HIP AutoencoderKL decoder (ecad_vae_* through the C ABI) vs a plain PyTorch fp32 reference of the same
-module graph (ecad_amd/pipelines/vae_decoder.py::AutoencoderKLDecoderOnly on the CPU), uint8 RGB out.
+module graph (oracle/vae_ref.py::AutoencoderKLDecoderOnly on the CPU -- the checker lives with the oracle, not in the product tree), uint8 RGB out.
 
 Tolerance (stated): after ~30 fp16 conv / GroupNorm layers and the final (x/2+0.5)*255 rounding, at most 1 % of the
 bytes may differ by more than 2 levels and the mean absolute difference must stay below 0.6 levels."""
@@ -16,7 +16,8 @@ def _ref_uint8(vae, latents):
 
 @pytest.mark.parametrize("B,h,w", [(2, 16, 8), (1, 32, 32), (3, 32, 32)])
 def test_hip_vae_decoder_matches_pytorch(B, h, w):
-    from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
+    from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
+    from oracle.vae_ref import AutoencoderKLDecoderOnly  # checker only
 
     torch.manual_seed(0)
     ref = AutoencoderKLDecoderOnly().float().eval()
@@ -42,7 +43,8 @@ def test_hip_vae_decoder_matches_pytorch(B, h, w):
 
 def test_hip_flux_vae_geometry_matches_pytorch():
     """FLUX VAE: 16 latent channels, no post_quant_conv, z = latents / scaling + shift."""
-    from ecad_amd.pipelines.vae_decoder import AutoencoderKLDecoderOnly, HipVaeDecoder
+    from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
+    from oracle.vae_ref import AutoencoderKLDecoderOnly  # checker only
 
     torch.manual_seed(2)
     ref = AutoencoderKLDecoderOnly.flux().float().eval()

@@ -67,6 +67,7 @@ struct EngineBase {
   virtual int init() = 0;
   virtual int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
   virtual int finalize_weights() = 0;
+  virtual int share_weights(EngineBase* src) = 0;
   virtual int set_fp8(int on) = 0;
   virtual int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
@@ -128,6 +129,7 @@ template <typename T> class EngineT : public EngineBase {
   // ---- weights
   char* warena = nullptr;
   size_t warena_bytes = 0, warena_used = 0;
+  bool weights_shared = false;  // ecad_share_weights: warena and every pointer into it belong to another engine (which must outlive this one)
   struct Dest { void* ptr; bool f32; int64_t rows, cols, ld; bool loaded; };
   std::map<std::string, Dest> dests;
   struct Blk {
@@ -238,7 +240,8 @@ template <typename T> class EngineT : public EngineBase {
     if (desc_dyn_dev) (void)hipFree(desc_dyn_dev);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
-    if (warena) (void)hipFree(warena);
+    if (warena && !weights_shared) (void)hipFree(warena);  // a borrowed arena belongs to the engine it came from
+    if (pos) (void)hipFree(pos);
     if (ws) (void)hipFree(ws);
     for (void* q : w8allocs) (void)hipFree(q);
     if (a8) (void)hipFree(a8);
@@ -285,6 +288,12 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) attn_shared = strcmp(at, "generic") != 0;
+    if (const char* gh = getenv("ECAD_GEMM_HALF")) {  // A/B switch: 1 = the two attention out-projections, 2 = + FF2, 3 = + cross-attention Q when it runs unfused
+      const int lv = atoi(gh);
+      if (lv >= 1) gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = 4;
+      if (lv >= 2) gemm_impl_cls[KC_GEMM_FF2] = 4;
+      if (lv >= 3) gemm_impl_cls[KC_GEMM_Q2] = gemm_impl_cls[KC_GEMM_QKV] = 4;
+    }
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
       if (strcmp(gi, "persistent") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
@@ -346,7 +355,7 @@ template <typename T> class EngineT : public EngineBase {
     w_c2 = walloc<T>(d * d); b_c2 = walloc<float>(d);
     w_proj = walloc<T>(PROJ_PAD * d); b_proj = walloc<float>(PROJ_PAD);
     sst_out = walloc<float>(2 * d);
-    pos = walloc<float>((size_t)cfg.max_tokens * d);
+    HIPCHK(hipMalloc((void**)&pos, (size_t)cfg.max_tokens * d * sizeof(float)));  // per engine (geometry-dependent), never part of a shared weight arena
     reg("pos_embed.proj.weight", w_patch, false, d, CIN * P * P, CIN * P * P);
     reg("pos_embed.proj.bias", b_patch, true, 1, d, d);
     reg("adaln_single.emb.timestep_embedder.linear_1.weight", w_t1, false, d, 256, 256);
@@ -428,6 +437,7 @@ template <typename T> class EngineT : public EngineBase {
   // -------------------------------------------------------------------------------------------
   int load_weight(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) override {
     HIPCHK(hipSetDevice(dev));
+    if (weights_shared) return fail(ECAD_E_INVALID, "this context borrows its weights (ecad_share_weights): load them into the engine that owns them");
     auto it = dests.find(name);
     if (it == dests.end()) {
       if (strcmp(name, "pos_embed.pos_embed") == 0) return ECAD_OK;  // fixed table, recomputed here
@@ -470,7 +480,34 @@ template <typename T> class EngineT : public EngineBase {
     if (fp8) return build_fp8_weights();
     return ECAD_OK;
   }
+  // Second (third ...) execution context on the same GPU: this engine keeps its own workspaces, cache arena, plans and hipGraph but reads the weights of
+  // `src` -- same configuration, so the arena was carved up in the same order and every pointer is the donor's base plus the same offset.
+  int share_weights(EngineBase* src_) override {
+    auto* src = dynamic_cast<EngineT<T>*>(src_);
+    if (!src || src == this) return fail(ECAD_E_INVALID, "share_weights: the donor must be another engine of the same dtype");
+    if (!src->finalized) return fail(ECAD_E_NOT_READY, "share_weights: the donor's weights are not finalized");
+    if (src->dev != dev || src->L != L || src->D != D || src->CAP != CAP || src->CIN != CIN || src->COUT != COUT || src->P != P ||
+        src->cfg.use_additional_conditions != cfg.use_additional_conditions || src->warena_bytes != warena_bytes || src->warena_used != warena_used)
+      return fail(ECAD_E_INVALID, "share_weights: the two engines were created with different model configurations (or on different devices)");
+    if (fp8 || src->fp8) return fail(ECAD_E_UNSUPPORTED, "share_weights: fp8 weight copies are per engine; load the weights into each context instead");
+    if (weights_shared) return fail(ECAD_E_INVALID, "share_weights: this engine already borrows its weights");
+    HIPCHK(hipSetDevice(dev));
+    drop_all_plans();
+    const ptrdiff_t delta = src->warena - warena;
+    auto rb = [&](auto*& ptr) { if (ptr) ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<char*>(ptr) + delta); };
+    for (auto& b : blk) { rb(b.w_qkv); rb(b.w_o1); rb(b.w_q2); rb(b.w_o2); rb(b.w_ff1); rb(b.w_ff2); rb(b.b_qkv); rb(b.b_o1); rb(b.b_q2); rb(b.b_o2); rb(b.b_ff1); rb(b.b_ff2); rb(b.sst); }
+    rb(w_kv2_all); rb(w_patch); rb(w_t1); rb(w_t2); rb(w_ada); rb(w_c1); rb(w_c2); rb(w_proj);
+    rb(b_kv2_all); rb(b_patch); rb(b_t1); rb(b_t2); rb(b_ada); rb(b_c1); rb(b_c2); rb(b_proj); rb(sst_out);
+    for (int k = 0; k < 2; ++k) { rb(w_sz1[k]); rb(w_sz2[k]); rb(b_sz1[k]); rb(b_sz2[k]); }
+    for (auto& kv : dests) { kv.second.ptr = reinterpret_cast<char*>(kv.second.ptr) + delta; kv.second.loaded = true; }
+    (void)hipFree(warena);
+    warena = src->warena;
+    weights_shared = true;
+    finalized = true;
+    return ECAD_OK;
+  }
   int set_fp8(int on) override {
+    if (on && weights_shared) return fail(ECAD_E_UNSUPPORTED, "fp8 weight copies are per engine: not on a context that borrows its weights");
     if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; drop_all_plans(); }
     return ECAD_OK;
   }
@@ -971,6 +1008,7 @@ template <typename T> class EngineT : public EngineBase {
   bool pg_attr[4][KC_COUNT] = {};
   int num_cus = 256;
   bool g3_attr[4][KC_COUNT] = {};
+  bool g3h_attr[4][KC_COUNT] = {};
   // per call-site class: 1 = persistent producer/consumer (pgemm.h), 0 = one tile per workgroup (gemm3s.h).  Defaults from
   // 2 = wide 256x288 tiles (gemm2w.h, N % 288 == 0).  Defaults from interleaved in-process A/B runs with cold caches
   // (scripts/bench_gemm.py --cold): wide tiles wherever the tile count still fills the chip (FF1, text K/V); the persistent
@@ -994,6 +1032,15 @@ template <typename T> class EngineT : public EngineBase {
         hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);
         return ECAD_OK;
       }
+    }
+    if (gemm_impl_cls[TAG] == 4) {  // 128 x 144 tiles, four waves, two workgroups per CU (gemm3s.h half-tile variant; ECAD_GEMM_HALF / kernel id 4)
+      if (!g3h_attr[EPI][TAG]) {
+        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3H_BM, G3H_NW, G3H_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3H_LDS_BYTES));
+        g3h_attr[EPI][TAG] = true;
+      }
+      const int tilesh = ((g.M + G3H_BM - 1) / G3H_BM) * (g.N / G3_BN);
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3H_BM, G3H_NW, G3H_STAGES>), dim3(tilesh), dim3(G3H_NW * 64), G3H_LDS_BYTES, s, g);
+      return ECAD_OK;
     }
     if (gemm_impl_cls[TAG] == 0) {
       if (!g3_attr[EPI][TAG]) {
@@ -1504,7 +1551,8 @@ template <typename T> class EngineT : public EngineBase {
       HIPCHK(hipGetLastError());
       return ECAD_OK;
     }
-    if (kernel < 0 || kernel > 2) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
+    if (kernel == 4 && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the half-tile kernel has no attention tail");
+    if ((kernel < 0 || kernel > 2) && kernel != 4) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
     if (Nn % PG_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
     if (kernel == 2) {
       if (Nn % G2_BN) return fail(ECAD_E_UNSUPPORTED, "gemm2w tiles need N %% 288 == 0, got %d", Nn);
@@ -1607,6 +1655,11 @@ const char* ecad_last_error(const EcadEngine* e) { return e ? e->impl->err.c_str
 
 int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { ENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
 int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights(); }
+int ecad_share_weights(EcadEngine* e, EcadEngine* donor) {
+  ENG(e);
+  if (!donor) return E->fail(ECAD_E_INVALID, "NULL donor");
+  return E->share_weights(reinterpret_cast<EngineBase*>(donor));
+}
 int ecad_set_fp8(EcadEngine* e, int on) { ENG(e); return E->set_fp8(on); }
 int ecad_set_added_cond(EcadEngine* e, const float* resolution, const float* aspect_ratio, int Bt) { ENG(e); return E->set_added_cond(resolution, aspect_ratio, Bt); }
 int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks) { ENG(e); if (!bits) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bits, steps, blocks); }

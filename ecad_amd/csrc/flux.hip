@@ -884,6 +884,7 @@ template <typename T> class FluxT : public FluxBase {
     if (T_ < 1 || T_ > cfg.max_text_tokens) return fail(ECAD_E_INVALID, "text tokens %d outside [1, %d]", T_, cfg.max_text_tokens);
     if (!plan_valid || B_ != B || gh != GH || gw != GW || T_ != Tt) {
       B = B_; GH = gh; GW = gw; N = gh * gw; Tt = T_;
+      ts_host.clear();  // ts_dev / gs_dev hold one row per (step, sample): a new batch size re-lays them out even when the timesteps are the same
       int rc = build_rope();
       if (rc) return rc;
       return build_plans();

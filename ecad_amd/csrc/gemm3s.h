@@ -15,13 +15,22 @@ constexpr int G3_STAGE_BYTES = (G3_BM + G3_BN) * 128;
 constexpr int G3_LDS_BYTES = G3_STAGES * G3_STAGE_BYTES;
 static_assert(G3A_LDS_BYTES <= G3_LDS_BYTES, "the fused attention tail (Q tile + K/V staging + bias strip) must fit the operand ring: launch_g3_attn requests G3_LDS_BYTES only");
 
-template <typename T, int EPI, int TAG>
-__global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p) {
-  constexpr int BM = G3_BM, BN = G3_BN, NWAVES = G3_NW;
+// Half-tile variant (round 3, measured in DESIGN 5c): BM_ = 128, NW_ = 4, STAGES_ = 2 -- 128 x 144 tiles, four waves of 32 x 144 (the same wave tile, fragment
+// layout and epilogue), a 2-stage ring of 34 816-byte stages = 69 632 bytes, so that TWO workgroups are resident per CU (and two waves per SIMD come from different
+// workgroups, behind different barriers).  Plain and read-modify-write epilogues only (the fused attention tail needs 86 KB).
+constexpr int G3H_BM = 128, G3H_NW = 4, G3H_STAGES = 2;
+constexpr int G3H_LDS_BYTES = G3H_STAGES * (G3H_BM + G3_BN) * 128;
+static_assert(2 * G3H_LDS_BYTES <= 160 * 1024, "two half-tile workgroups per CU");
+
+template <typename T, int EPI, int TAG, int BM_ = G3_BM, int NW_ = G3_NW, int STAGES_ = G3_STAGES>
+__global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p) {  // two waves per SIMD either way: 8 of one workgroup, or 4 + 4 of two
+  constexpr int BM = BM_, BN = G3_BN, NWAVES = NW_, NSTG = STAGES_;
   constexpr int WTM = BM / NWAVES;
   constexpr int FM = WTM / 16, FN = BN / 16;
+  static_assert(FM == 2 && FN == 9 && (NSTG == 2 || NSTG == 3), "wave tile 32 x 144");
+  static_assert(BM == G3_BM || (EPI != EPI_BIAS_ATTN && EPI != EPI_BIAS_ATTN_TAIL), "the attention tail runs on 256-row tiles");
   constexpr int A_BYTES = BM * 128;
-  constexpr int STAGE_BYTES = G3_STAGE_BYTES;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int A_INST = BM / 8 / NWAVES;
   constexpr int B_INST_TOTAL = BN / 8;
   constexpr int B_INST_MAX = (B_INST_TOTAL + NWAVES - 1) / NWAVES;
@@ -88,8 +97,10 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
       glds16(a_src[q], abase + (wave * A_INST + q) * 1024);
     } else {
       constexpr int i = q - A_INST;
-      const int inst = wave + i * NWAVES;
-      if (inst < B_INST_TOTAL) glds16(b_src[i], abase + A_BYTES + inst * 1024);
+      if constexpr (i < B_INST_MAX) {
+        const int inst = wave + i * NWAVES;
+        if (inst < B_INST_TOTAL) glds16(b_src[i], abase + A_BYTES + inst * 1024);
+      }
     }
   };
   auto advance_src = [&]() {
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   unsigned long long st_c1 = 0, st_c2 = 0, st_ca = 0, st_cb = 0;
 #endif
   issue(0);
-  if (nk > 1) issue(1);
+  if (NSTG == 3 && nk > 1) issue(1);
   // EPI_BIAS_CACHE_RESID: the hidden-state chunks this lane updates in the epilogue are fetched during the K loop, so their HBM latency hides
   // behind it instead of sitting at the tail of a 1-tile-per-CU kernel -- but not in front of it: vmcnt retires in order, so loads issued
   // before the first K-steps make the pipeline fill wait for them (stamped: prologue 5.7k cycles against 2.6k for the plain epilogue).
@@ -188,7 +199,8 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   // top of K-step kt: stage kt has landed when at most the newest stage's DMA (A_INST + 2 = 6 per wave) is outstanding; in the step after the
   // residual prefetch went out behind that DMA its NCH loads are newer still, so they may be outstanding as well
   auto step_top = [&](int kt) {
-    if (kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // 2-stage ring: the stage of this step is the newest thing in flight (it was issued during the previous step): everything must have landed
+    if (NSTG == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (EPI == EPI_BIAS_CACHE_RESID && resid_in_loop && kt == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NCH) : "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -226,9 +238,9 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     Pack8 af0[FM], wf0[FN];
     read_set(af0, wf0, stage, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < nk) {
-      int ns = stage + 2;
-      ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+    if (kt + NSTG - 1 < nk) {
+      int ns = stage + NSTG - 1;
+      ns = ns >= NSTG ? ns - NSTG : ns;
       issue(ns);
     }
     if (resid_in_loop && kt == 1) prefetch_resid();
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     __builtin_amdgcn_sched_barrier(0);
     read_set(afp, wfp, stage, 1);
     mfma_all(wf0, af0);
-    stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
+    stage = stage + 1 >= NSTG ? 0 : stage + 1;
   };
   // Staggered schedule (K-steps 1 .. nk-3: a carried fragment set exists and a stage is still to be fetched, so the body has no conditions).
   // Issuing one LDS-DMA piece stalls the issuing wave for ~60-180 cycles (MI355X_MICROARCH.md, cycle constants) but hardly its SIMD partner; with
@@ -250,7 +262,8 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
 #ifndef G3_STAG_GROUPS
 #define G3_STAG_GROUPS 6
 #endif
-  constexpr int NMF = FM * FN, GROUPS = G3_STAG_GROUPS, PER = NMF / GROUPS;  // 18 MFMAs in 6 groups of 3 (9 groups of 2: -DG3_STAG_GROUPS=9)
+  // 18 MFMAs in 6 groups of 3 (9 groups of 2: -DG3_STAG_GROUPS=9, and always for the 4-wave variant, whose waves issue 9 pieces each)
+  constexpr int NMF = FM * FN, GROUPS = NPIECE > G3_STAG_GROUPS + 1 ? 9 : G3_STAG_GROUPS, PER = NMF / GROUPS;
   static_assert(NMF % GROUPS == 0 && NPIECE <= GROUPS + 1, "piece / MFMA interleave");
   [[maybe_unused]] constexpr int LASTP = NPIECE > GROUPS ? GROUPS - 1 : NPIECE - 1;  // group that carries the last regular piece
   // both halves run the same MFMA stream (one code path: a wave-group branch around the MFMAs makes hipcc shuffle and spill the accumulators);
@@ -277,8 +290,8 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     Pack8 af0[FM], wf0[FN];
     read_set(af0, wf0, stage, 0);
     __builtin_amdgcn_sched_barrier(0);
-    int ns = stage + 2;
-    ns = ns >= G3_STAGES ? ns - G3_STAGES : ns;
+    int ns = stage + NSTG - 1;
+    ns = ns >= NSTG ? ns - NSTG : ns;
 #ifdef G3_STAG_REV
     const bool early = wave >= NWAVES / 2;
 #else
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     mfma_dma(wf0, af0, ns, !early);
     advance_src();
     if (resid_in_loop && kt == 1) prefetch_resid();
-    stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
+    stage = stage + 1 >= NSTG ? 0 : stage + 1;
   };
   // Measured NEGATIVE and removed (round 2): a ping-pong schedule -- every K-step as phase A (both fragment sets -> registers, DMA issue, wait) and
   // phase B (the 36 MFMAs) with a barrier after each, waves 4-7 one barrier behind waves 0-3 so that every SIMD has one wave in A and one in B.
@@ -301,8 +314,8 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
     int kt = 0;
     step_block(kt++);
 #ifndef G3_ONLY_BLOCK
-    if (p.variant != 0)
-      for (; kt + 2 < nk; ++kt) step_stagger(kt);
+    if (p.variant != 0 && NSTG == 3)  // 2-stage ring: a piece issued late in a step has less than a step to land before the next vmcnt(0) (gemm2w.h measured the same)
+      for (; kt + 2 < nk; ++kt) step_stagger(kt);  // (a stage is still to be fetched in each of these steps for either ring depth)
 #endif
     for (; kt < nk; ++kt) step_block(kt);
   }
@@ -386,7 +399,8 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s_kernel(const GemmArgs<T> p)
   // is the operand ring underneath.  When the last K-step reads stage 2 (nk % 3 == 0: every K of the model) the tile lies in stages 0 and 1,
   // which nobody touches after the last step's barrier: no workgroup barrier at all, and a wave that leaves the loop early streams its rows out
   // while the others still multiply (stamped: 1.3-2k cycles of waiting for the slowest wave gone).  Otherwise: one barrier, as before.
-  const bool private_epi = nk >= 2 && (nk - 1) % G3_STAGES == 2 && (BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float)) <= 2 * STAGE_BYTES;
+  const bool private_epi = NSTG == 3 && nk >= 2 && (nk - 1) % NSTG == 2 && (BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float)) <= 2 * STAGE_BYTES;
+  static_assert(BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float) <= NSTG * STAGE_BYTES, "C tile + gate copies inside the ring");
   if (!private_epi) __syncthreads();
 #ifdef G_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

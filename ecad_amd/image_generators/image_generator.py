@@ -125,6 +125,10 @@ class ImageGenerator(ABC):
         if self.diffusion_pipeline is None:
             print("WARNING: No diffusion pipeline to free.")
             return
+        pool = getattr(self.diffusion_pipeline, "_pool", None)
+        if pool is not None:
+            pool.close()  # the extra execution contexts borrow the first engine's weights: they go first
+            self.diffusion_pipeline._pool = None
         engine = getattr(getattr(self.diffusion_pipeline, "transformer", None), "engine", None)
         if engine is not None:
             engine.close()  # device arenas are owned by the native engine, not by torch's allocator

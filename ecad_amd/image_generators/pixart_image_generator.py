@@ -25,11 +25,15 @@ class PixArtImageGenerator(ImageGenerator, ABC):
     MAX_BATCH = 32  # CFG-doubled transformer batch the engine workspaces are sized for
 
     def __init__(self, weights_name: str | None = None, start_seed: int = 0, seed_step: int = 1, schedule_path: Path | None = None,
-                 pipeline_weights: str | None = None, pipeline_name: str | None = None, additional_callbacks=None, max_batch: int | None = None):
+                 pipeline_weights: str | None = None, pipeline_name: str | None = None, additional_callbacks=None, max_batch: int | None = None,
+                 contexts: int = 1):
         if not torch.cuda.is_available():
             # same hard requirement as the reference (:55-56); there is no CPU path for the hot loop
             raise ValueError("CUDA is required for image generation.")
         self.max_batch = max_batch or self.MAX_BATCH
+        # image batches in flight in generate_from_saved_prompts (not in the reference, which runs them back to back): n execution contexts over one set of
+        # weights; 1 = the reference's behaviour.  Per-image results do not change.
+        self.contexts = max(1, int(contexts))
         super().__init__(
             default_transformer_weights=weights_name or self.DEFAULT_WEIGHTS,
             default_pipeline_weights=pipeline_weights or self.PIPELINE_WEIGHTS,
@@ -80,6 +84,7 @@ class PixArtImageGenerator(ImageGenerator, ABC):
         pipeline = self.pipeline_from_pretrained(self.pipeline_weights, transformer=transformer, text_encoder=None, torch_dtype=torch.float16, use_safetensors=True).to(self.device)
         # whole-loop graph replay is only legal when nobody needs intermediate latents
         pipeline.native_loop = len(self.additional_callbacks) == 0
+        pipeline.contexts = self.contexts
         self.diffusion_pipeline = pipeline
 
     def encode_prompts(self, prompts, negative_prompts=None, batch_size=None, **kwargs) -> Sequence[dict]:
@@ -124,6 +129,39 @@ class PixArtImageGenerator(ImageGenerator, ABC):
             for j, image in enumerate(kth):
                 per_prompt[j].append(image)
         return per_prompt
+
+    @torch.inference_mode()
+    def generate_from_saved_prompts(self, input_dir: Path, output_dir: Path, batch_size: int = 1, images_per_prompt: int = 1, free_after: bool = False,
+                                    include_seed_in_name: bool = True, **kwargs) -> None:
+        """The reference's loop (image_generator.py:419-440) -- and, with ``contexts`` > 1, the same (batch, seed) units submitted to the execution contexts in turn
+        so that up to ``contexts`` of them overlap on the device; units finish (decode, save) in submission order, file names and pixels are unchanged."""
+        self._ensure_diffusion_pipeline()
+        pipe = self.diffusion_pipeline
+        if self.contexts <= 1 or not pipe.can_submit(4.5):
+            return super().generate_from_saved_prompts(input_dir, output_dir, batch_size, images_per_prompt, free_after, include_seed_in_name, **kwargs)
+        from collections import deque
+
+        height, width, output_type = kwargs.get("height") or self.height, kwargs.get("width") or self.width, kwargs.get("output_type", "pil")
+        batches = self.load_and_batch_embeddings(input_dir, batch_size, False)
+        pending: deque = deque()
+
+        def finish_one():
+            embeds, k, handle = pending.popleft()
+            for name, rel_path, image in zip(embeds["name"], embeds["relative_path"], pipe.finish(handle)):
+                self.save_image(image, Path(output_dir) / rel_path / self._image_file_stem(name, k, include_seed_in_name))
+
+        for index, embeds in enumerate(batches):
+            print(f"batch {index + 1} / {len(batches)}")
+            for k in range(images_per_prompt):
+                self.random_generator.manual_seed(self.start_seed + k * self.seed_step)
+                kw = self._pipeline_kwargs(embeds, height, width, output_type)
+                pending.append((embeds, k, pipe.submit(**{key: v for key, v in kw.items() if key not in ("prompt", "negative_prompt", "num_images_per_prompt", "return_dict")})))
+                if len(pending) >= self.contexts:
+                    finish_one()
+        while pending:
+            finish_one()
+        if free_after:
+            self.free_diffusion_pipeline()
 
     @torch.inference_mode()
     def generate_images_timed(self, prompt_embeds: dict, output_type: str = "pil", **kwargs) -> float:

@@ -35,6 +35,8 @@ class PixArtAlphaPipeline:
         self.text_encoder = text_encoder
         self.tokenizer = tokenizer
         self.native_loop = True
+        self.contexts = 1  # execution contexts for submit() / finish(): image batches in flight on this GPU (EngineContexts)
+        self._pool = None
         self._device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
     @classmethod
@@ -135,6 +137,58 @@ class PixArtAlphaPipeline:
         else:
             image = self.decode(latents, output_type)
         return (image,) if not return_dict else {"images": image}
+
+    # -- several batches in flight (round 3) ----------------------------------------------------------------------------------------------
+    def can_submit(self, guidance_scale: float = 4.5) -> bool:
+        """submit() / finish() cover what the whole-loop path covers: CFG on, no compute plug-ins, no consumer of intermediate latents."""
+        return bool(self.native_loop and guidance_scale > 1.0 and not getattr(self.transformer, "uses_plugins", False))
+
+    def _contexts(self):
+        from ecad_amd.engine import EngineContexts
+
+        n = max(1, int(self.contexts))
+        if self._pool is None or len(self._pool) != n or self._pool.engines[0] is not self.transformer.engine:
+            if self._pool is not None:
+                self._pool.close()
+            self._pool = EngineContexts(self.transformer.engine, n)
+        return self._pool
+
+    @torch.no_grad()
+    def submit(self, prompt_embeds, prompt_attention_mask, negative_prompt_embeds, negative_prompt_attention_mask, num_inference_steps: int = 20, generator=None,
+               guidance_scale: float = 4.5, height=None, width=None, latents=None, output_type: str = "pil", callback=None, callback_steps: int = 1, **_ignored) -> dict:
+        """The first half of ``__call__`` on the next execution context: stages the batch and launches its whole denoising loop, without waiting.  ``finish``
+        (in submission order) fires the step callbacks and decodes.  With ``contexts`` = n up to n batches overlap on the device; each batch's latents are bit for
+        bit those of ``__call__``."""
+        if not self.can_submit(guidance_scale):
+            raise ValueError("submit() needs the whole-loop path: guidance_scale > 1, no compute plug-ins, native_loop")
+        tr = self.transformer
+        height = height or tr.config.sample_size * self.vae_scale_factor
+        width = width or tr.config.sample_size * self.vae_scale_factor
+        device = tr.device
+        B = prompt_embeds.shape[0]
+        enc = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(device)
+        mask = torch.cat([negative_prompt_attention_mask, prompt_attention_mask], dim=0).to(device)
+        self.scheduler.set_timesteps(num_inference_steps, device=None)
+        timesteps = self.scheduler.timesteps
+        latents = self.prepare_latents(B, tr.config.in_channels, height, width, tr.dtype, device, generator, latents)
+        pool = self._contexts()
+        if getattr(tr, "use_additional_conditions", False):
+            res, ar = torch.tensor([[float(height), float(width)]]).repeat(2 * B, 1), torch.tensor([[float(height / width)]]).repeat(2 * B, 1)
+            for e in pool.engines:
+                e.set_added_cond(res, ar)
+        lat, stream = pool.submit(enc, mask, latents.float(), timesteps.numpy().astype(np.float32), self.scheduler.coefficient_table(), guidance_scale, use_graph=True)
+        tr._begun_key = None
+        return {"latents": lat, "stream": stream, "output_type": output_type, "callback": callback, "callback_steps": callback_steps, "timesteps": timesteps}
+
+    def finish(self, handle: dict):
+        """Second half: wait for that batch only, fire the per-step callbacks in order (the schedule counters end where ``__call__`` leaves them), decode."""
+        torch.cuda.current_stream().wait_stream(handle["stream"])
+        latents = handle["latents"].to(self.transformer.dtype)
+        if handle["callback"] is not None:
+            for i, t in enumerate(handle["timesteps"]):
+                if i % handle["callback_steps"] == 0:
+                    handle["callback"](i, t, latents)
+        return latents if handle["output_type"] == "latent" else self.decode(latents, handle["output_type"])
 
     def decode(self, latents: torch.Tensor, output_type: str = "pil"):
         """VAE decode when a VAE module is attached (stays PyTorch/MIOpen); otherwise a linear latent->RGB preview."""

@@ -88,6 +88,13 @@ int ecad_abi_version(void);
 int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim);
 /* Call once after the last ecad_load_weights: checks completeness, builds fused layouts. */
 int ecad_finalize_weights(EcadEngine* e);
+/* A further execution context on the same GPU (round 3): `e` -- created with the same model configuration and dtype as `donor`, whose weights are
+ * finalized -- drops its own weight arena and reads the donor's from now on; it keeps its own workspaces, cache arena, plans and hipGraph.  Image batches
+ * submitted to different contexts on different HIP streams overlap on the device (one batch's kernel boundaries and HBM-bound kernels hide behind the other's
+ * GEMMs), which is how a caller keeps several batches in flight -- the reference has one pipeline object per process and runs batches back to back
+ * (image_generator.py:161-186, `generate_from_saved_prompts`).  The donor must outlive `e`.  ECAD_E_INVALID for mismatched configurations,
+ * ECAD_E_UNSUPPORTED in fp8 mode (the e4m3 weight copies are per engine). */
+int ecad_share_weights(EcadEngine* e, EcadEngine* donor);
 /* Opt-in OCP fp8 (e4m3) for the block GEMMs (QKV, attention out-projections, cross-attention Q, FF1, FF2): e4m3 weight copies with
  * per-output-channel scales at finalize, activations quantised per row in front of each GEMM (csrc/gemm3s8.h).  Call before
  * ecad_finalize_weights.  Default off (env ECAD_FP8=1 sets the default): the reference computes in fp16, which stays the precision of
@@ -178,7 +185,7 @@ int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const flo
  * call-site class (it only selects the kernel symbol rocprof reports).  ECAD_E_UNSUPPORTED if that kernel cannot run the shape
  * (never a silent substitution).  Bits 8 and up of `kernel`: 0 = the engine's K-loop schedule, 1 + v = force schedule variant v (A/B runs in one process). */
 enum { ECAD_GEMM_K_TILE144 = 0 /* gemm3s.h 256x144 */, ECAD_GEMM_K_PERSISTENT = 1 /* pgemm.h */, ECAD_GEMM_K_WIDE288 = 2 /* gemm2w.h 256x288 */,
-       ECAD_GEMM_K_TILE128 = 3 /* gemm.h 128x128, N % 128 == 0 */ };
+       ECAD_GEMM_K_TILE128 = 3 /* gemm.h 128x128, N % 128 == 0 */, ECAD_GEMM_K_HALF144 = 4 /* gemm3s.h 128x144, four waves, two workgroups per CU */ };
 enum { ECAD_SITE_QKV = 0, ECAD_SITE_OUT1 = 1, ECAD_SITE_Q2 = 2, ECAD_SITE_OUT2 = 3, ECAD_SITE_FF1 = 4, ECAD_SITE_FF2 = 5, ECAD_SITE_TEXTKV = 6,
        ECAD_SITE_CAPTION = 7, ECAD_SITE_SMALL = 8, ECAD_SITE_KV1 = 9 };
 int ecad_op_gemm_ex(EcadEngine* e, int kernel, int call_site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,

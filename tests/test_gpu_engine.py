@@ -452,6 +452,59 @@ def test_sigma_1024_full_size_properties():
     eng.close()
 
 
+def test_execution_contexts_share_weights_and_keep_results_bit_identical():
+    """ecad_share_weights / EngineContexts: further execution contexts read the first engine's weight arena (no copy), keep their own cache arena,
+    plans and hipGraph, and run on their own streams, so several image batches are in flight at once.  Six different batches submitted to three contexts
+    without waiting == the same six batches run one after the other on one engine, bit for bit; a context refuses weight loads, fp8 and mismatched donors."""
+    from ecad_amd.engine import EcadEngine, EngineContexts
+
+    layers, steps, B = 3, 6, 2
+    bits = rand_bits(steps, layers, 0.5, seed=9)
+    eng, w, cfg = make_pair(layers, bits, max_batch=2 * B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    batches = []
+    for k in range(6):
+        inp = synthetic_inputs(B, start_seed=100 + k)
+        enc = (torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]], 0) * (1.0 + 0.1 * k)).cuda()
+        mask = torch.cat([inp["negative_prompt_attention_mask"], inp["prompt_attention_mask"]], 0).cuda()
+        batches.append((enc, mask, inp["latents"].cuda()))
+    alone = [eng.run_schedule(e, m, x, solver.timesteps, coefs, 4.5, use_graph=True).clone() for e, m, x in batches]
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    pool = EngineContexts(eng, 3)
+    assert len(pool) == 3 and pool.engines[1].steps == steps
+    used = free_before - torch.cuda.mem_get_info()[0]
+    weight_bytes = sum(v.numel() for v in w.values()) * 2
+    outs = [pool.submit(e, m, x, solver.timesteps, coefs, 4.5)[0] for e, m, x in batches]  # no wait in between: three batches in flight
+    pool.wait()
+    for a, b in zip(alone, outs):
+        assert torch.equal(a, b)
+    print(f"two extra contexts took {used / 2**20:.0f} MiB of device memory (one copy of the weights alone is {weight_bytes / 2**20:.0f} MiB)")
+    assert pool.engines[1].stats()["graph_captures"] == 1 and pool.engines[2].stats()["graph_captures"] == 1
+    # a new schedule reaches every context
+    bits2 = rand_bits(steps, layers, 0.7, seed=10)
+    pool.set_schedule(bits2)
+    eng2, _, _ = make_pair(layers, bits2, max_batch=2 * B)
+    ref2 = eng2.run_schedule(*batches[0], solver.timesteps, coefs, 4.5)
+    got = [pool.submit(*batches[0], solver.timesteps, coefs, 4.5)[0] for _ in range(3)]
+    pool.wait()
+    assert all(torch.equal(g, ref2) for g in got)
+    ctx = pool.engines[1]
+    with pytest.raises(ValueError, match="borrows its weights"):
+        ctx.load_state_dict(w)
+    with pytest.raises(ValueError, match="borrows"):
+        ctx._chk(ctx.lib.ecad_set_fp8(ctx._h, 1))
+    other = EcadEngine(num_layers=layers + 1, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
+    with pytest.raises(ValueError, match="different model configurations"):
+        other._chk(other.lib.ecad_share_weights(other._h, eng._h))
+    cold = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)  # weights never loaded: not a donor
+    taker = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="not finalized"):
+        taker._chk(taker.lib.ecad_share_weights(taker._h, cold._h))
+    pool.close()
+
+
 def test_fp8_mode_tracks_the_oracle_and_is_reproducible():
     """Opt-in e4m3 block GEMMs (ecad_set_fp8, gemm3s8.h).  Stated tolerance per forward against the fp32 oracle: 1.3e-2 rel-L2 (each fp8
     GEMM carries ~2-4 % e4m3 rounding noise, attenuated by the small adaLN gates of the synthetic weights: measured 6.4e-3, stated 1.3e-2; the fp16 engine sits at 1e-3); hipGraph replay == eager launches bit for bit."""

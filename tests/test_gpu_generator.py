@@ -55,6 +55,24 @@ def test_generator_surface_and_both_loops_agree(embedding_dir, tmp_path, capsys)
     assert len(names) == 8 and names[0] == "000__prompt_id:0__image_seed:007.png" and names[1] == "000__prompt_id:0__image_seed:010.png"
 
 
+def test_generation_with_three_batches_in_flight_writes_the_same_files(embedding_dir, tmp_path):
+    """`contexts=3` (EngineContexts behind pipeline.submit / finish): generate_from_saved_prompts keeps three (batch, seed) units in flight; file names and
+    pixels are those of the one-at-a-time run, the schedule counters end at 0, and freeing the pipeline releases the contexts before the donor engine."""
+    from ecad_amd.image_generators.load_image_generator import get_image_generator_type
+
+    outs = {}
+    for n in (1, 3):
+        gen = get_image_generator_type("PixArtAlphaImageGenerator")(start_seed=7, seed_step=3, schedule_path=FAST, max_batch=4, contexts=n)
+        gen.generate_from_saved_prompts(embedding_dir, tmp_path / f"c{n}", batch_size=2, images_per_prompt=3)
+        assert gen.cache_schedule.curr_step == 0 and gen.dit_scheduler.curr_step == 0
+        if n == 3:
+            assert len(gen.diffusion_pipeline._pool) == 3
+        gen.free_diffusion_pipeline()
+        outs[n] = {p.name: p.read_bytes() for p in sorted((tmp_path / f"c{n}").glob("*.png"))}
+    assert len(outs[1]) == 12 and outs[1].keys() == outs[3].keys()
+    assert all(outs[1][k] == outs[3][k] for k in outs[1])
+
+
 def test_compute_latency_writes_metrics(embedding_dir, tmp_path):
     from ecad_amd.benchmark.compute_latency import time_for_schedule
     from ecad_amd.image_generators.load_image_generator import get_image_generator_type

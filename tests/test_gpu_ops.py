@@ -69,6 +69,11 @@ KERNEL_CASES = [
     ("persistent", "qkv", 0, 600, 3456, 1152),
     ("persistent", "caption", 1, 3840, 1152, 4096),
     ("tile128", "small", 1, 1000, 1024, 512),
+    # gemm3s.h half-tile variant: 128 x 144 tiles, four waves, 2-stage ring, two workgroups per CU (ECAD_GEMM_HALF)
+    ("half144", "attn2_q", 0, 8192, 1152, 1152),
+    ("half144", "attn2_q", 0, 700, 1152, 1152),
+    ("half144", "small", 2, 40, 1152, 256),
+    ("half144", "small", 1, 1000, 576, 64),
 ]
 
 
@@ -108,7 +113,8 @@ def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("kernel,site,K,B,Ntok", [("tile144", "attn1_out", 1152, 32, 256), ("tile144", "attn2_out", 1152, 3, 192), ("tile144", "ff2", 4608, 32, 256),
-                                                 ("persistent", "ff2", 4608, 32, 256), ("persistent", "attn1_out", 1152, 3, 192), ("tile128", "small", 1152, 3, 192)])
+                                                 ("persistent", "ff2", 4608, 32, 256), ("persistent", "attn1_out", 1152, 3, 192), ("tile128", "small", 1152, 3, 192),
+                                                 ("half144", "attn1_out", 1152, 32, 256), ("half144", "attn2_out", 1152, 3, 192), ("half144", "ff2", 4608, 32, 256)])
 def test_gemm_cache_gate_residual_every_kernel(dtype_name, kernel, site, K, B, Ntok):
     """cache <- out; hidden += gate * out with gates of O(1) (cached_transformer_block.py:243-246,317-320,355-360) on every kernel that carries that epilogue, at
     config A's shape (M = 8192: one sample per 256-row tile -> gate via LDS) and with 192 tokens per sample (tiles straddle samples -> per-chunk gate)."""

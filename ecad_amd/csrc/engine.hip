@@ -146,7 +146,8 @@ template <typename T> class EngineT : public EngineBase {
   std::vector<float> cond_host;
   int cond_bt = 0;
   bool cond_uniform = true;
-  float *b_kv2_all, *b_patch, *b_t1, *b_t2, *b_ada, *b_c1, *b_c2, *b_proj, *sst_out, *pos;
+  float *b_kv2_all, *b_patch, *b_t1, *b_t2, *b_ada, *b_c1, *b_c2, *b_proj, *sst_out;
+  float* pos = nullptr;  // sincos table of the current token grid: its own allocation (never part of a shared weight arena)
   bool finalized = false;
   int pos_grid = 0;
   // ---- opt-in fp8 (e4m3) block GEMMs: gemm3s8.h; env ECAD_FP8=1 or ecad_set_fp8
@@ -1658,7 +1659,7 @@ int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights();
 int ecad_share_weights(EcadEngine* e, EcadEngine* donor) {
   ENG(e);
   if (!donor) return E->fail(ECAD_E_INVALID, "NULL donor");
-  return E->share_weights(reinterpret_cast<EngineBase*>(donor));
+  return E->share_weights(donor->impl);
 }
 int ecad_set_fp8(EcadEngine* e, int on) { ENG(e); return E->set_fp8(on); }
 int ecad_set_added_cond(EcadEngine* e, const float* resolution, const float* aspect_ratio, int Bt) { ENG(e); return E->set_added_cond(resolution, aspect_ratio, Bt); }

@@ -6,6 +6,7 @@ libecad_hip.so; torch only owns the I/O tensors and the stream.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Mapping
 
@@ -217,9 +218,12 @@ class EcadEngine:
         def trampoline(_user, step, block, comp, _in, _out, Bt, N, D, _stream):
             try:
                 # The engine filled io_in and will consume io_out on the stream step() was given; everything the plug-in launches (its own torch ops,
-                # block_attn / block_ff / batch_context, the copy into io_out) has to be ordered on THAT stream, not on whatever torch's current one is.
-                # The plug-in sees a fresh tensor, as the reference's do: the next component overwrites io_in.
-                with torch.cuda.stream(torch.cuda.ExternalStream(int(_stream or 0), device=self.device)):  # 0 = the null stream
+                # block_attn / block_ff / batch_context, the copy into io_out) has to be ordered on THAT stream.  Normally it is torch's current stream;
+                # when the caller passed another one, the callback runs with that stream made current.  The plug-in sees a fresh tensor, as the
+                # reference's do: the next component overwrites io_in.
+                handle = int(_stream or 0)
+                same = handle == int(torch.cuda.current_stream(self.device).cuda_stream)
+                with contextlib.nullcontext() if same else torch.cuda.stream(torch.cuda.ExternalStream(handle, device=self.device)):
                     out = callback(step, block, comp, io_in[: Bt * N].view(Bt, N, D).clone())
                     io_out[: Bt * N].copy_(out.reshape(Bt * N, D))
                 return 0

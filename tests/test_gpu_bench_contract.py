@@ -23,13 +23,15 @@ def _bench(*args, env=None):
 
 
 def test_bench_line_contract():
-    d = _bench("--steps", "2", "--warmup", "1", "--secondary", "alpha256_batch1_latency")
+    d = _bench("--steps", "6", "--warmup", "1", "--secondary", "alpha256_batch1_latency")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f16" and d["data"] == "synthetic"
     assert "ours_fast" in d["config"]["workload"] and "batch=16" in d["config"]["workload"] and "model" not in d["config"]
-    assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2 / 1000.0)) / d["value"] < 1e-6  # value == images / timed seconds
+    assert abs(d["value"] - 16 * 6 / (d["ms_per_step"] * 6 / 1000.0)) / d["value"] < 1e-6  # value == images / timed seconds
+    # the headline keeps three image batches in flight (execution contexts over one set of weights) and says so, with the one-at-a-time rate beside it
+    assert d["config"]["batches_in_flight"] == 3 and 0 < d["config"]["one_batch_at_a_time_images_per_s"] <= 1.02 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["achieved"] > 100.0  # the dominant GEMM really ran on the matrix cores

@@ -1,0 +1,223 @@
+// attention_dma.h -- attention128.h with the K / V chunks filled by LDS-DMA into a double-buffered image (round 3).
+//
+// attention128.h stages a 128-key chunk through registers: global loads right after the barrier, ds_write_b128 of the NEXT chunk between two barriers at the top
+// of the following iteration.  By ablation (its header) that store phase -- during which no wave multiplies -- is 16 % of the FLUX launch, the second barrier
+// 3.5 %, and the staging registers (32 VGPRs) are what a software-pipelined unit loop would need.  Here every wave writes its share of the next chunk straight
+// into the OTHER half of a two-image LDS buffer with global_load_lds_dwordx4 (1 KiB per wave instruction, LDS destination = wave-uniform base + lane * 16) while
+// the current image is being multiplied: one barrier per chunk, no register staging, no store phase.
+//   * The images keep attention128.h's padded row strides (d_h 128: K 272 B = 17 pieces, V 288 B = 18 pieces; d_h 72: K 208 B = 13, V 160 B = 10), so the
+//     fragment reads, the MFMA order and therefore the results are bit for bit attention128.h's.  A DMA instruction covers 64 consecutive 16-byte pieces of the
+//     image, pads included: lanes that fall on a pad are switched off (EXEC), so the pads keep what the prologue put there once -- zeros, and 1.0 in the V
+//     column d_h (the ones column that accumulates the softmax denominator).
+//   * Which row and column a lane's piece is depends on the thread and the instruction only: the byte offset from the chunk's first row is computed once per
+//     thread (NI registers) and added to a wave-uniform chunk base.
+//   * Self / joint attention with Nk % 128 == 0 and no chunk across the FLUX [text | image] boundary (true for every model shape); everything else stays on
+//     attention128.h.
+// Measured (scripts/ab_attn_dma.py, one process, interleaved, results bit-identical in every variant; FLUX joint shape B 2 x 24 heads x 128, S 4608 / Sigma-1024
+// self-attention Bt 8 x 16 heads x 72, N 4096 / alpha-512 N 1024 / alpha-256 N 256, microseconds per launch):
+//     attention128.h (register staging, two barriers per chunk)               600-605 / 830-841 / 255-262 / 28.4-29.4
+//     this kernel (LDS-DMA, one barrier per chunk)                             598-600 / 820-830 / 258-265 / 29.5-30.1     <- opt-in: ECAD_ATTN=dma, ECAD_FLUX_ATTN=dma
+//     + fragment reads one batch ahead of their MFMAs (sched_barrier-pinned)   610-612 / 858      / 283-290 / 30.0
+//     + the DMA pieces one per MFMA batch, branch-free (pads reload row data,
+//       the ones piece reloads {1, 0, ...} from a constant block)             699-701 / 911-913 / 301-303 / 28.7          (242 VGPRs, 19 spilled SGPRs)
+//     three-stage software pipeline over 64-key units (PV(u-1) | softmax(u) |
+//       S(u+1) in one basic block, ring of four DMA images, barrier per unit)  661      / 947-965 / 301-308 / 29.5
+//   So the store phase and the second barrier that the ablation of attention128.h priced at 16 % + 3.5 % were not what the launch waits for: removing them buys
+//   0-1.5 %, and no re-ordering of the fragment reads, of the DMA issue or of the three streams that hipcc will compile beats the plain loop.  What does bound it
+//   showed up by accident: with the DMA of every chunk after the first left out (a bug in a variant: stale keys, finite garbage) the same instruction stream
+//   runs in 443 / 619 / 188 / 25.4 us -- 26 % less.  Moving 70 KB (46 KB) of K / V per 128-key chunk into each CU's LDS is what the other 26 % are, although the
+//   rate (~7 B/clk per CU) is a tenth of what the L2 -> LDS path sustains in the GEMMs; DESIGN 5d discusses what is left (K / V staged once for 512 query rows,
+//   which the 72-register accumulators of d_h 72 would allow and those of d_h 128 do not).  EXEC-masked lanes of global_load_lds_dwordx4 do NOT write their 16
+//   bytes of LDS: the pads of the images, written once in the prologue, survive every refill (that is what makes this kernel's results exact).
+#pragma once
+#include "attention128.h"
+#include "common.h"
+
+namespace ecad {
+
+template <int DHC> constexpr int attn_dma_image_bytes() { return A128_KC * (AttCfg<DHC>::KS + AttCfg<DHC>::VS) * 2; }
+template <int DHC> constexpr int attn_dma_lds_bytes() { return 2 * attn_dma_image_bytes<DHC>(); }
+static_assert(attn_dma_lds_bytes<128>() <= 160 * 1024, "two images of the d_h 128 chunk");
+
+template <typename T, int DHC>
+__global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
+  constexpr int KC = A128_KC, KS = AttCfg<DHC>::KS, VS = AttCfg<DHC>::VS, DH = DHC, ND = AttCfg<DHC>::ND, KSTEPS = AttCfg<DHC>::KSTEPS;
+  constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0);
+  constexpr int KPR = KS / 8, VPR = VS / 8;        // 16-byte pieces per image row
+  constexpr int KDATA = DH / 8, VDATA = DH / 8;    // of which carry data
+  constexpr int K_INST = KC * KS * 2 / 1024, V_INST = KC * VS * 2 / 1024;  // 1-KiB DMA instructions per image: 34 + 36 (d_h 128), 26 + 20 (d_h 72)
+  static_assert(KC * KS * 2 % 1024 == 0 && KC * VS * 2 % 1024 == 0, "image regions in whole DMA instructions");
+  constexpr int N_INST = K_INST + V_INST;
+  constexpr int NI = (N_INST + 7) / 8;             // per wave: 9 (d_h 128) / 6 (d_h 72)
+  constexpr int IMG = attn_dma_image_bytes<DHC>();
+  extern __shared__ __attribute__((aligned(16))) char att_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const T* Q = reinterpret_cast<const T*>(p.q);
+  const T* K = reinterpret_cast<const T*>(p.k);
+  const T* V = reinterpret_cast<const T*>(p.v);
+  T* O = reinterpret_cast<T*>(p.out);
+  const int nqb = (p.Nq + ATT_QB - 1) / ATT_QB;
+  const int nkc = p.Nk / KC;
+  const int items = p.B * p.H * nqb;
+
+  // both images: zeros everywhere, 1.0 in column DH of every V row; the DMA never touches a pad
+  for (int i = tid; i < 2 * IMG / 16; i += 512) reinterpret_cast<u32x4*>(att_smem)[i] = (u32x4){0, 0, 0, 0};
+  __syncthreads();
+  for (int i = tid; i < 2 * KC; i += 512) {
+    T* Vs = reinterpret_cast<T*>(att_smem + (i / KC) * IMG) + KC * KS;
+    Vs[(i % KC) * VS + DH] = (T)1.0f;
+  }
+
+  // instruction j of this wave = image instruction wave + 8 j; its lane covers piece 64 * inst + lane of the K region (inst < K_INST) or of the V region
+  unsigned off[NI];
+  bool live[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int inst = wave + 8 * j;
+    const bool isv = inst >= K_INST;
+    const int piece = (isv ? inst - K_INST : inst) * 64 + lane;
+    const int row = piece / (isv ? VPR : KPR), col = piece - row * (isv ? VPR : KPR);
+    live[j] = inst < N_INST && col < (isv ? VDATA : KDATA);
+    off[j] = (unsigned)(((size_t)row * (isv ? p.ldv : p.ldk) + col * 8) * sizeof(T));
+  }
+  auto issue_chunk = [&](int item, int kc, int buf) {
+    const int bh = item / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const size_t row0 = att_row(b, kc * KC, p.Nk, p.seg_t, p.seg_bt);
+    const char* kb = reinterpret_cast<const char*>(K + row0 * p.ldk + (size_t)h * DH);  // wave-uniform
+    const char* vb = reinterpret_cast<const char*>(V + row0 * p.ldv + (size_t)h * DH);
+    char* img = att_smem + buf * IMG;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int inst = wave + 8 * j;
+      if (inst < N_INST) {                                  // wave-uniform
+        const char* src = (inst >= K_INST ? vb : kb) + off[j];
+        if (live[j]) glds16(src, img + inst * 1024);        // pad lanes are off: their 16 bytes of the image keep the prologue's contents
+      }
+    }
+  };
+
+  int item = blockIdx.x;
+  int buf = 0;
+  __syncthreads();  // ones columns in place before anybody reads an image
+  if (item < items) issue_chunk(item, 0, 0);
+  for (; item < items; item += gridDim.x) {
+    const int qb = item % nqb, bh = item / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    f32x4 oacc[2][ND];
+    float m_run[2] = {ATT_NEG, ATT_NEG};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Pack8 qfr[2][KSTEPS];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int qrow = qb * ATT_QB + wave * 32 + r * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        qfr[r][ks].u = (u32x4){0, 0, 0, 0};
+        if (qrow < p.Nq && 32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * DH + 32 * ks + 8 * g);
+      }
+    }
+    for (int kc = 0; kc < nkc; ++kc) {
+      // this wave's pieces of chunk kc have landed (they are the newest DMA it issued); after the barrier everybody's have, and nobody reads the other image
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const T* Ks = reinterpret_cast<const T*>(att_smem + buf * IMG);
+      const T* Vs = Ks + KC * KS;
+      const bool more = kc + 1 < nkc;
+      const int n_item = more ? item : item + (int)gridDim.x, n_kc = more ? kc + 1 : 0;
+      const bool any_next = n_item < items;
+      if (any_next) issue_chunk(n_item, n_kc, buf ^ 1);
+
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        const T* Kh = Ks + half * 64 * KS;
+        const T* Vh = Vs + half * 64 * VS;
+        f32x4 s[2][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          s[0][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          s[1][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            const Pack8 kf = lds_read16(Kh + (16 * f + l15) * KS + 32 * ks + 8 * g);
+            s[0][f] = mfma16<T>(kf, qfr[0][ks], s[0][f]);
+            s[1][f] = mfma16<T>(kf, qfr[1][ks], s[1][f]);
+          }
+        }
+        float m_new[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float mt = ATT_NEG;
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[r][f][e]);
+          mt *= p.scale_log2e;
+          mt = fmaxf(mt, __shfl_xor(mt, 16));
+          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          m_new[r] = fmaxf(m_run[r], mt);
+          if (__builtin_amdgcn_ballot_w64(m_new[r] > m_run[r]) != 0) {  // exact: alpha == 1.0 when no lane's maximum grew (attention128.h)
+            const float alpha = fast_exp2(m_run[r] - m_new[r]);
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) oacc[r][nd][e] *= alpha;
+          }
+          m_run[r] = m_new[r];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Pack8 pf[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float p0 = fast_exp2(__builtin_fmaf(s[r][2 * s2][e], p.scale_log2e, -m_new[r]));
+              const float p1 = fast_exp2(__builtin_fmaf(s[r][2 * s2 + 1][e], p.scale_log2e, -m_new[r]));
+              float_to_elem<T>(pf[r], e, p0);
+              float_to_elem<T>(pf[r], 4 + e, p1);
+            }
+          const int krow = 32 * s2 + 4 * g + (l15 >> 2);
+          const int dcol = 4 * (l15 & 3);
+#pragma unroll
+          for (int nd = 0; nd < ND; ++nd) {
+            const Pack4 lo = lds_read_tr16(Vh + krow * VS + 16 * nd + dcol);
+            const Pack4 hi = lds_read_tr16(Vh + (krow + 16) * VS + 16 * nd + dcol);
+            Pack8 vf;
+            vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
+            oacc[0][nd] = mfma16<T>(vf, pf[0], oacc[0][nd]);
+            oacc[1][nd] = mfma16<T>(vf, pf[1], oacc[1][nd]);
+          }
+        }
+      }
+      buf ^= 1;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      constexpr int DL = DH & 15;
+      const float den = __shfl(oacc[r][DH >> 4][DL & 3], l15 + 16 * (DL >> 2));
+      const float inv = 1.0f / den;
+      const int qrow = qb * ATT_QB + wave * 32 + r * 16 + l15;
+      if (qrow < p.Nq) {
+        T* orow = O + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldo + (size_t)h * DH;
+#pragma unroll
+        for (int nd = 0; nd < NDO; ++nd) {
+          if (16 * nd + 4 * g + 4 <= DH) {
+            Pack4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) float_to_elem4<T>(o, e, oacc[r][nd][e] * inv);
+            *reinterpret_cast<u32x2*>(orow + 16 * nd + 4 * g) = o.u;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace ecad

@@ -22,6 +22,7 @@
 
 #include "attention.h"
 #include "attention128.h"
+#include "attention_dma.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
@@ -288,7 +289,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_LN_COMB")) use_comb = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
-    if (const char* at = getenv("ECAD_ATTN")) attn_shared = strcmp(at, "generic") != 0;
+    if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : 0; }
     if (const char* gh = getenv("ECAD_GEMM_HALF")) {  // A/B switch: 1 = the two attention out-projections, 2 = + FF2, 3 = + cross-attention Q when it runs unfused
       const int lv = atoi(gh);
       if (lv >= 1) gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = 4;
@@ -1119,7 +1120,19 @@ template <typename T> class EngineT : public EngineBase {
   }
   int attn_shared = 1;  // attention128.h structure (both query fragments of a wave share each K / V fragment read); env ECAD_ATTN=generic: attention.h
   bool attn_shared_attr[2] = {};
+  int attn_dma = 0;  // env ECAD_ATTN=dma: attention_dma.h for unmasked attention over whole 128-key chunks (A/B)
+  bool attn_dma_attr[1] = {};
   int launch_attn(const AttnArgs& a, bool masked, hipStream_t s) {
+    if (attn_dma && a.dh == 72 && !masked && a.Nk % 128 == 0 && a.seg_t == 0) {
+      if (!attn_dma_attr[0]) {
+        HIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<72>()));
+        attn_dma_attr[0] = true;
+      }
+      const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
+      const int grid = items < num_cus ? items : num_cus;
+      hipLaunchKernelGGL((attn_dma_kernel<T, 72>), dim3(grid), dim3(512), attn_dma_lds_bytes<72>(), s, a);
+      return ECAD_OK;
+    }
     if (attn_shared && a.dh == 72) {
       const bool tail = masked || a.Nk % 128;
       if (!attn_shared_attr[tail]) {

@@ -29,6 +29,7 @@
 
 #include "attention.h"
 #include "attention128.h"
+#include "attention_dma.h"
 #include "common.h"
 #include "elementwise.h"
 #include "fgemm.h"
@@ -202,6 +203,8 @@ template <typename T> class FluxT : public FluxBase {
   bool f8_engine_attr = false;
   bool fuse_rope = true;      // env ECAD_FLUX_FUSE=0: separate qk_norm_rope pass and separate single-block QKV / proj_mlp GEMMs (A/B)
   bool attn_generic = false;  // env ECAD_FLUX_ATTN=generic: the d_h-templated kernel of attention.h (A/B)
+  int attn_dma = 0;           // env ECAD_FLUX_ATTN=dma: attention_dma.h (K / V chunks by LDS-DMA into a double-buffered image; A/B)
+  bool attn_dma_attr[1] = {};
   const void* call_in = nullptr;
   void* call_out = nullptr;
 
@@ -341,7 +344,7 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     FHIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     if (fp8 && D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
-    if (const char* e = getenv("ECAD_FLUX_ATTN")) attn_generic = strcmp(e, "generic") == 0;
+    if (const char* e = getenv("ECAD_FLUX_ATTN")) { attn_generic = strcmp(e, "generic") == 0; attn_dma = strcmp(e, "dma") == 0 ? 1 : 0; }
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
 
     // ---- weights: a dry layout pass sizes the arena
@@ -939,6 +942,14 @@ template <typename T> class FluxT : public FluxBase {
     constexpr int lds = attn_lds_bytes<128, 128>();
     const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
     const int grid = items < num_cus ? items : num_cus;
+    if (!attn_generic && attn_dma && a.Nk % 128 == 0 && a.seg_t % 128 == 0) {  // attention_dma.h: same arithmetic, chunks by LDS-DMA, one barrier per chunk
+      if (!attn_dma_attr[0]) {
+        FHIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<128>()));
+        attn_dma_attr[0] = true;
+      }
+      hipLaunchKernelGGL((attn_dma_kernel<T, 128>), dim3(grid), dim3(512), attn_dma_lds_bytes<128>(), s, a);
+      return ECAD_OK;
+    }
     if (!attn_generic) {  // attention128.h: both query fragments of a wave share every K / V fragment read
       if (a.Nk % 128) hipLaunchKernelGGL((attn128_kernel<T, true>), dim3(grid), dim3(512), A128_LDS_BYTES, s, a);
       else hipLaunchKernelGGL((attn128_kernel<T, false>), dim3(grid), dim3(512), A128_LDS_BYTES, s, a);

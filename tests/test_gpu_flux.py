@@ -139,6 +139,21 @@ def test_joint_attention_matches_sdpa(op_engine, dtype, tol, T, N):
     assert within(rel_l2(out.float(), want), tol)
 
 
+def test_joint_attention_lds_dma_kernel_is_the_same_arithmetic(monkeypatch, op_engine):
+    """attention_dma.h at d_h 128 (opt-in, ECAD_FLUX_ATTN=dma) on the joint [text | image] layout with whole 128-key chunks on both sides of the boundary
+    (T = 128, N = 384: four chunks, both LDS images used twice): bit-identical to attention128.h."""
+    dtype = torch.bfloat16
+    B, T, N, D = 2, 128, 384, 256
+    qkv = torch.randn(B * (T + N), 3 * D, generator=torch.Generator().manual_seed(11)).to(dtype).cuda()
+    want = op_engine[dtype].op_attention(qkv, B, T, N)
+    monkeypatch.setenv("ECAD_FLUX_ATTN", "dma")
+    eng = make_engine(tiny_cfg(1, 1), dtype, max_n=384)
+    got = eng.op_attention(qkv, B, T, N)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    eng.close()
+
+
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 def test_ln_modulate_two_segments(op_engine, dtype, tol):
     eng = op_engine[dtype]

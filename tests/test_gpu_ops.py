@@ -341,6 +341,29 @@ def test_cross_attention_masked(T):
     assert within(rel_l2(out, ref), ATT_TOL["float16"])
 
 
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("N", [256, 1024])
+def test_self_attention_lds_dma_kernel_is_the_same_arithmetic(monkeypatch, dtype_name, N):
+    """attention_dma.h (opt-in, ECAD_ATTN=dma): K / V chunks by LDS-DMA into a double-buffered image whose pads -- zeros and the ones column -- are written once
+    and never touched again because pad lanes are switched off.  Same fragment layouts and operation order as attention128.h: bit-identical outputs, N = 1024
+    runs eight chunks through both images with a late dominant key tile (running-maximum rescale)."""
+    from ecad_amd.engine import EcadEngine
+
+    dt = getattr(torch, dtype_name)
+    B, H, dh = 3, 16, 72
+    D = H * dh
+    qkv = _r((B * N, 3 * D), dt, 1.0, 5)
+    qkv[N - 40 : N - 32, D : 2 * D] *= 5.0
+    ref_eng = small_engine(dtype_name)
+    want = ref_eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh)
+    monkeypatch.setenv("ECAD_ATTN", "dma")
+    eng = EcadEngine(num_layers=1, max_batch=2, dtype=dt)
+    got = eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh)
+    assert torch.equal(got, want)
+    assert within(rel_l2(got, _attn_ref(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh, None)), ATT_TOL[dtype_name])
+    eng.close()
+
+
 def test_attention_large_scores_online_softmax():
     """Force the running-max rescale branch: one key tile dominates late (guide rule 26)."""
     eng = small_engine("float16")

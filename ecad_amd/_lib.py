@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libecad_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ECAD_DTYPE_F16, ECAD_DTYPE_BF16, ECAD_DTYPE_F32 = 0, 1, 2
 ECAD_E_INVALID, ECAD_E_HIP, ECAD_E_NOT_READY, ECAD_E_UNSUPPORTED = -1, -2, -3, -4
@@ -58,6 +58,8 @@ class EcadStats(C.Structure):
         ("graph_captures", C.c_int32),
         ("dynamic_step_plans", C.c_int32),
         ("plan_sets_cached", C.c_int32),
+        ("ln_folded", C.c_int32),
+        ("fold_preps", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

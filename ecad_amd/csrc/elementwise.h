@@ -465,6 +465,46 @@ __global__ void comb_mod_kernel(const float* __restrict__ sst0, int64_t sst_stri
   }
 }
 
+// LayerNorm folded into the consumer GEMM (gemm.h `ln_stat`): per (step, block, component) of a shared-timestep plan
+//     Wp[n][k] = T(W[n][k] * (1 + scale[k])),   c1[n] = sum_k Wp[n][k] (of the ROUNDED values),   c2[n] = sum_k shift[k] * W[n][k] + bias[n]
+// so that  LN(h)(1 + scale) + shift  times W^T + bias  ==  rstd * (h Wp^T) - rstd * mean * c1 + c2.  One workgroup per output row, fixed-order reduction.
+struct FoldDesc {
+  const void* W;      // [rows][K]
+  const float* bias;  // [rows]
+  const void* shift;  // [K] (comb vectors of the step / block, model dtype)
+  const void* scale;
+  void* Wp;           // [rows][K]
+  float* c1;          // [rows]
+  float* c2;
+  int rows;
+};
+template <typename T> __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const FoldDesc* __restrict__ descs, int K) {
+  const FoldDesc d = descs[blockIdx.y];
+  const int n = blockIdx.x;
+  if (n >= d.rows) return;
+  const T* w = reinterpret_cast<const T*>(d.W) + (size_t)n * K;
+  const T* sh = reinterpret_cast<const T*>(d.shift);
+  const T* sc = reinterpret_cast<const T*>(d.scale);
+  T* wp = reinterpret_cast<T*>(d.Wp) + (size_t)n * K;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float wv = (float)w[k];
+    const T r = (T)(wv * (1.0f + (float)sc[k]));
+    wp[k] = r;
+    s1 += (float)r;
+    s2 = __builtin_fmaf((float)sh[k], wv, s2);
+  }
+  __shared__ float red[2][256];
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { d.c1[n] = red[0][0]; d.c2[n] = red[1][0] + (d.bias ? d.bias[n] : 0.f); }
+}
+
 template <typename T> __global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (T)silu((float)x[i]);
 }

@@ -168,6 +168,20 @@ template <typename T> class EngineT : public EngineBase {
   T *tsin, *temb1, *temb, *temb_silu, *mod_all;
   T* comb = nullptr;  // [max_steps][L][4][D]: LN shift / scale of every (step, block) of a shared-timestep plan (comb_mod_kernel)
   bool comb_live = false;
+  // ---- LayerNorm folded into the consumer GEMMs of a shared-timestep plan (env ECAD_LN_FOLD=0: off)
+  bool ln_fold = true;
+  bool fold_plan_on = false;          // build_plans: this plan set folds (geometry, dtype mode and kernels permit it, arena acquired)
+  float* hstat = nullptr;             // [D / 144][max rows][2]: per-row partial (sum x, sum x^2) of the hidden states, written by the read-modify-write GEMMs
+  struct FoldArena { char* base = nullptr; size_t cap = 0; };
+  std::vector<FoldArena> fold_pool;   // arenas of parked / evicted plan sets, recycled (grow-only): no hipFree (a device-wide sync) on a schedule change
+  FoldArena fold_cur;                 // pre-scaled weights W', c1, c2 of the live plan set
+  std::vector<FoldDesc> fold_descs;   // one per folded (step, block, attn1 | ff); uploaded behind the weights in fold_cur
+  size_t fold_used = 0;
+  bool fold_built = false;            // the arena holds what fold_descs describe, for the timesteps in ts_host
+  size_t fold_prep_ops = 0;           // plan_run[n_begin .. n_begin + fold_prep_ops) = timestep MLP + comb vectors: what the prep needs before the first replay
+  size_t fold_prep_begin = 0;
+  int ln_folded = 0, fold_preps = 0;
+  std::vector<float> fold_ts;         // the timesteps the arena was prepared for
   bool use_comb = true;  // env ECAD_LN_COMB=0: LN reads table + modulation separately (fp32 sum), as the per-step plans do
   float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
   uint8_t* mask_buf;
@@ -198,6 +212,12 @@ template <typename T> class EngineT : public EngineBase {
     float gg = 0.f;
     EcadStats st{};
     bool comb = false;
+    FoldArena fold;                    // the set's pre-scaled weights travel with it (no re-preparation when the GA alternates between schedules)
+    std::vector<FoldDesc> fdescs;
+    std::vector<float> fts;
+    size_t fused = 0, fprep = 0, fbegin = 0;
+    bool fbuilt = false;
+    int folded = 0;
   };
   std::list<PlanStash> plan_lru;
   size_t plan_lru_cap = 4;
@@ -239,6 +259,8 @@ template <typename T> class EngineT : public EngineBase {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
     for (auto& e : plan_lru) free_stash(e);
+    if (fold_cur.base) (void)hipFree(fold_cur.base);
+    for (auto& a : fold_pool) if (a.base) (void)hipFree(a.base);
     if (desc_dyn_dev) (void)hipFree(desc_dyn_dev);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -287,6 +309,7 @@ template <typename T> class EngineT : public EngineBase {
     custom_mask.assign((size_t)cfg.num_layers * 3, 0);
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
     if (const char* l = getenv("ECAD_LN_COMB")) use_comb = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_LN_FOLD")) ln_fold = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : 0; }
@@ -409,6 +432,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t o_ts = take(trows * sizeof(float)), o_coef = take(max_steps * 8 * sizeof(float)), o_mask = take(Mt);
     const size_t o_cond = take(Bm * 3 * sizeof(float)), o_szemb = take(Bm * d * sizeof(T));
     const size_t o_comb = take(max_steps * (size_t)L * 4 * d * sizeof(T));
+    const size_t o_hstat = take((d / 144 + 1) * M * 2 * sizeof(float));
     ws_bytes = off;
     HIPCHK(hipMalloc((void**)&ws, ws_bytes));
     HIPCHK(hipMemset(ws, 0, ws_bytes));
@@ -420,6 +444,7 @@ template <typename T> class EngineT : public EngineBase {
     coef_dev = (float*)(ws + o_coef); mask_buf = (uint8_t*)(ws + o_mask);
     cond_dev = (float*)(ws + o_cond); size_emb = (T*)(ws + o_szemb);
     comb = (T*)(ws + o_comb);
+    hstat = (float*)(ws + o_hstat);
     st.workspace_bytes = (int64_t)ws_bytes;
     st.cache_arena_bytes = (int64_t)((size_t)L * 3 * M * d * sizeof(T));
 
@@ -618,16 +643,40 @@ template <typename T> class EngineT : public EngineBase {
 
   // -------------------------------------------------------------------------------------------
   // plan-set cache
-  static void free_stash(PlanStash& e) {
+  void free_stash(PlanStash& e) {
     if (e.ge) (void)hipGraphExecDestroy(e.ge);
     if (e.g) (void)hipGraphDestroy(e.g);
     if (e.dd) (void)hipFree(e.dd);
-    e.ge = nullptr; e.g = nullptr; e.dd = nullptr;
+    if (e.fold.base) fold_pool.push_back(e.fold);  // recycled by the next build_plans, freed with the engine
+    e.ge = nullptr; e.g = nullptr; e.dd = nullptr; e.fold = FoldArena{};
+  }
+  // an arena of at least `need` bytes: the smallest pooled one that fits, else a new allocation (the largest pooled one goes first, so the pool does not grow)
+  int fold_acquire(size_t need) {
+    int best = -1;
+    for (int i = 0; i < (int)fold_pool.size(); ++i)
+      if (fold_pool[i].cap >= need && (best < 0 || fold_pool[i].cap < fold_pool[best].cap)) best = i;
+    if (best >= 0) { fold_cur = fold_pool[best]; fold_pool.erase(fold_pool.begin() + best); return ECAD_OK; }
+    if (!fold_pool.empty()) {
+      int big = 0;
+      for (int i = 1; i < (int)fold_pool.size(); ++i) if (fold_pool[i].cap > fold_pool[big].cap) big = i;
+      (void)hipFree(fold_pool[big].base);
+      fold_pool.erase(fold_pool.begin() + big);
+    }
+    fold_cur = FoldArena{};
+    const size_t cap = need + (need >> 3);
+    HIPCHK(hipMalloc((void**)&fold_cur.base, cap));
+    fold_cur.cap = cap;
+    return ECAD_OK;
+  }
+  void fold_release_current() {
+    if (fold_cur.base) fold_pool.push_back(fold_cur);
+    fold_cur = FoldArena{};
+    fold_descs.clear(); fold_used = 0; fold_built = false; fold_prep_ops = 0; fold_prep_begin = 0; ln_folded = 0; fold_ts.clear();
   }
   std::string make_key() const {
     std::string k((const char*)bits.data(), bits.size());
     k.append((const char*)custom_mask.data(), custom_mask.size());
-    const int geo[10] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0};
+    const int geo[11] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0, ln_fold ? 1 : 0};
     k.append((const char*)geo, sizeof geo);
     return k;
   }
@@ -640,6 +689,9 @@ template <typename T> class EngineT : public EngineBase {
     e.key = std::move(cur_key);
     e.begin = std::move(plan_begin); e.run = std::move(plan_run); e.step = std::move(plan_step); e.dh = std::move(desc_host);
     e.dd = desc_dev; e.dcap = desc_cap; e.g = graph; e.ge = graph_exec; e.gg = graph_guidance; e.st = st; e.comb = comb_live;
+    e.fold = fold_cur; e.fdescs = std::move(fold_descs); e.fts = std::move(fold_ts); e.fused = fold_used; e.fprep = fold_prep_ops; e.fbegin = fold_prep_begin;
+    e.fbuilt = fold_built; e.folded = ln_folded;
+    fold_cur = FoldArena{}; fold_descs.clear(); fold_ts.clear(); fold_used = 0; fold_built = false; fold_prep_ops = 0; fold_prep_begin = 0; ln_folded = 0;
     desc_dev = nullptr; desc_cap = 0; graph = nullptr; graph_exec = nullptr;
     plan_begin.clear(); plan_run.clear(); plan_step.clear(); desc_host.clear(); cur_key.clear();
     plan_lru.push_front(std::move(e));
@@ -657,6 +709,10 @@ template <typename T> class EngineT : public EngineBase {
       PlanStash& e = *it;
       plan_begin = std::move(e.begin); plan_run = std::move(e.run); plan_step = std::move(e.step); desc_host = std::move(e.dh);
       desc_dev = e.dd; desc_cap = e.dcap; graph = e.g; graph_exec = e.ge; graph_guidance = e.gg; comb_live = e.comb;
+      fold_release_current();
+      fold_cur = e.fold; fold_descs = std::move(e.fdescs); fold_ts = std::move(e.fts); fold_used = e.fused; fold_prep_ops = e.fprep; fold_prep_begin = e.fbegin;
+      fold_built = e.fbuilt; ln_folded = e.folded;
+      e.fold = FoldArena{};
       st = e.st;
       cur_key = key;
       plan_lru.erase(it);
@@ -776,6 +832,20 @@ template <typename T> class EngineT : public EngineBase {
     }
     std::vector<Pending> pend;
     const int ldkv = L * 2 * D;
+    // LayerNorm folded into its consumer GEMMs: only in the shared-timestep plan (one shift / scale vector per (step, block): comb), only where the
+    // LayerNorm launch would carry no pending cache replays (it then only reads h), and only while the row statistics published by the read-modify-write
+    // GEMM that last wrote h are still current (`stats_ok`).
+    const bool fold_plan = fold_plan_on && !bind_call && comb_live;
+    bool stats_ok = false;
+    auto push_rmw = [&](Op<T> o) {
+      if (fold_plan) o.g.stat_out = hstat;
+      push_gemm(ops, o);
+      stats_ok = fold_plan;
+    };
+    auto fold_take = [&](size_t bytes) { char* q = fold_cur.base + fold_used; fold_used += (bytes + 255) & ~(size_t)255; return q; };
+    auto set_fold = [&](Op<T>& o, const float* c1) {
+      o.g.ln_stat = hstat; o.g.ln_c1 = c1; o.g.ln_parts = D / G3_BN; o.g.ln_eps = cfg.norm_eps; o.g.ln_inv_d = 1.0f / (float)D;
+    };
     for (int b = 0; b < L; ++b) {
       const Blk& B = blk[b];
       const uint8_t* ex = ex_rt ? ex_rt + (size_t)b * 3 : &executed[((size_t)s * L + b) * 3];
@@ -789,14 +859,34 @@ template <typename T> class EngineT : public EngineBase {
         emit_custom(b, 0, xn);
         pend.push_back(Pending{io_out, B.sst + 2 * D, mod_s + 2 * D});
       } else if (ex[0]) {
-        emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, true, cb ? cb + 0 * D : nullptr, cb ? cb + 1 * D : nullptr);
-        const double attn1_flops = 4.0 * Bt * (double)NH * N * (double)N * DH;
         // attention in the tail of the Q projection (gemm3s_attn.h): the K,V columns first (wide tiles), then one launch that projects Q for
         // (sample, two heads) and runs their attention on the spot -- no attention launch, no Q round trip through HBM
         const bool fuse1 = fuse_attn && !fp8 && DH == 72 && split_qkv && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0;
+        const bool fold1 = fold_plan && fuse1 && cb && pend.empty() && stats_ok;
+        const T* a_in = xn;
+        const T* w_in = B.w_qkv;
+        const float* b_in = B.b_qkv;
+        const float* c1_in = nullptr;
+        if (fold1) {  // no LayerNorm launch: the projections read h and carry (1 + scale) in their weights, shift in their bias
+          T* wp = (T*)fold_take((size_t)3 * D * D * sizeof(T));
+          float* c1 = (float*)fold_take((size_t)3 * D * sizeof(float));
+          float* c2 = (float*)fold_take((size_t)3 * D * sizeof(float));
+          fold_descs.push_back(FoldDesc{B.w_qkv, B.b_qkv, cb + 0 * D, cb + 1 * D, wp, c1, c2, 3 * D});
+          a_in = h; w_in = wp; b_in = c2; c1_in = c1;
+          ++ln_folded;
+        } else {
+          if (!pend.empty()) stats_ok = false;  // the launch (or the replay flush in front of it) folds pending replays into h
+          emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, true, cb ? cb + 0 * D : nullptr, cb ? cb + 1 * D : nullptr);
+        }
+        const double attn1_flops = 4.0 * Bt * (double)NH * N * (double)N * DH;
         if (fuse1) {
-          push_gemm(ops, mk_gemm(KC_GEMM_KV1, EPI_BIAS, xn, B.w_qkv + (size_t)D * D, B.b_qkv + D, qkv + D, M, 2 * D, D, D, 3 * D), true);
-          Op<T> q = mk_gemm(KC_GEMM_QKV, EPI_BIAS_ATTN, xn, B.w_qkv, B.b_qkv, qkv, M, D, D, D, 3 * D);
+          {
+            Op<T> kv = mk_gemm(KC_GEMM_KV1, EPI_BIAS, a_in, w_in + (size_t)D * D, b_in + D, qkv + D, M, 2 * D, D, D, 3 * D);
+            if (fold1) set_fold(kv, c1_in + D);
+            push_gemm(ops, kv, true);
+          }
+          Op<T> q = mk_gemm(KC_GEMM_QKV, EPI_BIAS_ATTN, a_in, w_in, b_in, qkv, M, D, D, D, 3 * D);
+          if (fold1) set_fold(q, c1_in);
           q.g.att_k = qkv + D; q.g.att_v = qkv + 2 * D; q.g.att_out = attn_o; q.g.att_bias = nullptr; q.g.att_ldk = 3 * D; q.g.att_ldo = D; q.g.att_nk = N;
           q.g.att_scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
           q.flops += attn1_flops; q.bytes += 3.0 * M * (double)D * sizeof(T) - (double)M * D * sizeof(T);  // + K, V, O; the Q tile never leaves the CU
@@ -817,7 +907,7 @@ template <typename T> class EngineT : public EngineBase {
         a.flops = attn1_flops; a.bytes = 4.0 * M * (double)D * sizeof(T);
         ops.push_back(a);
         }
-        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, live(b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
+        push_rmw(mk_gemm_resid(KC_GEMM_OUT1, attn_o, B.w_o1, B.b_o1, live(b, 0) ? c0 : nullptr, M, D, B.sst + 2 * D, mod_s + 2 * D, mstride));
         if (live(b, 0)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 4ll * M * D * D; st.linear_macs_executed += 4ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)N * D;
       } else {
@@ -829,6 +919,7 @@ template <typename T> class EngineT : public EngineBase {
         emit_custom(b, 1, h);
         pend.push_back(Pending{io_out, nullptr, nullptr});
       } else if (ex[1]) {
+        if (!pend.empty()) stats_ok = false;
         emit_replay(ops, pend, M, mstride);
         const double attn2_flops = 4.0 * Bt * (double)NH * N * (double)Tt * DH;
         const bool fuse2 = fuse_attn && !fp8 && DH == 72 && N % G3_BM == 0;
@@ -848,7 +939,7 @@ template <typename T> class EngineT : public EngineBase {
         a.flops = attn2_flops; a.bytes = (2.0 * M + 2.0 * Mt) * D * sizeof(T);
         ops.push_back(a);
         }
-        push_gemm(ops, mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, live(b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
+        push_rmw(mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, live(b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
         if (live(b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
       } else {
@@ -860,9 +951,22 @@ template <typename T> class EngineT : public EngineBase {
         emit_custom(b, 2, xn);
         pend.push_back(Pending{io_out, B.sst + 5 * D, mod_s + 5 * D});
       } else if (ex[2]) {
-        emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride, true, cb ? cb + 2 * D : nullptr, cb ? cb + 3 * D : nullptr);
-        push_gemm(ops, mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D), true);
-        push_gemm(ops, mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, live(b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
+        const bool fold2 = fold_plan && cb && pend.empty() && stats_ok && !fp8 && gemm_impl_cls[KC_GEMM_FF1] == 2 && (4 * D) % G2_BN == 0;
+        if (fold2) {
+          T* wp = (T*)fold_take((size_t)4 * D * D * sizeof(T));
+          float* fc1 = (float*)fold_take((size_t)4 * D * sizeof(float));
+          float* fc2 = (float*)fold_take((size_t)4 * D * sizeof(float));
+          fold_descs.push_back(FoldDesc{B.w_ff1, B.b_ff1, cb + 2 * D, cb + 3 * D, wp, fc1, fc2, 4 * D});
+          Op<T> f1 = mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, h, wp, fc2, ffmid, M, 4 * D, D, D, 4 * D);
+          set_fold(f1, fc1);
+          push_gemm(ops, f1, true);
+          ++ln_folded;
+        } else {
+          if (!pend.empty()) stats_ok = false;
+          emit_ln(ops, pend, M, B.sst + 3 * D, B.sst + 4 * D, mod_s + 3 * D, mod_s + 4 * D, mstride, mstride, true, cb ? cb + 2 * D : nullptr, cb ? cb + 3 * D : nullptr);
+          push_gemm(ops, mk_gemm(KC_GEMM_FF1, EPI_BIAS_GELU, xn, B.w_ff1, B.b_ff1, ffmid, M, 4 * D, D, D, 4 * D), true);
+        }
+        push_rmw(mk_gemm_resid(KC_GEMM_FF2, ffmid, B.w_ff2, B.b_ff2, live(b, 2) ? c2 : nullptr, M, 4 * D, B.sst + 5 * D, mod_s + 5 * D, mstride));
         if (live(b, 2)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 8ll * M * D * D; st.linear_macs_executed += 8ll * M * D * D;
       } else {
@@ -938,9 +1042,24 @@ template <typename T> class EngineT : public EngineBase {
     // --- run plan: shared timestep per step, tables for all steps computed up front
     EcadStats keep = st;
     plan_run = plan_begin;
+    fold_release_current();
+    fold_prep_begin = plan_run.size();
     emit_temb(plan_run, ts_dev, steps, 0, false);
     comb_live = use_comb && ln16 && D == 1152 && (L < 2 || blk[1].sst - blk[0].sst == (blk[L - 1].sst - blk[0].sst) / (L - 1));
     if (comb_live) { Op<T> c; c.kind = Op<T>::COMB; c.cls = KC_MISC; plan_run.push_back(c); }
+    fold_prep_ops = plan_run.size() - fold_prep_begin;
+    // LayerNorm folded into the consumer GEMMs: needs the per-(step, block) comb vectors, fp16 / bf16 GEMMs, 144-column tiles for the statistics,
+    // and a timestep embedding that depends on the timestep only (the 1024-MS micro-conditioning adds per-batch terms)
+    fold_plan_on = ln_fold && comb_live && !fp8 && !cfg.use_additional_conditions && D == LN_PARTS * G3_BN && gemm_impl_cls[KC_GEMM_OUT1] == 0 &&
+                   gemm_impl_cls[KC_GEMM_OUT2] == 0 && gemm_impl_cls[KC_GEMM_FF2] == 0 && gemm_impl_cls[KC_GEMM_KV1] == 2 && gemm_impl_cls[KC_GEMM_QKV] == 0 && !tile128_mode;
+    if (fold_plan_on) {
+      size_t n1 = 0, n2 = 0;
+      for (int s_ = 0; s_ < steps; ++s_)
+        for (int b_ = 0; b_ < L; ++b_) { n1 += executed[((size_t)s_ * L + b_) * 3 + 0]; n2 += executed[((size_t)s_ * L + b_) * 3 + 2]; }
+      const size_t need = n1 * ((size_t)3 * D * D * sizeof(T) + 2 * (((size_t)3 * D * 4 + 255) & ~(size_t)255) + 256) +
+                          n2 * ((size_t)4 * D * D * sizeof(T) + 2 * (((size_t)4 * D * 4 + 255) & ~(size_t)255) + 256) + (n1 + n2 + 1) * sizeof(FoldDesc) + 4096;
+      if (int rc = fold_acquire(need)) return rc;
+    }
     { Op<T> d; d.kind = Op<T>::DUP; d.cls = KC_MISC; plan_run.push_back(d); }
     for (int s = 0; s < steps; ++s) {
       emit_transformer(plan_run, s, mod_all + (size_t)s * 6 * D, 0, temb + (size_t)s * D, 0, false);
@@ -948,6 +1067,14 @@ template <typename T> class EngineT : public EngineBase {
       plan_run.push_back(o);
     }
     st.launches_per_batch = (int)plan_run.size();
+    if (fold_plan_on) {
+      if (fold_descs.empty()) { fold_pool.push_back(fold_cur); fold_cur = FoldArena{}; }
+      else {  // the descriptors of the preparation kernel live behind the weights they describe
+        char* dd = fold_cur.base + fold_used;
+        if (fold_used + fold_descs.size() * sizeof(FoldDesc) > fold_cur.cap) return fail(ECAD_E_HIP, "fold arena too small");
+        HIPCHK(hipMemcpy(dd, fold_descs.data(), fold_descs.size() * sizeof(FoldDesc), hipMemcpyHostToDevice));
+      }
+    }
     // temb macs: steps rows
     st.linear_macs_executed += (int64_t)steps * (256ll * D + 7ll * D * D);
     EcadStats run_stats = st;
@@ -1395,6 +1522,21 @@ template <typename T> class EngineT : public EngineBase {
     }
     rc = stage_inputs(enc, mask, s);
     if (rc) return rc;
+    if (!fold_descs.empty() && (!fold_built || fold_ts != tsv)) {
+      // once per (plan set, timestep grid): the adaLN tables and comb vectors of all steps (the same ops the graph replays every batch), then
+      // W' = W (.) (1 + scale), c1, c2 for every folded (step, block, component) in one launch
+      std::vector<Op<T>> prep(plan_run.begin() + fold_prep_begin, plan_run.begin() + fold_prep_begin + fold_prep_ops);
+      rc = run_ops(prep, s, 0.f, false);
+      if (rc) return rc;
+      int max_rows = 0;
+      for (auto& d : fold_descs) max_rows = d.rows > max_rows ? d.rows : max_rows;
+      hipLaunchKernelGGL((ln_fold_weights_kernel<T>), dim3(max_rows, (unsigned)fold_descs.size()), dim3(256), 0, s,
+                         reinterpret_cast<const FoldDesc*>(fold_cur.base + fold_used), D);
+      HIPCHK(hipGetLastError());
+      fold_built = true;
+      fold_ts = tsv;
+      ++fold_preps;
+    }
     const size_t nlat = (size_t)(Bt / 2) * CIN * Hl * Wl;
     HIPCHK(hipMemcpyAsync(lat_buf, latents, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (use_graph && !profiling) {
@@ -1488,6 +1630,7 @@ template <typename T> class EngineT : public EngineBase {
   int stats(EcadStats* s) override {
     *s = st;
     s->plan_builds = plan_builds; s->graph_captures = graph_captures; s->dynamic_step_plans = dynamic_steps; s->plan_sets_cached = (int32_t)plan_lru.size();
+    s->ln_folded = ln_folded; s->fold_preps = fold_preps;
     return ECAD_OK;
   }
   int set_profiling(int on) override {

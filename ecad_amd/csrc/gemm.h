@@ -42,6 +42,16 @@ template <typename T> struct GemmArgs {
   const float* att_bias;
   int att_ldk, att_ldo, att_nk;
   float att_scale_log2e;
+  // LayerNorm folded into this GEMM (round 3; shared-timestep plans only).  A = the raw hidden states h, W = W (.) (1 + scale) rounded to T,
+  // bias = c2 = shift . W^T + b, and the epilogue computes  rstd_m * acc - rstd_m * mean_m * c1[n] + c2[n]  with c1[n] = sum_k W'[n][k]:
+  // ln_stat = per-row partial sums (sum x, sum x^2) over the ln_parts column tiles of h, [ln_parts][M][2] floats, written by the read-modify-write
+  // epilogue that produced h (stat_out below); summed here in fixed order.  null: plain GEMM.
+  const float* ln_stat;
+  const float* ln_c1;
+  int ln_parts;
+  float ln_eps, ln_inv_d;
+  // read-modify-write epilogue (gemm3s.h): also publish (sum x, sum x^2) of the tile's 144 columns of the UPDATED hidden states, [N / 144][M][2] floats
+  float* stat_out;
   int variant;  // K-loop schedule of gemm3s.h / gemm2w.h: 0 = every wave issues its LDS-DMA pieces in one block after the barrier (round 1),
                 // 1 = staggered: pieces interleaved one per MFMA group, waves 0-3 in the first half of the step, waves 4-7 in the second
 };

@@ -11,6 +11,7 @@
 #pragma once
 #include "common.h"
 #include "gemm.h"
+#include "gemm3s.h"  // ln_row_coeffs
 
 namespace ecad {
 
@@ -302,6 +303,19 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   for (int j = 0; j < FN; ++j) {
     bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 144 + 16 * j + 4 * g);
+  }
+  // LayerNorm folded into this GEMM (gemm.h): acc <- rstd_m * acc - rstd_m * mean_m * c1[n]; the bias vectors above already hold c2
+  if (p.ln_stat) {
+    float ra[FM], rb[FM];
+    ln_row_coeffs<FM>(p, m0 + wm * 64 + l15, ra, rb);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n0 + wn * 144 + 16 * j + 4 * g);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(acc[i][j][r], ra[i], rb[i] * c1[r]);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();

@@ -15,6 +15,31 @@ constexpr int G3_STAGE_BYTES = (G3_BM + G3_BN) * 128;
 constexpr int G3_LDS_BYTES = G3_STAGES * G3_STAGE_BYTES;
 static_assert(G3A_LDS_BYTES <= G3_LDS_BYTES, "the fused attention tail (Q tile + K/V staging + bias strip) must fit the operand ring: launch_g3_attn requests G3_LDS_BYTES only");
 
+// LayerNorm folded into a consumer GEMM (gemm.h): rstd and -rstd * mean of rows row0, row0 + 16, ... from the per-tile partial sums, summed in tile order
+constexpr int LN_PARTS = 8;  // D = 1152 = 8 column tiles of 144 (the engine folds only then)
+template <int NR, typename T>
+ECAD_DEV void ln_row_coeffs(const GemmArgs<T>& p, int row0, float (&ra)[NR], float (&rb)[NR]) {
+  f32x2 v[NR][LN_PARTS];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    int m = row0 + 16 * i;
+    m = m < p.M ? m : p.M - 1;
+#pragma unroll
+    for (int t = 0; t < LN_PARTS; ++t) v[i][t] = *reinterpret_cast<const f32x2*>(p.ln_stat + ((size_t)t * p.M + m) * 2);  // all loads in one batch
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    float sx = 0.f, sxx = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_PARTS; ++t) { sx += v[i][t][0]; sxx += v[i][t][1]; }  // tile order: the same sum on every launch
+    const float mean = sx * p.ln_inv_d;
+    const float var = __builtin_fmaf(-mean, mean, sxx * p.ln_inv_d);
+    const float rstd = rsqrtf(fmaxf(var, 0.f) + p.ln_eps);
+    ra[i] = rstd;
+    rb[i] = -rstd * mean;
+  }
+}
+
 // Half-tile variant (round 3, measured in DESIGN 5c): BM_ = 128, NW_ = 4, STAGES_ = 2 -- 128 x 144 tiles, four waves of 32 x 144 (the same wave tile, fragment
 // layout and epilogue), a 2-stage ring of 34 816-byte stages = 69 632 bytes, so that TWO workgroups are resident per CU (and two waves per SIMD come from different
 // workgroups, behind different barriers).  Plain and read-modify-write epilogues only (the fused attention tail needs 86 KB).
@@ -392,7 +417,21 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   if (!bias_in_loop) load_bias();
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (EPI == EPI_BIAS_ATTN || EPI == EPI_BIAS_ATTN_TAIL) {  // the tile is a query projection: its attention runs here (gemm3s_attn.h)
-    g3_attention_epilogue<T, EPI == EPI_BIAS_ATTN_TAIL>(p, smem, m0, tn, acc, bvs);
+    if constexpr (BM == G3_BM) {
+      if (p.ln_stat) {  // LayerNorm folded into this projection: acc <- rstd * acc - rstd * mean * c1; the bias vectors already hold c2 (gemm.h)
+        float ra[FM], rb[FM];
+        ln_row_coeffs<FM>(p, m0 + wave * WTM + l15, ra, rb);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n0 + 16 * j + 4 * g);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(acc[i][j][r], ra[i], rb[i] * c1[r]);
+        }
+      }
+      g3_attention_epilogue<T, EPI == EPI_BIAS_ATTN_TAIL>(p, smem, m0, tn, acc, bvs);
+    }
     return;
   }
   // The C tile (and the per-wave gate copies behind it) is staged in LDS rows that only their own wave writes and reads, so the only hazard
@@ -483,12 +522,38 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] += o[e];
       }
-      gstore16(rp, pack8<T>(h));
+      const Pack8 hn = pack8<T>(h);
+      gstore16(rp, hn);
+      if (p.stat_out) *reinterpret_cast<u32x4*>(ctile + ml * CS + cchunk * 8) = hn.u;  // the wave's own rows of the C tile now hold the updated hidden states
     } else {
 #ifdef G_ABL_NOSTORE
       if (v.u[0] == 0x12345678u)  // ablation build (wrong results): the epilogue without its global stores
 #endif
       gstore16(p.C + (size_t)m * p.ldc + n, v);
+    }
+  }
+  if constexpr (EPI == EPI_BIAS_CACHE_RESID) {
+    if (p.stat_out) {
+      // row statistics for a LayerNorm folded into the NEXT GEMM (gemm.h): lane l sums row (l & 31), chunks [9 (l >> 5), 9 (l >> 5) + 9) of the wave's 32 rows in
+      // fixed order, the two halves meet through one shuffle: deterministic, and no atomics anywhere.  Values are the ROUNDED hidden states, i.e. exactly what
+      // the LayerNorm kernel would read back from memory.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int rl = lane & 31, hh = lane >> 5;
+      float sx = 0.f, sxx = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPR / 2; ++c) {
+        float x[8];
+        unpack8<T>(lds_read16(ctile + (wave * WTM + rl) * CS + (hh * (CPR / 2) + c) * 8), x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sx += x[e]; sxx = __builtin_fmaf(x[e], x[e], sxx); }
+      }
+      const float ox = __shfl_xor(sx, 32), oxx = __shfl_xor(sxx, 32);
+      const int m = m0 + wave * WTM + rl;
+      if (hh == 0 && m < p.M) {
+        float* dst = p.stat_out + ((size_t)tn * p.M + m) * 2;
+        dst[0] = sx + ox;    // lower half + upper half: the same order on every launch
+        dst[1] = sxx + oxx;
+      }
     }
   }
 #ifdef G_STAMP

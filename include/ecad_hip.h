@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ECAD_ABI_VERSION 2
+#define ECAD_ABI_VERSION 3
 
 enum {
   ECAD_OK = 0,
@@ -69,6 +69,8 @@ typedef struct EcadStats {
   int32_t graph_captures;        /* hipGraph captures + instantiations since ecad_create */
   int32_t dynamic_step_plans;    /* ecad_step calls that ran an ad-hoc plan because the usable caches differed from the static resolution (reset_cache mid-run) */
   int32_t plan_sets_cached;      /* plan sets (with their graphs) parked in the LRU right now */
+  int32_t ln_folded;             /* LayerNorm + modulate launches of the whole-loop plan folded into their consumer GEMMs */
+  int32_t fold_preps;            /* times the pre-scaled weights of a plan set were (re)built: once per (schedule, timestep grid) */
 } EcadStats;
 
 typedef struct EcadEngine EcadEngine;

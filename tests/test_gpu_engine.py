@@ -292,6 +292,7 @@ def test_attention_fused_into_the_query_projection_is_the_same_arithmetic(monkey
     solver = DPMSolverPP2M(steps)
     coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
     outs = {}
+    monkeypatch.setenv("ECAD_LN_FOLD", "0")  # the LayerNorm fold exists for the fused launches only: this test isolates the attention fusion
     for fuse in ("1", "0"):
         monkeypatch.setenv("ECAD_FUSE_ATTN", fuse)
         eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=(side // 2) ** 2, max_text_tokens=120, dtype=dtype)
@@ -450,6 +451,55 @@ def test_sigma_1024_full_size_properties():
     one = eng.run_schedule(enc[sel].cuda(), mask[sel].cuda(), lat[idx: idx + 1].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
     assert torch.equal(one, a[idx: idx + 1])
     eng.close()
+
+
+def test_layernorm_folded_into_the_consumer_gemms(monkeypatch):
+    """in the whole-loop plan a LayerNorm + modulate launch that carries no pending cache replays is not launched at all -- its consumers (K,V and
+    Q + attention, or FF1) read the hidden states, carry (1 + scale) in per-(step, block) weight copies and shift in their bias, and apply rstd / mean from the
+    row statistics the producing read-modify-write GEMM published.  Against the engine with the fold switched off: fewer launches, the same latents up to the
+    rounding that moved (and both are held to the oracle by the run-parity tests, which use the default = folded engine); prepared once per (schedule, timestep
+    grid); deterministic; batch rows independent."""
+    from ecad_amd.engine import EcadEngine
+
+    layers, steps, B = 4, 6, 2
+    bits = rand_bits(steps, layers, 0.7, seed=21)
+    bits[0] = True
+    cfg = PixArtConfig(num_layers=layers)
+    w = unit_gate_weights(cfg, seed=8)  # gates of O(1): a wrong LayerNorm input reaches the output at full size
+    inp, enc, mask = cfg_inputs(B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    outs, stats = {}, {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("ECAD_LN_FOLD", fold)
+        eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
+        eng.load_state_dict(w)
+        eng.set_schedule(bits)
+        a = eng.run_schedule(*args, use_graph=True)
+        b = eng.run_schedule(*args, use_graph=True)
+        c = eng.run_schedule(*args, use_graph=False)
+        assert torch.equal(a, b) and torch.equal(a, c)
+        outs[fold], stats[fold] = a.clone(), eng.stats()
+        if fold == "1":
+            assert stats[fold]["fold_preps"] == 1
+            other_ts = (np.asarray(solver.timesteps, dtype=np.float32) * 0.5).copy()
+            d = eng.run_schedule(enc.cuda(), mask.cuda(), inp["latents"].cuda(), other_ts, coefs, 4.5, use_graph=True)  # new timestep grid: W' rebuilt
+            assert eng.stats()["fold_preps"] == 2 and torch.isfinite(d).all()
+            e = eng.run_schedule(*args, use_graph=True)
+            assert eng.stats()["fold_preps"] == 3 and torch.equal(e, a)
+            one = eng.run_schedule(enc[[1, B + 1]].cuda(), mask[[1, B + 1]].cuda(), inp["latents"][1:2].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
+            assert torch.equal(one, a[1:2])
+        eng.close()
+    assert stats["1"]["ln_folded"] > 0 and stats["0"]["ln_folded"] == 0
+    assert stats["1"]["launches_per_batch"] == stats["0"]["launches_per_batch"] - stats["1"]["ln_folded"]
+    rel = rel_l2(outs["1"], outs["0"])
+    print(f"LayerNorm folded vs launched: final-latent rel-L2 {rel:.3e}, {stats['1']['ln_folded']} launches folded of {stats['0']['launches_per_batch']}")
+    assert within(rel, 3e-3)
+    ref = denoise(PixArtOracle(cfg, w), bits, {k: (v.half().float() if v.is_floating_point() else v) for k, v in inp.items()})
+    err = rel_l2(outs["1"], ref)
+    print(f"folded engine vs oracle (unit gates, {layers} blocks, {steps} steps): rel-L2 {err:.3e}")
+    assert within(err, 8e-3)
 
 
 def test_execution_contexts_share_weights_and_keep_results_bit_identical():

@@ -19,7 +19,8 @@ constexpr int G2_BM = 256, G2_BN = 288, G2_NW = 8;
 constexpr int G2_A_BYTES = G2_BM * 128;
 constexpr int G2_STAGE_BYTES = (G2_BM + G2_BN) * 128;  // 69632
 constexpr int G2_CS = G2_BN + 8;
-constexpr int G2_LDS_BYTES = (2 * G2_STAGE_BYTES) > (G2_BM * G2_CS * 2) ? (2 * G2_STAGE_BYTES) : (G2_BM * G2_CS * 2);  // 151552
+constexpr int G2_TILE_BYTES = (2 * G2_STAGE_BYTES) > (G2_BM * G2_CS * 2) ? (2 * G2_STAGE_BYTES) : (G2_BM * G2_CS * 2);  // 151552: operand ring / C tile
+constexpr int G2_LDS_BYTES = G2_TILE_BYTES + G2_BM * 8;  // + (rstd, -rstd * mean) of the tile's 256 rows for a folded LayerNorm (gemm.h): 153600
 
 template <typename T, int EPI, int TAG>
 __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p) {
@@ -306,8 +307,23 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   }
   // LayerNorm folded into this GEMM (gemm.h): acc <- rstd_m * acc - rstd_m * mean_m * c1[n]; the bias vectors above already hold c2
   if (p.ln_stat) {
+    // one thread per row sums the row's LN_PARTS partial statistics (16 live registers, one L2 round trip for the workgroup) and leaves (rstd, -rstd * mean)
+    // behind the tile in LDS; taking them per lane (FM rows x LN_PARTS loads = 64 registers next to 144 accumulators + 72 of bias / c1) spilled
+    f32x2* rowab = reinterpret_cast<f32x2*>(smem + G2_TILE_BYTES);
+    if (tid < G2_BM) {
+      float ca[1], cb[1];
+      ln_row_coeffs<1>(p, m0 + tid, ca, cb);
+      rowab[tid] = (f32x2){ca[0], cb[0]};
+    }
+    __syncthreads();
+    // (touching the statistics and the c1 / c2 lines at kernel start, so that these reads hit L2, was measured: no change)
     float ra[FM], rb[FM];
-    ln_row_coeffs<FM>(p, m0 + wm * 64 + l15, ra, rb);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const f32x2 ab = rowab[wm * 64 + 16 * i + l15];
+      ra[i] = ab[0];
+      rb[i] = ab[1];
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n0 + wn * 144 + 16 * j + 4 * g);

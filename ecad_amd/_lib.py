@@ -60,6 +60,7 @@ class EcadStats(C.Structure):
         ("plan_sets_cached", C.c_int32),
         ("ln_folded", C.c_int32),
         ("fold_preps", C.c_int32),
+        ("fold_bytes", C.c_int64),
     ]
 
     def as_dict(self) -> dict:

@@ -1630,7 +1630,7 @@ template <typename T> class EngineT : public EngineBase {
   int stats(EcadStats* s) override {
     *s = st;
     s->plan_builds = plan_builds; s->graph_captures = graph_captures; s->dynamic_step_plans = dynamic_steps; s->plan_sets_cached = (int32_t)plan_lru.size();
-    s->ln_folded = ln_folded; s->fold_preps = fold_preps;
+    s->ln_folded = ln_folded; s->fold_preps = fold_preps; s->fold_bytes = (int64_t)fold_used;
     return ECAD_OK;
   }
   int set_profiling(int on) override {

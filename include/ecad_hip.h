@@ -71,6 +71,7 @@ typedef struct EcadStats {
   int32_t plan_sets_cached;      /* plan sets (with their graphs) parked in the LRU right now */
   int32_t ln_folded;             /* LayerNorm + modulate launches of the whole-loop plan folded into their consumer GEMMs */
   int32_t fold_preps;            /* times the pre-scaled weights of a plan set were (re)built: once per (schedule, timestep grid) */
+  int64_t fold_bytes;            /* bytes of pre-scaled weights + c1 / c2 vectors the live plan set uses */
 } EcadStats;
 
 typedef struct EcadEngine EcadEngine;

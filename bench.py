@@ -34,7 +34,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 # Several image batches in flight (--streams) need their HIP streams on different hardware queues; the runtime's default of 4 queues, dealt round-robin to
 # every stream the process creates (torch's, the engines' capture streams), put both streams of a 2-context run on ONE queue in two runs out of two.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 SCHEDULE = ROOT / "schedules/schedules_in_paper/pixart_alpha_256/ours_fast.json"
 SIGMA1024_SCHEDULE = ROOT / "schedules/sigma_cache_schedules/transfer_256_to_1024/ours_fast_256_to_1024.json"

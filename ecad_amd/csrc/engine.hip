@@ -313,6 +313,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : 0; }
+    if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
     if (const char* gh = getenv("ECAD_GEMM_HALF")) {  // A/B switch: 1 = the two attention out-projections, 2 = + FF2, 3 = + cross-attention Q when it runs unfused
       const int lv = atoi(gh);
       if (lv >= 1) gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = 4;
@@ -1150,7 +1151,23 @@ template <typename T> class EngineT : public EngineBase {
   int gemm_variant = 1;  // K-loop schedule (GemmArgs::variant); env ECAD_GEMM_SCHED=0: the round-1 schedule
   bool g2_attr[4][KC_COUNT] = {};
   bool split_qkv = true;  // env ECAD_SPLIT_QKV=0 keeps the single 3D-wide launch
+  // Few rows (batch 1-4): a launch whose 256-row tiles cover less than half the chip is a latency chain (18-72 K-steps of ~0.8 us whatever the tile count);
+  // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
+  // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections keep their 256-row tile (one sample x two heads).
+  bool latency_tiles = true;
+  bool g3q_attr[4][KC_COUNT] = {};
+  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * 2 <= num_cus; }
+  template <int EPI, int TAG> int launch_quarter(const GemmArgs<T>& g, hipStream_t s) {
+    if (!g3q_attr[EPI][TAG]) {
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
+      g3q_attr[EPI][TAG] = true;
+    }
+    const int tq = ((g.M + G3Q_BM - 1) / G3Q_BM) * (g.N / G3_BN);
+    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3(tq), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
+    return ECAD_OK;
+  }
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
+    if (gemm_impl_cls[TAG] == 5 || (few_rows(g) && gemm_impl_cls[TAG] != 4 && gemm_impl_cls[TAG] != 1)) return launch_quarter<EPI, TAG>(g, s);
     if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
       if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0) {  // wide 256x288 tiles
         if (!g2_attr[EPI][TAG]) {
@@ -1708,8 +1725,8 @@ template <typename T> class EngineT : public EngineBase {
       HIPCHK(hipGetLastError());
       return ECAD_OK;
     }
-    if (kernel == 4 && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the half-tile kernel has no attention tail");
-    if ((kernel < 0 || kernel > 2) && kernel != 4) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
+    if ((kernel == 4 || kernel == 5) && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the half / latency tiles have no attention tail");
+    if ((kernel < 0 || kernel > 2) && kernel != 4 && kernel != 5) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
     if (Nn % PG_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
     if (kernel == 2) {
       if (Nn % G2_BN) return fail(ECAD_E_UNSUPPORTED, "gemm2w tiles need N %% 288 == 0, got %d", Nn);
@@ -1717,9 +1734,12 @@ template <typename T> class EngineT : public EngineBase {
         return fail(ECAD_E_UNSUPPORTED, "gemm2w is instantiated for the FF1 / text-KV / attn1-KV / small call sites only");
     }
     const int keep = gemm_impl_cls[site];
+    const bool keep_lat = latency_tiles;
     gemm_impl_cls[site] = kernel;
+    latency_tiles = false;  // the caller named the kernel: no few-rows substitution (kernel 5 IS the latency tile)
     const int rc = launch_gemm(epi, site, g, s);
     gemm_impl_cls[site] = keep;
+    latency_tiles = keep_lat;
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return ECAD_OK;

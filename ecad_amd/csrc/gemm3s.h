@@ -46,19 +46,26 @@ ECAD_DEV void ln_row_coeffs(const GemmArgs<T>& p, int row0, float (&ra)[NR], flo
 constexpr int G3H_BM = 128, G3H_NW = 4, G3H_STAGES = 2;
 constexpr int G3H_LDS_BYTES = G3H_STAGES * (G3H_BM + G3_BN) * 128;
 static_assert(2 * G3H_LDS_BYTES <= 160 * 1024, "two half-tile workgroups per CU");
+// Latency variant for FEW rows (round 3): BM_ = 64, NW_ = 4, STAGES_ = 3 -- 64 x 144 tiles, four waves of 16 x 144.  A K-step of the 256-row tile is
+// ~0.8 us of MFMA work per CU however few tiles the launch has, so at batch 1-4 (M = 512-2048: 16-64 tiles on 256 CUs) every K = 1152 GEMM is an 18-step, ~20 us
+// latency chain; here a wave has 18 MFMAs per K-step instead of 36 per wave pair and SIMD, four times as many workgroups share the rows, and two fit a CU.
+constexpr int G3Q_BM = 64, G3Q_NW = 4, G3Q_STAGES = 3;
+constexpr int G3Q_LDS_BYTES = G3Q_STAGES * (G3Q_BM + G3_BN) * 128;  // 79 872
+static_assert(2 * G3Q_LDS_BYTES <= 160 * 1024, "two latency-tile workgroups per CU");
 
 template <typename T, int EPI, int TAG, int BM_ = G3_BM, int NW_ = G3_NW, int STAGES_ = G3_STAGES>
 __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p) {  // two waves per SIMD either way: 8 of one workgroup, or 4 + 4 of two
   constexpr int BM = BM_, BN = G3_BN, NWAVES = NW_, NSTG = STAGES_;
   constexpr int WTM = BM / NWAVES;
   constexpr int FM = WTM / 16, FN = BN / 16;
-  static_assert(FM == 2 && FN == 9 && (NSTG == 2 || NSTG == 3), "wave tile 32 x 144");
+  static_assert((FM == 1 || FM == 2) && FN == 9 && (NSTG == 2 || NSTG == 3), "wave tile 32 x 144 or 16 x 144");
   static_assert(BM == G3_BM || (EPI != EPI_BIAS_ATTN && EPI != EPI_BIAS_ATTN_TAIL), "the attention tail runs on 256-row tiles");
   constexpr int A_BYTES = BM * 128;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int A_INST = BM / 8 / NWAVES;
   constexpr int B_INST_TOTAL = BN / 8;
   constexpr int B_INST_MAX = (B_INST_TOTAL + NWAVES - 1) / NWAVES;
+  constexpr int VMW = A_INST + B_INST_TOTAL / NWAVES;  // fewest LDS-DMA pieces any wave issues per stage: what may stay in flight across a 3-stage step top (6)
   constexpr int CS = BN + 8;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,8 +233,8 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   auto step_top = [&](int kt) {
     // 2-stage ring: the stage of this step is the newest thing in flight (it was issued during the previous step): everything must have landed
     if (NSTG == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (EPI == EPI_BIAS_CACHE_RESID && resid_in_loop && kt == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NCH) : "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (EPI == EPI_BIAS_CACHE_RESID && resid_in_loop && kt == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW + NCH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef G3_ABL_NOBAR
     if (kt < 2)  // ablation build (racy): a K-step without its barrier
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #define G3_STAG_GROUPS 6
 #endif
   // 18 MFMAs in 6 groups of 3 (9 groups of 2: -DG3_STAG_GROUPS=9, and always for the 4-wave variant, whose waves issue 9 pieces each)
-  constexpr int NMF = FM * FN, GROUPS = NPIECE > G3_STAG_GROUPS + 1 ? 9 : G3_STAG_GROUPS, PER = NMF / GROUPS;
+  constexpr int NMF = FM * FN, GROUPS = (NPIECE > G3_STAG_GROUPS + 1 || NMF % G3_STAG_GROUPS) ? 9 : G3_STAG_GROUPS, PER = NMF / GROUPS;
   static_assert(NMF % GROUPS == 0 && NPIECE <= GROUPS + 1, "piece / MFMA interleave");
   [[maybe_unused]] constexpr int LASTP = NPIECE > GROUPS ? GROUPS - 1 : NPIECE - 1;  // group that carries the last regular piece
   // both halves run the same MFMA stream (one code path: a wave-group branch around the MFMAs makes hipcc shuffle and spill the accumulators);
@@ -438,6 +445,20 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   // is the operand ring underneath.  When the last K-step reads stage 2 (nk % 3 == 0: every K of the model) the tile lies in stages 0 and 1,
   // which nobody touches after the last step's barrier: no workgroup barrier at all, and a wave that leaves the loop early streams its rows out
   // while the others still multiply (stamped: 1.3-2k cycles of waiting for the slowest wave gone).  Otherwise: one barrier, as before.
+  if constexpr (EPI != EPI_BIAS_CACHE_RESID) {
+    if (p.ln_stat) {  // LayerNorm folded into this GEMM (gemm.h): plain / GELU / SiLU epilogues of the unfused and the latency-tile launches
+      float ra[FM], rb[FM];
+      ln_row_coeffs<FM>(p, m0 + wave * WTM + l15, ra, rb);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n0 + 16 * j + 4 * g);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(acc[i][j][r], ra[i], rb[i] * c1[r]);
+      }
+    }
+  }
   const bool private_epi = NSTG == 3 && nk >= 2 && (nk - 1) % NSTG == 2 && (BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float)) <= 2 * STAGE_BYTES;
   static_assert(BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float) <= NSTG * STAGE_BYTES, "C tile + gate copies inside the ring");
   if (!private_epi) __syncthreads();
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       // fixed order, the two halves meet through one shuffle: deterministic, and no atomics anywhere.  Values are the ROUNDED hidden states, i.e. exactly what
       // the LayerNorm kernel would read back from memory.
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int rl = lane & 31, hh = lane >> 5;
+      const int rl = lane & (WTM - 1), hh = (lane / WTM) & 1;  // 16-row wave tiles: lanes 32-63 repeat lanes 0-31 and do not store
       float sx = 0.f, sxx = 0.f;
 #pragma unroll
       for (int c = 0; c < CPR / 2; ++c) {
@@ -547,9 +568,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sx += x[e]; sxx = __builtin_fmaf(x[e], x[e], sxx); }
       }
-      const float ox = __shfl_xor(sx, 32), oxx = __shfl_xor(sxx, 32);
+      const float ox = __shfl_xor(sx, WTM), oxx = __shfl_xor(sxx, WTM);
       const int m = m0 + wave * WTM + rl;
-      if (hh == 0 && m < p.M) {
+      if (lane < WTM && m < p.M) {
         float* dst = p.stat_out + ((size_t)tn * p.M + m) * 2;
         dst[0] = sx + ox;    // lower half + upper half: the same order on every launch
         dst[1] = sxx + oxx;

@@ -502,6 +502,51 @@ def test_layernorm_folded_into_the_consumer_gemms(monkeypatch):
     assert within(err, 8e-3)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+def test_latency_tiles_for_few_rows_are_the_same_arithmetic(monkeypatch, dtype, tol):
+    """with few rows (batch 1-4) every GEMM outside the attention-fused query projections runs on 64 x 144 tiles (gemm3s.h latency variant, the product
+    default; this suite switches it off elsewhere, conftest.py).  Same K order, same epilogues, same per-tile row statistics for the folded LayerNorm: per-step outputs
+    and the whole-loop latents must equal the 256-row kernels' bit for bit -- and are held to the oracle here as well."""
+    from ecad_amd.engine import EcadEngine
+
+    layers, steps, B = 3, 6, 2
+    bits = rand_bits(steps, layers, 0.6, seed=17)
+    bits[0] = True
+    cfg = PixArtConfig(num_layers=layers)
+    w = make_weights(cfg, seed=2)
+    ref = PixArtOracle(cfg, w)
+    inp, enc, mask = cfg_inputs(B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    res = {}
+    for lat in ("1", "0"):
+        monkeypatch.setenv("ECAD_LATENCY_TILES", lat)
+        eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=dtype)
+        eng.load_state_dict(w)
+        eng.set_schedule(bits)
+        eng.begin_image_batch(enc.cuda(), mask.cuda(), 32, 32)
+        g = torch.Generator().manual_seed(5)
+        per_step, worst = [], 0.0
+        for s in range(steps):
+            x = torch.randn(2 * B, 4, 32, 32, generator=g)
+            t = torch.tensor([999.0 - 50 * s] * (2 * B)) + torch.arange(2 * B) * 3.0
+            out = eng.step(s, x.cuda(), t.cuda())
+            per_step.append(out.cpu())
+            if lat == "1":
+                worst = max(worst, rel_l2(out, ref.forward(x.to(dtype).float(), enc.to(dtype).float(), mask, t, s, bits[s])))
+        a = eng.run_schedule(enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5, use_graph=True)
+        b = eng.run_schedule(enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
+        assert torch.equal(a, b)
+        res[lat] = (per_step, a.cpu(), worst, eng.stats()["ln_folded"])
+        eng.close()
+    print(f"latency tiles, worst per-step rel-L2 vs the oracle ({dtype}): {res['1'][2]:.3e}")
+    assert within(res["1"][2], tol)
+    assert res["1"][3] == res["0"][3] > 0  # the LayerNorm fold is on in both
+    for x, y in zip(res["1"][0], res["0"][0]):
+        assert torch.equal(x, y)
+    assert torch.equal(res["1"][1], res["0"][1])
+
+
 def test_execution_contexts_share_weights_and_keep_results_bit_identical():
     """ecad_share_weights / EngineContexts: further execution contexts read the first engine's weight arena (no copy), keep their own cache arena,
     plans and hipGraph, and run on their own streams, so several image batches are in flight at once.  Six different batches submitted to three contexts

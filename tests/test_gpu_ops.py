@@ -74,6 +74,12 @@ KERNEL_CASES = [
     ("half144", "attn2_q", 0, 700, 1152, 1152),
     ("half144", "small", 2, 40, 1152, 256),
     ("half144", "small", 1, 1000, 576, 64),
+    # gemm3s.h latency variant: 64 x 144 tiles, four waves of 16 x 144 -- what the engine launches when a GEMM has few rows (batch 1-4)
+    ("latency64", "attn2_q", 0, 512, 1152, 1152),
+    ("latency64", "ff1", 1, 512, 4608, 1152),
+    ("latency64", "attn1_kv", 0, 1000, 2304, 1152),
+    ("latency64", "small", 2, 40, 1152, 256),
+    ("latency64", "caption", 1, 240, 1152, 4096),
 ]
 
 
@@ -114,7 +120,8 @@ def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("kernel,site,K,B,Ntok", [("tile144", "attn1_out", 1152, 32, 256), ("tile144", "attn2_out", 1152, 3, 192), ("tile144", "ff2", 4608, 32, 256),
                                                  ("persistent", "ff2", 4608, 32, 256), ("persistent", "attn1_out", 1152, 3, 192), ("tile128", "small", 1152, 3, 192),
-                                                 ("half144", "attn1_out", 1152, 32, 256), ("half144", "attn2_out", 1152, 3, 192), ("half144", "ff2", 4608, 32, 256)])
+                                                 ("half144", "attn1_out", 1152, 32, 256), ("half144", "attn2_out", 1152, 3, 192), ("half144", "ff2", 4608, 32, 256),
+                                                 ("latency64", "attn1_out", 1152, 2, 256), ("latency64", "attn2_out", 1152, 3, 192), ("latency64", "ff2", 4608, 4, 256)])
 def test_gemm_cache_gate_residual_every_kernel(dtype_name, kernel, site, K, B, Ntok):
     """cache <- out; hidden += gate * out with gates of O(1) (cached_transformer_block.py:243-246,317-320,355-360) on every kernel that carries that epilogue, at
     config A's shape (M = 8192: one sample per 256-row tile -> gate via LDS) and with 192 tokens per sample (tiles straddle samples -> per-chunk gate)."""

@@ -39,7 +39,9 @@ template <int DHC> constexpr int attn_dma_image_bytes() { return A128_KC * (AttC
 template <int DHC> constexpr int attn_dma_lds_bytes() { return 2 * attn_dma_image_bytes<DHC>(); }
 static_assert(attn_dma_lds_bytes<128>() <= 160 * 1024, "two images of the d_h 128 chunk");
 
-template <typename T, int DHC>
+// R = query fragments (16 rows each) per wave: 2 (256 query rows per work item, as attention128.h) or 4 (512 rows: every K / V fragment read feeds four MFMAs and a
+// chunk is staged once for twice the rows; fits the 72-wide head only -- d_h 128 would need 144 accumulator + 64 query + 64 score registers).  DESIGN 5d.
+template <typename T, int DHC, int R = 2>
 __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
   constexpr int KC = A128_KC, KS = AttCfg<DHC>::KS, VS = AttCfg<DHC>::VS, DH = DHC, ND = AttCfg<DHC>::ND, KSTEPS = AttCfg<DHC>::KSTEPS;
   constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0);
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
   const T* K = reinterpret_cast<const T*>(p.k);
   const T* V = reinterpret_cast<const T*>(p.v);
   T* O = reinterpret_cast<T*>(p.out);
-  const int nqb = (p.Nq + ATT_QB - 1) / ATT_QB;
+  constexpr int QB = 8 * 16 * R;  // query rows per work item
+  const int nqb = (p.Nq + QB - 1) / QB;
   const int nkc = p.Nk / KC;
   const int items = p.B * p.H * nqb;
 
@@ -107,16 +110,18 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
   for (; item < items; item += gridDim.x) {
     const int qb = item % nqb, bh = item / nqb;
     const int h = bh % p.H, b = bh / p.H;
-    f32x4 oacc[2][ND];
-    float m_run[2] = {ATT_NEG, ATT_NEG};
+    f32x4 oacc[R][ND];
+    float m_run[R];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < R; ++r) {
+      m_run[r] = ATT_NEG;
 #pragma unroll
       for (int nd = 0; nd < ND; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    Pack8 qfr[2][KSTEPS];
+    }
+    Pack8 qfr[R][KSTEPS];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int qrow = qb * ATT_QB + wave * 32 + r * 16 + l15;
+    for (int r = 0; r < R; ++r) {
+      const int qrow = qb * QB + wave * (16 * R) + r * 16 + l15;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         qfr[r][ks].u = (u32x4){0, 0, 0, 0};
@@ -138,21 +143,21 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
       for (int half = 0; half < 2; ++half) {
         const T* Kh = Ks + half * 64 * KS;
         const T* Vh = Vs + half * 64 * VS;
-        f32x4 s[2][4];
+        f32x4 s[R][4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          s[0][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          s[1][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < R; ++r) s[r][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
             const Pack8 kf = lds_read16(Kh + (16 * f + l15) * KS + 32 * ks + 8 * g);
-            s[0][f] = mfma16<T>(kf, qfr[0][ks], s[0][f]);
-            s[1][f] = mfma16<T>(kf, qfr[1][ks], s[1][f]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r][f] = mfma16<T>(kf, qfr[r][ks], s[r][f]);
           }
         }
-        float m_new[2];
+        float m_new[R];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
           float mt = ATT_NEG;
 #pragma unroll
           for (int f = 0; f < 4; ++f)
@@ -173,9 +178,9 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          Pack8 pf[2];
+          Pack8 pf[R];
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
+          for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float p0 = fast_exp2(__builtin_fmaf(s[r][2 * s2][e], p.scale_log2e, -m_new[r]));
@@ -191,19 +196,19 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
             const Pack4 hi = lds_read_tr16(Vh + (krow + 16) * VS + 16 * nd + dcol);
             Pack8 vf;
             vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
-            oacc[0][nd] = mfma16<T>(vf, pf[0], oacc[0][nd]);
-            oacc[1][nd] = mfma16<T>(vf, pf[1], oacc[1][nd]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) oacc[r][nd] = mfma16<T>(vf, pf[r], oacc[r][nd]);
           }
         }
       }
       buf ^= 1;
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < R; ++r) {
       constexpr int DL = DH & 15;
       const float den = __shfl(oacc[r][DH >> 4][DL & 3], l15 + 16 * (DL >> 2));
       const float inv = 1.0f / den;
-      const int qrow = qb * ATT_QB + wave * 32 + r * 16 + l15;
+      const int qrow = qb * QB + wave * (16 * R) + r * 16 + l15;
       if (qrow < p.Nq) {
         T* orow = O + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldo + (size_t)h * DH;
 #pragma unroll

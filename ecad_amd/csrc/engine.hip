@@ -312,8 +312,9 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_LN_FOLD")) ln_fold = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
-    if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : 0; }
+    if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : strcmp(at, "dma4") == 0 ? 2 : 0; }
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_ATTN_WIDE")) attn_wide = atoi(l) != 0;
     if (const char* gh = getenv("ECAD_GEMM_HALF")) {  // A/B switch: 1 = the two attention out-projections, 2 = + FF2, 3 = + cross-attention Q when it runs unfused
       const int lv = atoi(gh);
       if (lv >= 1) gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = 4;
@@ -862,8 +863,12 @@ template <typename T> class EngineT : public EngineBase {
       } else if (ex[0]) {
         // attention in the tail of the Q projection (gemm3s_attn.h): the K,V columns first (wide tiles), then one launch that projects Q for
         // (sample, two heads) and runs their attention on the spot -- no attention launch, no Q round trip through HBM
-        const bool fuse1 = fuse_attn && !fp8 && DH == 72 && split_qkv && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0;
-        const bool fold1 = fold_plan && fuse1 && cb && pend.empty() && stats_ok;
+        // Long sequences (N >= 1024, e.g. Sigma-1024's 4096 tokens): the attention kernel with FOUR query fragments per wave (attention_dma.h R = 4: K / V staged
+        // once per 512 query rows, every fragment read feeds four MFMAs) beats the fused tail, whose 256-row tile fixes two fragments per wave: Sigma-1024 shape 750
+        // against 850 us stand-alone, and the Q round trip it reintroduces is 2 % of that launch.  env ECAD_ATTN_WIDE=0: fused tail at every length.
+        const bool wide_items = attn_wide && !fp8 && DH == 72 && N >= 1024 && N % 512 == 0 && split_qkv && (2 * D) % G2_BN == 0 && attn_shared;
+        const bool fuse1 = fuse_attn && !wide_items && !fp8 && DH == 72 && split_qkv && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0;
+        const bool fold1 = fold_plan && (fuse1 || wide_items) && cb && pend.empty() && stats_ok;
         const T* a_in = xn;
         const T* w_in = B.w_qkv;
         const float* b_in = B.b_qkv;
@@ -897,12 +902,15 @@ template <typename T> class EngineT : public EngineBase {
         if (split_qkv && (2 * D) % G2_BN == 0) {
           // Q columns on 256x144 tiles (256 tiles) + K,V columns on 256x288 tiles (256 tiles): the wide tiles move 32 % fewer
           // L2->LDS bytes per flop, and both launches fill the chip exactly once
-          push_gemm(ops, mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, D, D, D, 3 * D), true);
-          push_gemm(ops, mk_gemm(KC_GEMM_KV1, EPI_BIAS, xn, B.w_qkv + (size_t)D * D, B.b_qkv + D, qkv + D, M, 2 * D, D, D, 3 * D), true);
+          Op<T> q = mk_gemm(KC_GEMM_QKV, EPI_BIAS, a_in, w_in, b_in, qkv, M, D, D, D, 3 * D);
+          Op<T> kv = mk_gemm(KC_GEMM_KV1, EPI_BIAS, a_in, w_in + (size_t)D * D, b_in + D, qkv + D, M, 2 * D, D, D, 3 * D);
+          if (fold1) { set_fold(q, c1_in); set_fold(kv, c1_in + D); }
+          push_gemm(ops, q, true);
+          push_gemm(ops, kv, true);
         } else {
           push_gemm(ops, mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D), true);
         }
-        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0;
+        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0; a.i0 = wide_items ? 1 : 0;
         a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = attn1_flops; a.bytes = 4.0 * M * (double)D * sizeof(T);
@@ -1264,9 +1272,19 @@ template <typename T> class EngineT : public EngineBase {
   }
   int attn_shared = 1;  // attention128.h structure (both query fragments of a wave share each K / V fragment read); env ECAD_ATTN=generic: attention.h
   bool attn_shared_attr[2] = {};
+  bool attn_wide = true;  // self-attention over >= 1024 tokens: stand-alone launch with four query fragments per wave instead of the fused tail (env ECAD_ATTN_WIDE=0)
   int attn_dma = 0;  // env ECAD_ATTN=dma: attention_dma.h for unmasked attention over whole 128-key chunks (A/B)
-  bool attn_dma_attr[1] = {};
-  int launch_attn(const AttnArgs& a, bool masked, hipStream_t s) {
+  bool attn_dma_attr[2] = {};
+  int launch_attn(const AttnArgs& a, bool masked, hipStream_t s, bool wide = false) {
+    if ((attn_dma == 2 || wide) && a.dh == 72 && !masked && a.Nk % 128 == 0 && a.seg_t == 0 && a.Nq % 512 == 0) {  // four query fragments per wave: 512 query rows per work item
+      if (!attn_dma_attr[1]) {
+        HIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 72, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<72>()));
+        attn_dma_attr[1] = true;
+      }
+      const int items4 = a.B * a.H * (a.Nq / 512);
+      hipLaunchKernelGGL((attn_dma_kernel<T, 72, 4>), dim3(items4 < num_cus ? items4 : num_cus), dim3(512), attn_dma_lds_bytes<72>(), s, a);
+      return ECAD_OK;
+    }
     if (attn_dma && a.dh == 72 && !masked && a.Nk % 128 == 0 && a.seg_t == 0) {
       if (!attn_dma_attr[0]) {
         HIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<72>()));
@@ -1356,7 +1374,7 @@ template <typename T> class EngineT : public EngineBase {
         else hipLaunchKernelGGL((gemm3s8_kernel<T, EPI_BIAS_CACHE_RESID>), dim3(tiles), dim3(G3_NW * 64), G3_LDS_BYTES, s, q);
         break;
       }
-      case Op<T>::ATTN: return launch_attn(o.a, o.attn_masked, s);
+      case Op<T>::ATTN: return launch_attn(o.a, o.attn_masked, s, o.i0 == 1);
       case Op<T>::LN: return launch_ln(o.f, s);
       case Op<T>::REPLAY: launch_replay(o.f, s, o.cls == KC_CACHE_HIT_STEP); break;
       case Op<T>::PATCH: {

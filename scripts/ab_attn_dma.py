@@ -52,7 +52,7 @@ def pixart(B, N, label):
     D = H * dh
     qkv = torch.randn(B * N, 3 * D, device="cuda").half()
     engs = {}
-    for mode in ("shared", "dma"):
+    for mode in ("shared", "dma", "dma4"):
         os.environ["ECAD_ATTN"] = mode
         engs[mode] = EcadEngine(num_layers=1, max_batch=2, dtype=torch.float16)
     run = lambda e: e.op_attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, dh)

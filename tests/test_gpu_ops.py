@@ -349,11 +349,12 @@ def test_cross_attention_masked(T):
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
-@pytest.mark.parametrize("N", [256, 1024])
-def test_self_attention_lds_dma_kernel_is_the_same_arithmetic(monkeypatch, dtype_name, N):
+@pytest.mark.parametrize("N,mode", [(256, "dma"), (1024, "dma"), (1024, "dma4"), (2048, "dma4")])
+def test_self_attention_lds_dma_kernel_is_the_same_arithmetic(monkeypatch, dtype_name, N, mode):
     """attention_dma.h (opt-in, ECAD_ATTN=dma): K / V chunks by LDS-DMA into a double-buffered image whose pads -- zeros and the ones column -- are written once
     and never touched again because pad lanes are switched off.  Same fragment layouts and operation order as attention128.h: bit-identical outputs, N = 1024
-    runs eight chunks through both images with a late dominant key tile (running-maximum rescale)."""
+    runs eight chunks through both images with a late dominant key tile (running-maximum rescale).  "dma4" = four query fragments per wave (512 query rows per work
+    item): what the engine launches for self-attention over >= 1024 tokens (Sigma-1024, alpha-512) instead of the fused tail."""
     from ecad_amd.engine import EcadEngine
 
     dt = getattr(torch, dtype_name)
@@ -363,7 +364,7 @@ def test_self_attention_lds_dma_kernel_is_the_same_arithmetic(monkeypatch, dtype
     qkv[N - 40 : N - 32, D : 2 * D] *= 5.0
     ref_eng = small_engine(dtype_name)
     want = ref_eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh)
-    monkeypatch.setenv("ECAD_ATTN", "dma")
+    monkeypatch.setenv("ECAD_ATTN", mode)
     eng = EcadEngine(num_layers=1, max_batch=2, dtype=dt)
     got = eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh)
     assert torch.equal(got, want)

@@ -37,6 +37,7 @@ struct AttnArgs {
   int B, H, Nq, Nk, dh;
   float scale_log2e;  // (1/sqrt(dh)) * log2(e)
   int seg_t, seg_bt;  // 0, 0: plain [B, N] rows; else the joint [text | image] layout (same for q, k, v, out)
+  int q_off, q_cnt;   // attention_dma.h: this launch covers query rows [q_off, q_off + q_cnt) of every (sample, head); q_cnt 0 = all Nq rows
 };
 
 template <int DHC> struct AttCfg;

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
   const T* V = reinterpret_cast<const T*>(p.v);
   T* O = reinterpret_cast<T*>(p.out);
   constexpr int QB = 8 * 16 * R;  // query rows per work item
-  const int nqb = (p.Nq + QB - 1) / QB;
+  const int q_cnt = p.q_cnt > 0 ? p.q_cnt : p.Nq;  // a launch may cover a slice of the query rows of every (sample, head): see launch_attn in flux.hip
+  const int nqb = (q_cnt + QB - 1) / QB;
   const int nkc = p.Nk / KC;
   const int items = p.B * p.H * nqb;
 
@@ -121,11 +122,11 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
     Pack8 qfr[R][KSTEPS];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int qrow = qb * QB + wave * (16 * R) + r * 16 + l15;
+      const int qloc = qb * QB + wave * (16 * R) + r * 16 + l15, qrow = p.q_off + qloc;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         qfr[r][ks].u = (u32x4){0, 0, 0, 0};
-        if (qrow < p.Nq && 32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * DH + 32 * ks + 8 * g);
+        if (qloc < q_cnt && qrow < p.Nq && 32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * DH + 32 * ks + 8 * g);
       }
     }
     for (int kc = 0; kc < nkc; ++kc) {
@@ -208,8 +209,8 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
       constexpr int DL = DH & 15;
       const float den = __shfl(oacc[r][DH >> 4][DL & 3], l15 + 16 * (DL >> 2));
       const float inv = 1.0f / den;
-      const int qrow = qb * QB + wave * (16 * R) + r * 16 + l15;
-      if (qrow < p.Nq) {
+      const int qloc = qb * QB + wave * (16 * R) + r * 16 + l15, qrow = p.q_off + qloc;
+      if (qloc < q_cnt && qrow < p.Nq) {
         T* orow = O + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldo + (size_t)h * DH;
 #pragma unroll
         for (int nd = 0; nd < NDO; ++nd) {

@@ -203,7 +203,8 @@ template <typename T> class FluxT : public FluxBase {
   bool f8_engine_attr = false;
   bool fuse_rope = true;      // env ECAD_FLUX_FUSE=0: separate qk_norm_rope pass and separate single-block QKV / proj_mlp GEMMs (A/B)
   bool attn_generic = false;  // env ECAD_FLUX_ATTN=generic: the d_h-templated kernel of attention.h (A/B)
-  int attn_dma = 0;           // env ECAD_FLUX_ATTN=dma: attention_dma.h (K / V chunks by LDS-DMA into a double-buffered image; A/B)
+  int attn_dma = 2;           // attention_dma.h (K / V chunks by LDS-DMA into a double-buffered image) with the partial last round of work items run as 128-row
+                              // items in a second launch; env ECAD_FLUX_ATTN=dma: one launch, =shared: attention128.h, =generic: attention.h
   bool attn_dma_attr[1] = {};
   const void* call_in = nullptr;
   void* call_out = nullptr;
@@ -344,7 +345,7 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     FHIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     if (fp8 && D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
-    if (const char* e = getenv("ECAD_FLUX_ATTN")) { attn_generic = strcmp(e, "generic") == 0; attn_dma = strcmp(e, "dma") == 0 ? 1 : 0; }
+    if (const char* e = getenv("ECAD_FLUX_ATTN")) { attn_generic = strcmp(e, "generic") == 0; attn_dma = strcmp(e, "dma") == 0 ? 1 : strcmp(e, "dma-split") == 0 ? 2 : (strcmp(e, "shared") == 0 || strcmp(e, "generic") == 0) ? 0 : attn_dma; }
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
 
     // ---- weights: a dry layout pass sizes the arena
@@ -944,10 +945,26 @@ template <typename T> class FluxT : public FluxBase {
     const int grid = items < num_cus ? items : num_cus;
     if (!attn_generic && attn_dma && a.Nk % 128 == 0 && a.seg_t % 128 == 0) {  // attention_dma.h: same arithmetic, chunks by LDS-DMA, one barrier per chunk
       if (!attn_dma_attr[0]) {
-        FHIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<128>()));
+        FHIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<128>()));
+        FHIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<128>()));
         attn_dma_attr[0] = true;
       }
-      hipLaunchKernelGGL((attn_dma_kernel<T, 128>), dim3(grid), dim3(512), attn_dma_lds_bytes<128>(), s, a);
+      // Tile-count quantisation: FLUX-1024 has 864 work items of 256 query rows on 256 CUs = 3.375 rounds, i.e. the launch takes 4.  With attn_dma == 2 the
+      // whole rounds run as they are and the rest of every (sample, head) as 128-row items (one query fragment per wave, half the MFMAs per item, the same K / V
+      // stream) in a second launch that all CUs share: 3 + ~0.6 rounds.
+      const int per_bh = (a.Nq + ATT_QB - 1) / ATT_QB;
+      const int whole = (items / num_cus) * num_cus;                       // items in whole rounds
+      const int keep_qb = whole / (a.B * a.H);                             // 256-row blocks per (sample, head) that stay
+      if (attn_dma == 2 && items > num_cus && items % num_cus != 0 && keep_qb >= 1 && keep_qb < per_bh && whole == keep_qb * a.B * a.H) {
+        AttnArgs a1 = a, a2 = a;
+        a1.q_off = 0; a1.q_cnt = keep_qb * ATT_QB;
+        a2.q_off = keep_qb * ATT_QB; a2.q_cnt = a.Nq - a2.q_off;
+        hipLaunchKernelGGL((attn_dma_kernel<T, 128, 2>), dim3(num_cus), dim3(512), attn_dma_lds_bytes<128>(), s, a1);
+        const int items2 = a.B * a.H * ((a2.q_cnt + 127) / 128);
+        hipLaunchKernelGGL((attn_dma_kernel<T, 128, 1>), dim3(items2 < num_cus ? items2 : num_cus), dim3(512), attn_dma_lds_bytes<128>(), s, a2);
+        return ECAD_OK;
+      }
+      hipLaunchKernelGGL((attn_dma_kernel<T, 128, 2>), dim3(grid), dim3(512), attn_dma_lds_bytes<128>(), s, a);
       return ECAD_OK;
     }
     if (!attn_generic) {  // attention128.h: both query fragments of a wave share every K / V fragment read

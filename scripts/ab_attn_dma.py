@@ -33,7 +33,7 @@ def flux():
     B, T, N, H = 2, 512, 4096, 24
     qkv = (torch.randn(B * (T + N), 3 * H * 128, device="cuda") * 0.5).bfloat16()
     engs = {}
-    for mode in ("shared", "dma"):
+    for mode in ("shared", "dma", "dma-split"):
         os.environ["ECAD_FLUX_ATTN"] = mode
         engs[mode] = EcadFluxEngine(num_layers=0, num_single_layers=0, num_heads=H, max_batch=B, max_image_tokens=N, max_text_tokens=T, dtype=torch.bfloat16)
     ref = engs["shared"].op_attention(qkv, B, T, N)

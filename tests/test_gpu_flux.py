@@ -139,19 +139,31 @@ def test_joint_attention_matches_sdpa(op_engine, dtype, tol, T, N):
     assert within(rel_l2(out.float(), want), tol)
 
 
-def test_joint_attention_lds_dma_kernel_is_the_same_arithmetic(monkeypatch, op_engine):
-    """attention_dma.h at d_h 128 (opt-in, ECAD_FLUX_ATTN=dma) on the joint [text | image] layout with whole 128-key chunks on both sides of the boundary
-    (T = 128, N = 384: four chunks, both LDS images used twice): bit-identical to attention128.h."""
+def test_joint_attention_kernels_are_the_same_arithmetic(monkeypatch):
+    """The FLUX engine's default joint attention (attention_dma.h: K / V chunks by LDS-DMA into a double-buffered image; when the work items do not fill whole rounds
+    of workgroups, the rest of every (sample, head) runs as 128-row items in a second launch), its one-launch form (ECAD_FLUX_ATTN=dma) and attention128.h
+    (=shared) on the joint [text | image] layout with whole 128-key chunks on both sides of the boundary: bit-identical outputs.  B 2 x 24 heads x (128 + 2944) rows =
+    576 items on 256 CUs = 2.25 rounds, so the default really splits (512 items + 2 x 48 x 2 half items)."""
     dtype = torch.bfloat16
-    B, T, N, D = 2, 128, 384, 256
-    qkv = torch.randn(B * (T + N), 3 * D, generator=torch.Generator().manual_seed(11)).to(dtype).cuda()
-    want = op_engine[dtype].op_attention(qkv, B, T, N)
-    monkeypatch.setenv("ECAD_FLUX_ATTN", "dma")
-    eng = make_engine(tiny_cfg(1, 1), dtype, max_n=384)
-    got = eng.op_attention(qkv, B, T, N)
-    torch.cuda.synchronize()
-    assert torch.equal(got, want)
-    eng.close()
+    B, T, N, H = 2, 128, 2944, 24
+    D = H * 128
+    qkv = (torch.randn(B * (T + N), 3 * D, generator=torch.Generator().manual_seed(11)) * 0.5).to(dtype).cuda()
+    outs = {}
+    for mode in ("shared", "dma", "dma-split"):
+        monkeypatch.setenv("ECAD_FLUX_ATTN", mode)
+        from ecad_amd.flux_engine import EcadFluxEngine
+
+        eng = EcadFluxEngine(num_layers=0, num_single_layers=0, num_heads=H, max_batch=B, max_image_tokens=N, max_text_tokens=T, dtype=dtype)
+        outs[mode] = eng.op_attention(qkv, B, T, N)
+        torch.cuda.synchronize()
+        eng.close()
+    assert torch.equal(outs["dma"], outs["shared"]) and torch.equal(outs["dma-split"], outs["shared"])
+    S = T + N
+    rows = torch.cat([torch.arange(0, T), torch.arange(B * T, B * T + N)])  # sample 0
+    x = qkv[rows].float()
+    q, k, v = [x[:, i * D : (i + 1) * D].view(S, H, 128).transpose(0, 1) for i in range(3)]
+    want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(128), -1) @ v).transpose(0, 1).reshape(S, D)
+    assert within(rel_l2(outs["dma-split"][rows].float(), want), 5e-3)
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)

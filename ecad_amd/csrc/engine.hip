@@ -30,7 +30,6 @@
 #include "gemm2w.h"
 #include "gemm3s.h"
 #include "gemm3s8.h"
-#include "pgemm.h"
 
 namespace ecad {
 
@@ -294,10 +293,10 @@ template <typename T> class EngineT : public EngineBase {
     if (cfg.use_additional_conditions && (D % 3 != 0 || (D / 3) % 4 != 0)) return fail(ECAD_E_UNSUPPORTED, "use_additional_conditions needs inner dim %d divisible by 12", D);
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
-    for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
+    for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0;
     gemm_impl_cls[KC_GEMM_QKV] = gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = gemm_impl_cls[KC_GEMM_Q2] = 0;
     // since gemm3s consumes its second fragment set across the K-step barrier it beats the persistent producer / consumer kernel on FF2
-    // too (in-run: 19.77 -> 18.80 ms per batch = 1008 TFLOP/s) and on the caption / small GEMMs; pgemm stays selectable (ECAD_GEMM=persistent)
+    // too (in-run: 19.77 -> 18.80 ms per batch = 1008 TFLOP/s) and on the caption / small GEMMs (pgemm.h, which nothing has launched since, was retired in round 3: scripts/retired_pgemm.h)
     gemm_impl_cls[KC_GEMM_FF2] = gemm_impl_cls[KC_GEMM_CAPTION] = gemm_impl_cls[KC_GEMM_SMALL] = 0;
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
@@ -323,7 +322,6 @@ template <typename T> class EngineT : public EngineBase {
     }
     if (const char* gi = getenv("ECAD_GEMM")) {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
-      if (strcmp(gi, "persistent") == 0) for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 1;
       if (strcmp(gi, "tile128") == 0) tile128_mode = 2;
       if (strcmp(gi, "wide") == 0) gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_SMALL] = 2;
     }
@@ -1143,15 +1141,14 @@ template <typename T> class EngineT : public EngineBase {
     constexpr int lds = gemm_lds_bytes<128, 128>();
     hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, EPI>), dim3(tiles), dim3(256), lds, s, g);
   }
-  bool pg_attr[4][KC_COUNT] = {};
   int num_cus = 256;
   bool g3_attr[4][KC_COUNT] = {};
   bool g3h_attr[4][KC_COUNT] = {};
-  // per call-site class: 1 = persistent producer/consumer (pgemm.h), 0 = one tile per workgroup (gemm3s.h).  Defaults from
+  // per call-site class: 0 = one 256 x 144 tile per workgroup (gemm3s.h), 4 = its 128-row half tile, 5 = its 64-row latency tile;
   // 2 = wide 256x288 tiles (gemm2w.h, N % 288 == 0).  Defaults from interleaved in-process A/B runs with cold caches
-  // (scripts/bench_gemm.py --cold): wide tiles wherever the tile count still fills the chip (FF1, text K/V); the persistent
+  // (scripts/bench_gemm.py --cold): wide tiles wherever the tile count still fills the chip (FF1, text K/V, attn1 K,V);
   // kernel for long K with a plain tile count (FF2); 8 mixed waves for the N = 1152 RMW epilogues and QKV.
-  // env ECAD_GEMM=classic|persistent forces one kernel everywhere.
+  // env ECAD_GEMM=classic forces gemm3s everywhere.
   int gemm_impl_cls[KC_COUNT];
   int tile128_mode = 0;  // 2: every GEMM with N % 128 == 0 on the 128 x 128 kernel (ECAD_GEMM=tile128)
   bool fuse_final = true;  // replays + norm_out + modulate + proj_out + unpatchify as one launch (final_layer.h; env ECAD_FUSE_FINAL=0: separate launches)
@@ -1175,7 +1172,7 @@ template <typename T> class EngineT : public EngineBase {
     return ECAD_OK;
   }
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
-    if (gemm_impl_cls[TAG] == 5 || (few_rows(g) && gemm_impl_cls[TAG] != 4 && gemm_impl_cls[TAG] != 1)) return launch_quarter<EPI, TAG>(g, s);
+    if (gemm_impl_cls[TAG] == 5 || (few_rows(g) && gemm_impl_cls[TAG] != 4)) return launch_quarter<EPI, TAG>(g, s);
     if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
       if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0) {  // wide 256x288 tiles
         if (!g2_attr[EPI][TAG]) {
@@ -1205,14 +1202,7 @@ template <typename T> class EngineT : public EngineBase {
       hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
       return ECAD_OK;
     }
-    if (!pg_attr[EPI][TAG]) {
-      HIPCHK(hipFuncSetAttribute((const void*)pgemm_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_BYTES));
-      pg_attr[EPI][TAG] = true;
-    }
-    const int tiles = ((g.M + PG_BM - 1) / PG_BM) * (g.N / PG_BN);
-    const int grid = tiles < num_cus ? tiles : num_cus;  // one persistent workgroup per CU
-    hipLaunchKernelGGL((pgemm_kernel<T, EPI, TAG>), dim3(grid), dim3(512), PG_LDS_BYTES, s, g);
-    return ECAD_OK;
+    return fail(ECAD_E_INVALID, "no GEMM kernel selected for call site %d (implementation id %d)", TAG, gemm_impl_cls[TAG]);
   }
   // query projection with its attention in the tail (gemm3s_attn.h): gemm3s only, tiles inside one sample, two 72-wide heads per tile
   bool g3a_attr[2] = {};
@@ -1239,14 +1229,14 @@ template <typename T> class EngineT : public EngineBase {
     if (epi == EPI_BIAS_ATTN && cls == KC_GEMM_QKV) return launch_g3_attn<EPI_BIAS_ATTN, KC_GEMM_QKV>(g, s);
     if (epi == EPI_BIAS_ATTN_TAIL && cls == KC_GEMM_Q2) return launch_g3_attn<EPI_BIAS_ATTN_TAIL, KC_GEMM_Q2>(g, s);
     if (epi == EPI_BIAS_ATTN || epi == EPI_BIAS_ATTN_TAIL) return fail(ECAD_E_INVALID, "fused attention epilogue on call site %d", cls);
-    if (g.N % PG_BN == 0 && !use_tile128(g)) {
+    if (g.N % G3_BN == 0 && !use_tile128(g)) {
 #define G144(E, C) if (epi == E && cls == C) return launch_pg<E, C>(g, s)
       G144(EPI_BIAS, KC_GEMM_QKV); G144(EPI_BIAS, KC_GEMM_KV1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT1); G144(EPI_BIAS, KC_GEMM_Q2); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT2);
       G144(EPI_BIAS_GELU, KC_GEMM_FF1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_FF2); G144(EPI_BIAS, KC_GEMM_TEXTKV);
       G144(EPI_BIAS_GELU, KC_GEMM_CAPTION); G144(EPI_BIAS, KC_GEMM_CAPTION);
       G144(EPI_BIAS, KC_GEMM_SMALL); G144(EPI_BIAS_GELU, KC_GEMM_SMALL); G144(EPI_BIAS_SILU, KC_GEMM_SMALL); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_SMALL);
 #undef G144
-      return fail(ECAD_E_INVALID, "no pgemm instantiation for epilogue %d class %d", epi, cls);
+      return fail(ECAD_E_INVALID, "no 144-column GEMM instantiation for epilogue %d class %d", epi, cls);
     }
     if (g.N % 128) return fail(ECAD_E_INVALID, "gemm N=%d must be a multiple of 144 or 128", g.N);
     switch (epi) {
@@ -1744,8 +1734,9 @@ template <typename T> class EngineT : public EngineBase {
       return ECAD_OK;
     }
     if ((kernel == 4 || kernel == 5) && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the half / latency tiles have no attention tail");
+    if (kernel == 1) return fail(ECAD_E_UNSUPPORTED, "the persistent producer / consumer kernel (pgemm.h) was retired in round 3: no call site used it");
     if ((kernel < 0 || kernel > 2) && kernel != 4 && kernel != 5) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
-    if (Nn % PG_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
+    if (Nn % G3_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
     if (kernel == 2) {
       if (Nn % G2_BN) return fail(ECAD_E_UNSUPPORTED, "gemm2w tiles need N %% 288 == 0, got %d", Nn);
       if (site != KC_GEMM_FF1 && site != KC_GEMM_TEXTKV && site != KC_GEMM_SMALL && site != KC_GEMM_KV1)

@@ -31,7 +31,7 @@ def main():
     import os
 
     engines = {}
-    for impl in ("persistent", "classic", "wide"):  # both kernels in ONE process, interleaved (guide rule 24)
+    for impl in ("classic", "wide"):  # both kernels in ONE process, interleaved (guide rule 24)
         os.environ["ECAD_GEMM"] = impl
         engines[impl] = EcadEngine(num_layers=1, max_batch=2, dtype=torch.float16)
     for name, M, N, K, epi in SHAPES:

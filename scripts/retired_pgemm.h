@@ -1,3 +1,6 @@
+// RETIRED (round 3): not part of libecad_hip.so any more -- no call site has launched it since the end of round 1 (gemm3s.h overtook it on FF2 once its second
+// fragment set was carried across the K-step barrier).  Kept for its hand-pipelined consumer loop (sched_group_barrier-pinned fragment ring), which DESIGN 9
+// refers to.  To build it again: include it from engine.hip after gemm.h and restore the launch branch removed in the commit that moved this file.
 // pgemm.h -- persistent producer/consumer MFMA GEMM for the PixArt block on gfx950 (production path).
 //
 //   C[M,N] = epilogue( A[M,K] @ W[N,K]^T + bias ),   N % 144 == 0, K % 64 == 0

@@ -50,7 +50,7 @@ def tile_rel_l2(out, ref, bm=256, bn=144):
 
 # (kernel, call site, epilogue, M, N, K): the instantiations the engine launches, at the shapes it launches them with (config A: M = 8192) plus ragged M.
 # wide288 = gemm2w.h (FF1 + GELU, attn1 K,V two-thirds of the fused QKV weight, hoisted text K/V of all 28 blocks); tile144 = gemm3s.h;
-# persistent = pgemm.h (ECAD_GEMM=persistent); tile128 = gemm.h (N % 144 != 0).
+# tile128 = gemm.h (N % 144 != 0).
 KERNEL_CASES = [
     ("wide288", "ff1", 1, 8192, 4608, 1152),
     ("wide288", "ff1", 1, 600, 4608, 1152),
@@ -64,10 +64,6 @@ KERNEL_CASES = [
     ("tile144", "ff1", 1, 8192, 4608, 1152),
     ("tile144", "caption", 1, 3840, 1152, 4096),
     ("tile144", "small", 2, 40, 1152, 256),
-    ("persistent", "ff1", 1, 8192, 4608, 1152),
-    ("persistent", "text_kv", 0, 3840, 8064, 1152),
-    ("persistent", "qkv", 0, 600, 3456, 1152),
-    ("persistent", "caption", 1, 3840, 1152, 4096),
     ("tile128", "small", 1, 1000, 1024, 512),
     # gemm3s.h half-tile variant: 128 x 144 tiles, four waves, 2-stage ring, two workgroups per CU (ECAD_GEMM_HALF)
     ("half144", "attn2_q", 0, 8192, 1152, 1152),
@@ -119,7 +115,7 @@ def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("kernel,site,K,B,Ntok", [("tile144", "attn1_out", 1152, 32, 256), ("tile144", "attn2_out", 1152, 3, 192), ("tile144", "ff2", 4608, 32, 256),
-                                                 ("persistent", "ff2", 4608, 32, 256), ("persistent", "attn1_out", 1152, 3, 192), ("tile128", "small", 1152, 3, 192),
+                                                 ("tile128", "small", 1152, 3, 192),
                                                  ("half144", "attn1_out", 1152, 32, 256), ("half144", "attn2_out", 1152, 3, 192), ("half144", "ff2", 4608, 32, 256),
                                                  ("latency64", "attn1_out", 1152, 2, 256), ("latency64", "attn2_out", 1152, 3, 192), ("latency64", "ff2", 4608, 4, 256)])
 def test_gemm_cache_gate_residual_every_kernel(dtype_name, kernel, site, K, B, Ntok):
@@ -153,6 +149,10 @@ def test_gemm_ex_refuses_instead_of_substituting():
         eng.op_gemm_ex("wide288", "attn1_out", 0, a, w, None)
     with pytest.raises(ValueError, match="144"):
         eng.op_gemm_ex("tile144", "qkv", 0, a, w[:1024], None)
+    with pytest.raises(ValueError, match="retired"):  # pgemm.h left the library in round 3 (scripts/retired_pgemm.h): its id is refused, not mapped to another kernel
+        eng.op_gemm_ex("persistent", "ff2", 0, a, w, None)
+    with pytest.raises(ValueError, match="attention tail"):
+        eng.op_gemm_ex("latency64", "qkv", 4, a, w, None)
 
 
 def test_gemm_asymmetric_identity():

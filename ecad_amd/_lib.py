@@ -119,6 +119,7 @@ SIGNATURES = {
     "ecad_load_weights": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
     "ecad_finalize_weights": (_I, [_P]),
     "ecad_share_weights": (_I, [_P, _P]),
+    "ecad_set_ln_fold": (_I, [_P, _I]),
     "ecad_set_fp8": (_I, [_P, _I]),
     "ecad_set_added_cond": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I]),
     "ecad_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),

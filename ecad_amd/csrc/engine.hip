@@ -69,6 +69,7 @@ struct EngineBase {
   virtual int finalize_weights() = 0;
   virtual int share_weights(EngineBase* src) = 0;
   virtual int set_fp8(int on) = 0;
+  virtual int set_ln_fold(int on) = 0;
   virtual int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
   virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st) = 0;
@@ -531,6 +532,12 @@ template <typename T> class EngineT : public EngineBase {
     warena = src->warena;
     weights_shared = true;
     finalized = true;
+    return ECAD_OK;
+  }
+  // LayerNorm fold on / off at run time: a caller that runs every schedule for ONE batch (the NSGA-II evaluation) cannot amortise the
+  // per-schedule preparation of the pre-scaled weights; plan sets are keyed by this switch, so both kinds coexist in the plan cache
+  int set_ln_fold(int on) override {
+    if ((on != 0) != ln_fold) { stash_current(); ln_fold = on != 0; }
     return ECAD_OK;
   }
   int set_fp8(int on) override {
@@ -1841,6 +1848,7 @@ const char* ecad_last_error(const EcadEngine* e) { return e ? e->impl->err.c_str
 
 int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { ENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
 int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights(); }
+int ecad_set_ln_fold(EcadEngine* e, int on) { ENG(e); return E->set_ln_fold(on); }
 int ecad_share_weights(EcadEngine* e, EcadEngine* donor) {
   ENG(e);
   if (!donor) return E->fail(ECAD_E_INVALID, "NULL donor");

@@ -94,6 +94,10 @@ class EcadEngine:
             self._h = C.c_void_p()
         self._donor = None
 
+    def set_ln_fold(self, on: bool) -> None:
+        """LayerNorm folded into the consumer GEMMs of the whole-loop plan (default on): switch it off where every schedule runs for one batch only."""
+        self._chk(self.lib.ecad_set_ln_fold(self._h, int(bool(on))))
+
     def new_context(self) -> "EcadEngine":
         """A further execution context on the same GPU: same configuration, the SAME weights (``ecad_share_weights``: no copy, this engine must outlive
         it), the same schedule; its own workspaces, cache arena, plans and hipGraph.  Batches submitted to different contexts on different streams overlap

@@ -52,6 +52,7 @@ def evaluate_population(X: np.ndarray, score_fn: Callable[[int, np.ndarray], flo
 def engine_score_fn(engine, enc, mask, latents, timesteps, coefs, guidance: float = 4.5):
     """score_fn over a fixed prompt/latent batch on this rank's engine (reference latents from the all-true schedule)."""
     steps = len(timesteps)
+    engine.set_ln_fold(False)  # every candidate schedule runs for ONE batch here: the fold's per-schedule weight preparation would never be amortised
     engine.set_schedule(np.ones((steps, engine.cfg.num_layers, 3), dtype=np.uint8))
     ref = engine.run_schedule(enc, mask, latents, timesteps, coefs, guidance)
 

@@ -100,7 +100,7 @@ int ecad_finalize_weights(EcadEngine* e);
 int ecad_share_weights(EcadEngine* e, EcadEngine* donor);
 /* LayerNorm + modulate folded into the consumer GEMMs of the whole-loop plan (default on, env ECAD_LN_FOLD): the per-(step, block) pre-scaled weights are
  * built on the first ecad_run_schedule of a (schedule, timestep grid) -- a few milliseconds that a caller running each schedule for one batch only (the genetic
- * search's candidate evaluation, ecad/genetic/*) does not get back.  Results with and without the fold agree to the rounding that moved (3e-3 on final latents). */
+ * search's candidate evaluation under ecad/genetic) does not get back.  Results with and without the fold agree to the rounding that moved (3e-3 on final latents). */
 int ecad_set_ln_fold(EcadEngine* e, int on);
 /* Opt-in OCP fp8 (e4m3) for the block GEMMs (QKV, attention out-projections, cross-attention Q, FF1, FF2): e4m3 weight copies with
  * per-output-channel scales at finalize, activations quantised per row in front of each GEMM (csrc/gemm3s8.h).  Call before

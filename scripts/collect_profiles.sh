@@ -17,10 +17,10 @@ case "$WL" in
   *) echo "unknown workload $WL"; exit 2 ;;
 esac
 if [ -n "$FP8" ]; then PFX=${PFX}_fp8; DT=fp8; WARGS="$WARGS --fp8"; fi
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${PFX}_prof -- python3 bench.py $WARGS --no-cpu-baseline --no-secondary --no-decode-tail > gpurun_out/${PFX}_bench_under_rocprof.json 2> gpurun_out/${PFX}_prof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${PFX}_prof -- python3 bench.py $WARGS --streams 1 --no-cpu-baseline --no-secondary --no-decode-tail > gpurun_out/${PFX}_bench_under_rocprof.json 2> gpurun_out/${PFX}_prof.log
 cp $(find gpurun_out/${PFX}_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${PFX}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/${PFX}_pmc_$c -- python3 bench.py $WARGS --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-secondary --no-decode-tail > /dev/null 2> gpurun_out/${PFX}_pmc_$c.log
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/${PFX}_pmc_$c -- python3 bench.py $WARGS --streams 1 --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-secondary --no-decode-tail > /dev/null 2> gpurun_out/${PFX}_pmc_$c.log
 done
 python3 scripts/pmc_traffic.py gpurun_out/${PFX}_pmc_FETCH_SIZE gpurun_out/${PFX}_pmc_WRITE_SIZE gpurun_out/${PFX}_pmc_traffic.json $STAMP $DT | tail -20
 rm -rf gpurun_out/${PFX}_prof gpurun_out/${PFX}_pmc_FETCH_SIZE gpurun_out/${PFX}_pmc_WRITE_SIZE

@@ -45,7 +45,7 @@ def classify_flux(name: str, tiles: int) -> str | None:
             (1, t(9216, 12288)): "gemm_single_mlp_gelu", (2, t(9216, 3072)): "gemm_single_proj_out",
         }
         return table.get((epi, tiles))
-    if "attn128_kernel" in name or "attn_kernel" in name:
+    if "attn128_kernel" in name or "attn_kernel" in name or "attn_dma_kernel" in name:
         return "attn_joint"
     if "flux_ln_modulate" in name:
         return "ln_modulate"
@@ -67,6 +67,8 @@ def classify(name: str) -> str | None:
         return "cache_hit_step" if tag and tag.group(1) == "1" else "cache_replay"
     if "ln_modulate" in name:
         return "ln_modulate"
+    if "attn_dma_kernel" in name:  # attention_dma.h: unmasked self-attention only
+        return "attn_self"
     if "attn128_kernel" in name or "attn_kernel" in name:
         masked = re.search(r"Lb([01])E", name) or re.search(r"(true|false)", name)
         if masked is None:

@@ -1165,7 +1165,7 @@ template <typename T> class EngineT : public EngineBase {
   bool split_qkv = true;  // env ECAD_SPLIT_QKV=0 keeps the single 3D-wide launch
   // Few rows (batch 1-4): a launch whose 256-row tiles cover less than half the chip is a latency chain (18-72 K-steps of ~0.8 us whatever the tile count);
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
-  // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections keep their 256-row tile (one sample x two heads).
+  // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
   bool latency_tiles = true;
   bool g3q_attr[4][KC_COUNT] = {};
   bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * 2 <= num_cus; }
@@ -1212,11 +1212,19 @@ template <typename T> class EngineT : public EngineBase {
     return fail(ECAD_E_INVALID, "no GEMM kernel selected for call site %d (implementation id %d)", TAG, gemm_impl_cls[TAG]);
   }
   // query projection with its attention in the tail (gemm3s_attn.h): gemm3s only, tiles inside one sample, two 72-wide heads per tile
-  bool g3a_attr[2] = {};
+  bool g3a_attr[2] = {}, g3qa_attr[2] = {};
   template <int EPI, int TAG> int launch_g3_attn(const GemmArgs<T>& g, hipStream_t s) {
     if (g.N % G3_BN || g.rows_per_batch % G3_BM || g.M % G3_BM || DH != 72 || !g.att_k || !g.att_v || !g.att_out || g.att_nk < 1 || g.att_ldo % 4 || g.att_ldk % 8)
       return fail(ECAD_E_UNSUPPORTED, "fused attention needs 256-row tiles inside one sample and head_dim 72");
     if (EPI == EPI_BIAS_ATTN && g.att_nk % G3A_KC) return fail(ECAD_E_UNSUPPORTED, "fused self-attention needs a key count that is a multiple of 128");
+    if (gemm_impl_cls[TAG] == 5 || few_rows(g)) {  // few rows: 64 query rows x two heads per workgroup, four times the workgroups (the same arithmetic per row)
+      if (!g3qa_attr[EPI - EPI_BIAS_ATTN]) {
+        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
+        g3qa_attr[EPI - EPI_BIAS_ATTN] = true;
+      }
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3((g.M / G3Q_BM) * (g.N / G3_BN)), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
+      return ECAD_OK;
+    }
     if (!g3a_attr[EPI - EPI_BIAS_ATTN]) {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
       g3a_attr[EPI - EPI_BIAS_ATTN] = true;

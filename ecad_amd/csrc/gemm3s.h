@@ -59,7 +59,8 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   constexpr int WTM = BM / NWAVES;
   constexpr int FM = WTM / 16, FN = BN / 16;
   static_assert((FM == 1 || FM == 2) && FN == 9 && (NSTG == 2 || NSTG == 3), "wave tile 32 x 144 or 16 x 144");
-  static_assert(BM == G3_BM || (EPI != EPI_BIAS_ATTN && EPI != EPI_BIAS_ATTN_TAIL), "the attention tail runs on 256-row tiles");
+  static_assert((EPI != EPI_BIAS_ATTN && EPI != EPI_BIAS_ATTN_TAIL) || (BM == WTM * NWAVES && g3a_lds_bytes<BM>() <= NSTG * (BM + BN) * 128 && NSTG == 3),
+                "the attention tail (Q tile + K/V staging + bias strip) lives in the operand ring: 256-row tiles, or the 64-row latency tile");
   constexpr int A_BYTES = BM * 128;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int A_INST = BM / 8 / NWAVES;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   if (!bias_in_loop) load_bias();
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (EPI == EPI_BIAS_ATTN || EPI == EPI_BIAS_ATTN_TAIL) {  // the tile is a query projection: its attention runs here (gemm3s_attn.h)
-    if constexpr (BM == G3_BM) {
+    {
       if (p.ln_stat) {  // LayerNorm folded into this projection: acc <- rstd * acc - rstd * mean * c1; the bias vectors already hold c2 (gemm.h)
         float ra[FM], rb[FM];
         ln_row_coeffs<FM>(p, m0 + wave * WTM + l15, ra, rb);
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
             for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(acc[i][j][r], ra[i], rb[i] * c1[r]);
         }
       }
-      g3_attention_epilogue<T, EPI == EPI_BIAS_ATTN_TAIL>(p, smem, m0, tn, acc, bvs);
+      g3_attention_epilogue<T, EPI == EPI_BIAS_ATTN_TAIL, FM, NWAVES>(p, smem, m0, tn, acc, bvs);
     }
     return;
   }

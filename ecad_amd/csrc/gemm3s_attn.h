@@ -26,15 +26,20 @@ constexpr int G3A_LDS_BYTES = G3A_KV_OFF + attn_lds_bytes<G3A_KC, G3A_DH>();  //
 
 // Called by every thread of the workgroup after the K loop.  `ring_free`: false => the caller has NOT yet synchronised the workgroup after the last
 // K-step (other waves may still read operand stage 2).  acc / bvs: the wave's 32 x 144 accumulators and bias vectors (gemm3s.h layout).
-template <typename T, bool TAIL>
-ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, int tn, const f32x4 (&acc)[2][9], const f32x4 (&bvs)[9]) {
+// FM = 16-row query fragments per wave (2: the 256-row tile of 8 waves; 1: the 64-row latency tile of 4 waves, gemm3s.h), NW = waves of the workgroup.  Every
+// query fragment runs the same operations in the same order whatever FM is, so the two tile sizes give bit-identical attention outputs.
+template <int ROWS> constexpr int g3a_kv_off() { return (ROWS * 152 * 2 + 1023) & ~1023; }  // K / V staging behind the [ROWS][152] Q tile
+template <int ROWS> constexpr int g3a_lds_bytes() { return g3a_kv_off<ROWS>() + attn_lds_bytes<G3A_KC, G3A_DH>(); }
+static_assert(g3a_kv_off<256>() == G3A_KV_OFF && g3a_lds_bytes<256>() == G3A_LDS_BYTES && g3a_lds_bytes<64>() == 19456 + 47616, "Q tile sizes");
+template <typename T, bool TAIL, int FM_ = 2, int NW_ = 8>
+ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, int tn, const f32x4 (&acc)[FM_][9], const f32x4 (&bvs)[9]) {
   constexpr int DH = G3A_DH, KC = G3A_KC, KS = AttCfg<DH>::KS, VS = AttCfg<DH>::VS, ND = AttCfg<DH>::ND, KSTEPS = AttCfg<DH>::KSTEPS, NCH = AttCfg<DH>::NCH;
-  constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0), CS = 152, FN = 9, FM = 2;
-  constexpr int MAXL = (KC * NCH * 2 + 511) / 512;  // 5 staging loads per thread and chunk
+  constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0), CS = 152, FN = 9, FM = FM_, NT = NW_ * 64, WR = 16 * FM_;
+  constexpr int MAXL = (KC * NCH * 2 + NT - 1) / NT;  // staging loads per thread and chunk: 5 (512 threads) / 9 (256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   T* qtile = reinterpret_cast<T*>(smem);
-  T* Ks = reinterpret_cast<T*>(smem + G3A_KV_OFF);
+  T* Ks = reinterpret_cast<T*>(smem + g3a_kv_off<NW_ * 16 * FM_>());
   T* Vs = Ks + KC * KS;
   float* bias_s = reinterpret_cast<float*>(Vs + KC * VS);
   const int b = m0 / p.rows_per_batch;  // the tile lies inside one sample (checked on the host)
@@ -49,7 +54,7 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
     const T* vbase = Vg + (size_t)kc * KC * p.att_ldk + (size_t)h * DH;
 #pragma unroll
     for (int i = 0; i < MAXL; ++i) {
-      int id = tid + i * 512;
+      int id = tid + i * NT;
       // branch-free: lanes without a piece and rows past the end read the chunk's first row (always there) and are dropped / zeroed in store_stage.
       // A load under a lane-dependent branch makes the compiler give up counting: it then waits vmcnt(0) at the next use of ANY earlier load --
       // here the bias vectors the Q tile needs at once, i.e. the K / V latency this prefetch is meant to hide.
@@ -67,20 +72,20 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
   int k_arr[MAXL];
 #pragma unroll
   for (int i = 0; i < MAXL; ++i) {
-    int id = tid + i * 512;
+    int id = tid + i * NT;
     const bool isv = id >= KC * NCH;
     id = isv ? id - KC * NCH : id;
     const int key = id / NCH, c = id - key * NCH;
     k_arr[i] = key;
-    l_arr[i] = (unsigned)(G3A_KV_OFF + (isv ? KC * KS + key * VS + c * 8 : key * KS + c * 8) * (int)sizeof(T));
+    l_arr[i] = (unsigned)(g3a_kv_off<NW_ * 16 * FM_>() + (isv ? KC * KS + key * VS + c * 8 : key * KS + c * 8) * (int)sizeof(T));
   }
   auto store_stage = [&](int kc) {
     const int left = p.att_nk - kc * KC;
 #pragma unroll
     for (int i = 0; i < MAXL; ++i)
-      if (tid + i * 512 < 2 * KC * NCH) *reinterpret_cast<u32x4*>(smem + l_arr[i]) = k_arr[i] < left ? stg[i].u : (u32x4){0, 0, 0, 0};
+      if (tid + i * NT < 2 * KC * NCH) *reinterpret_cast<u32x4*>(smem + l_arr[i]) = k_arr[i] < left ? stg[i].u : (u32x4){0, 0, 0, 0};
     if (TAIL) {
-      for (int i = tid; i < KC; i += 512) {
+      for (int i = tid; i < KC; i += NT) {
         const int gk = kc * KC + i;
         float bv = ATT_NEG;
         if (gk < p.att_nk) bv = p.att_bias ? p.att_bias[(size_t)b * p.att_nk + gk] * 1.4426950408889634f : 0.f;
@@ -97,7 +102,7 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
     const int nl = 16 * j + 4 * g;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int ml = wave * 32 + 16 * i + l15;
+      const int ml = wave * WR + 16 * i + l15;
       Pack4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) float_to_elem4<T>(o, r, acc[i][j][r] + bvs[j][r]);
@@ -105,26 +110,28 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
     }
   }
   // K / V staging area: zero (the padding columns of K and V must be zero), ones column of V (softmax denominator by the PV MFMAs)
-  for (int i = tid; i < KC * (KS + VS) / 8; i += 512) reinterpret_cast<u32x4*>(Ks)[i] = (u32x4){0, 0, 0, 0};
+  for (int i = tid; i < KC * (KS + VS) / 8; i += NT) reinterpret_cast<u32x4*>(Ks)[i] = (u32x4){0, 0, 0, 0};
   __syncthreads();
-  for (int i = tid; i < KC; i += 512) Vs[i * VS + DH] = (T)1.0f;
+  for (int i = tid; i < KC; i += NT) Vs[i * VS + DH] = (T)1.0f;
 
   for (int hd = 0; hd < 2; ++hd) {
     const int h = 2 * tn + hd;
-    f32x4 oacc[2][ND];
-    float m_run[2] = {ATT_NEG, ATT_NEG};
+    f32x4 oacc[FM][ND];
+    float m_run[FM];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < FM; ++r) {
+      m_run[r] = ATT_NEG;
 #pragma unroll
       for (int nd = 0; nd < ND; ++nd) oacc[r][nd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     // query fragments of this head from the wave's own rows of the Q tile (B operand: lane (l15, g) holds 8 consecutive d of query row l15)
-    Pack8 qfr[2][KSTEPS];
+    Pack8 qfr[FM][KSTEPS];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < FM; ++r)
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         qfr[r][ks].u = (u32x4){0, 0, 0, 0};
-        if (32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = lds_read16(qtile + (wave * 32 + r * 16 + l15) * CS + hd * DH + 32 * ks + 8 * g);
+        if (32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = lds_read16(qtile + (wave * WR + r * 16 + l15) * CS + hd * DH + 32 * ks + 8 * g);
       }
     for (int kc = 0; kc < nkc; ++kc) {
       __syncthreads();  // every wave finished reading the previous chunk (first chunk: the zero fill and the ones column are in place)
@@ -137,21 +144,21 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
       for (int half = 0; half < 2; ++half) {
         const T* Kh = Ks + half * 64 * KS;
         const T* Vh = Vs + half * 64 * VS;
-        f32x4 s[2][4];
+        f32x4 s[FM][4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          s[0][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          s[1][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < FM; ++r) s[r][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
             const Pack8 kf = lds_read16(Kh + (16 * f + l15) * KS + 32 * ks + 8 * g);
-            s[0][f] = mfma16<T>(kf, qfr[0][ks], s[0][f]);
-            s[1][f] = mfma16<T>(kf, qfr[1][ks], s[1][f]);
+#pragma unroll
+            for (int r = 0; r < FM; ++r) s[r][f] = mfma16<T>(kf, qfr[r][ks], s[r][f]);
           }
         }
-        float m_new[2];
+        float m_new[FM];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < FM; ++r) {
           float mt = ATT_NEG;
           if (TAIL) {
 #pragma unroll
@@ -182,9 +189,9 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          Pack8 pf[2];
+          Pack8 pf[FM];
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
+          for (int r = 0; r < FM; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float p0, p1;
@@ -206,19 +213,19 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
             const Pack4 hi = lds_read_tr16(Vh + (krow + 16) * VS + 16 * nd + dcol);
             Pack8 vf;
             vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
-            oacc[0][nd] = mfma16<T>(vf, pf[0], oacc[0][nd]);
-            oacc[1][nd] = mfma16<T>(vf, pf[1], oacc[1][nd]);
+#pragma unroll
+            for (int r = 0; r < FM; ++r) oacc[r][nd] = mfma16<T>(vf, pf[r], oacc[r][nd]);
           }
         }
       }
     }
     // denominator = O^T row DH (the ones column), normalise, round, store the wave's 32 rows of this head
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < FM; ++r) {
       constexpr int DL = DH & 15;
       const float den = __shfl(oacc[r][DH >> 4][DL & 3], l15 + 16 * (DL >> 2));
       const float inv = 1.0f / den;
-      const int m = m0 + wave * 32 + r * 16 + l15;
+      const int m = m0 + wave * WR + r * 16 + l15;
       if (m < p.M) {
         T* orow = p.att_out + (size_t)m * p.att_ldo + (size_t)h * DH;
 #pragma unroll

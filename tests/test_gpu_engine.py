@@ -504,7 +504,7 @@ def test_layernorm_folded_into_the_consumer_gemms(monkeypatch):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
 def test_latency_tiles_for_few_rows_are_the_same_arithmetic(monkeypatch, dtype, tol):
-    """with few rows (batch 1-4) every GEMM outside the attention-fused query projections runs on 64 x 144 tiles (gemm3s.h latency variant, the product
+    """with few rows (batch 1-4) every GEMM, the attention-fused query projections included, runs on 64 x 144 tiles (gemm3s.h latency variant, the product
     default; this suite switches it off elsewhere, conftest.py).  Same K order, same epilogues, same per-tile row statistics for the folded LayerNorm: per-step outputs
     and the whole-loop latents must equal the 256-row kernels' bit for bit -- and are held to the oracle here as well."""
     from ecad_amd.engine import EcadEngine

@@ -288,7 +288,7 @@ def test_attention_generic_kernel(dtype_name, dh, Nq, Nk, masked):
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("kind,Bt,Ntok,Nk", [("self", 3, 256, 256), ("self", 2, 1024, 1024), ("self", 1, 4096, 4096), ("cross", 3, 256, 120), ("cross", 2, 1024, 300),
                                             ("cross", 2, 256, 1)])
-def test_query_projection_with_attention_in_its_tail(dtype_name, kind, Bt, Ntok, Nk):
+def test_query_projection_with_attention_in_its_tail(monkeypatch, dtype_name, kind, Bt, Ntok, Nk):
     """gemm3s_attn.h through ecad_op_qproj_attention: the launch the engine uses for attention on the 256 / 1024 / 4096-token geometries -- the Q projection
     (256 x 144 tiles = one sample x two heads) with softmax(Q K^T / sqrt(72) + bias) V of its rows in the GEMM tail.  Reference: fp32 projection of the
     rounded inputs, Q rounded to the storage type (the value the separate launches pass through HBM), fp32 attention.  Judged per 256 x 144 output tile
@@ -318,6 +318,10 @@ def test_query_projection_with_attention_in_its_tail(dtype_name, kind, Bt, Ntok,
     q2 = eng.op_gemm_ex("tile144", site, 0, x, wq, bq)
     two = eng.op_attention(q2, k, v, Bt, H, Ntok, Nk, dh, bias=bias, kernel="shared")
     assert torch.equal(out, two)
+    # few rows (all of these cases): the product default runs the same tail on 64 x 144 latency tiles -- 64 query rows x two heads per workgroup
+    monkeypatch.setenv("ECAD_LATENCY_TILES", "1")
+    lat = small_engine(dtype_name)
+    assert torch.equal(lat.op_qproj_attention(site, x, wq, bq, k, v, Bt, Ntok, Nk, key_bias=bias), out)
 
 
 def test_query_projection_with_attention_refuses_other_geometries():

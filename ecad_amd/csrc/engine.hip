@@ -314,6 +314,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : strcmp(at, "dma4") == 0 ? 2 : 0; }
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_LATENCY_FILL")) latency_fill = atoi(l) > 0 ? atoi(l) : latency_fill;
     if (const char* l = getenv("ECAD_ATTN_WIDE")) attn_wide = atoi(l) != 0;
     if (const char* gh = getenv("ECAD_GEMM_HALF")) {  // A/B switch: 1 = the two attention out-projections, 2 = + FF2, 3 = + cross-attention Q when it runs unfused
       const int lv = atoi(gh);
@@ -1167,8 +1168,9 @@ template <typename T> class EngineT : public EngineBase {
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
   bool latency_tiles = true;
+  int latency_fill = 50;  // "few" = the 256-row tiles of the launch cover at most this percentage of the CUs (env ECAD_LATENCY_FILL)
   bool g3q_attr[4][KC_COUNT] = {};
-  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * 2 <= num_cus; }
+  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * 100 <= num_cus * latency_fill; }
   template <int EPI, int TAG> int launch_quarter(const GemmArgs<T>& g, hipStream_t s) {
     if (!g3q_attr[EPI][TAG]) {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));

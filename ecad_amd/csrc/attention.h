@@ -196,8 +196,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs p) {
             for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[f][e]);
           mt *= p.scale_log2e;  // scale > 0: max commutes with it
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 16));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mt = rows_max(mt);
         const float m_new = fmaxf(m_r, mt);
         const float alpha = fast_exp2(m_r - m_new);
         m_r = m_new;

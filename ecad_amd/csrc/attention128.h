@@ -237,8 +237,7 @@ __global__ __launch_bounds__(512) void attn128_kernel(const AttnArgs p) {
               for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[r][f][e]);
             mt *= p.scale_log2e;
           }
-          mt = fmaxf(mt, __shfl_xor(mt, 16));
-          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          mt = rows_max(mt);
           m_new[r] = fmaxf(m_run[r], mt);
           // the running maximum stops growing after the first chunks of a long key sequence: alpha == exp2(0) == 1.0 exactly for every lane then, and
           // skipping the rescale of the 2 x ND accumulator fragments is bit-identical (wave-uniform branch)

@@ -35,6 +35,29 @@
 
 namespace ecad {
 
+// Timing-only ablations for scripts/probe_attention.hip (never defined in the product build; results are wrong by design): bit 0 no exponential, 1 one K fragment
+// read per K-step instead of four, 2 one V fragment read per 32 keys instead of ND, 3 no DMA after the first chunk, 4 no S MFMAs, 5 no PV MFMAs, 6 no barrier.
+#ifndef ATT_ABL
+#define ATT_ABL 0
+#endif
+// Probe switches (scripts/probe_attention.hip): ATT_KSWZ -- d_h 128 K image in unpadded 256-byte rows with the 16-byte column XOR-swizzled by the row (conflict-free
+// ds_read_b128; the padded 272-byte rows are 2-way on one slot per lane group); ATT_DMA_STAGGER -- waves 4-7 issue their DMA pieces after the first 64 keys.
+#ifndef ATT_KSWZ
+#define ATT_KSWZ 0
+#endif
+#ifndef ATT_DMA_STAGGER
+#define ATT_DMA_STAGGER 0
+#endif
+// ATT_STAMP: wave 0 of workgroup 0 sums s_memtime deltas per loop phase into p.bias (reused as a u64[8] debug buffer): wait+barrier, DMA issue, S, softmax, PV, units
+#ifndef ATT_STAMP
+#define ATT_STAMP 0
+#endif
+// ATT_KPREF 1: all K fragments of a 64-key unit requested in one batch in front of the unit's S MFMAs (one exposed LDS latency per unit instead of one per pair of
+// reads); 2: the batch of the chunk's second unit is requested before the first unit's softmax and PV (two query fragments per wave only: 64 more registers)
+#ifndef ATT_KPREF
+#define ATT_KPREF 0
+#endif
+
 template <int DHC> constexpr int attn_dma_image_bytes() { return A128_KC * (AttCfg<DHC>::KS + AttCfg<DHC>::VS) * 2; }
 template <int DHC> constexpr int attn_dma_lds_bytes() { return 2 * attn_dma_image_bytes<DHC>(); }
 static_assert(attn_dma_lds_bytes<128>() <= 160 * 1024, "two images of the d_h 128 chunk");
@@ -43,7 +66,8 @@ static_assert(attn_dma_lds_bytes<128>() <= 160 * 1024, "two images of the d_h 12
 // chunk is staged once for twice the rows; fits the 72-wide head only -- d_h 128 would need 144 accumulator + 64 query + 64 score registers).  DESIGN 5d.
 template <typename T, int DHC, int R = 2>
 __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
-  constexpr int KC = A128_KC, KS = AttCfg<DHC>::KS, VS = AttCfg<DHC>::VS, DH = DHC, ND = AttCfg<DHC>::ND, KSTEPS = AttCfg<DHC>::KSTEPS;
+  constexpr bool KSWZ = ATT_KSWZ && DHC == 128;
+  constexpr int KC = A128_KC, KS = KSWZ ? 128 : AttCfg<DHC>::KS, VS = AttCfg<DHC>::VS, DH = DHC, ND = AttCfg<DHC>::ND, KSTEPS = AttCfg<DHC>::KSTEPS;
   constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0);
   constexpr int KPR = KS / 8, VPR = VS / 8;        // 16-byte pieces per image row
   constexpr int KDATA = DH / 8, VDATA = DH / 8;    // of which carry data
@@ -85,7 +109,7 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
     const int piece = (isv ? inst - K_INST : inst) * 64 + lane;
     const int row = piece / (isv ? VPR : KPR), col = piece - row * (isv ? VPR : KPR);
     live[j] = inst < N_INST && col < (isv ? VDATA : KDATA);
-    off[j] = (unsigned)(((size_t)row * (isv ? p.ldv : p.ldk) + col * 8) * sizeof(T));
+    off[j] = (unsigned)(((size_t)row * (isv ? p.ldv : p.ldk) + ((KSWZ && !isv) ? (col ^ (row & 15)) : col) * 8) * sizeof(T));
   }
   auto issue_chunk = [&](int item, int kc, int buf) {
     const int bh = item / nqb;
@@ -129,33 +153,65 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
         if (qloc < q_cnt && qrow < p.Nq && 32 * ks + 8 * g + 8 <= DH) qfr[r][ks] = gload16(Q + att_row(b, qrow, p.Nq, p.seg_t, p.seg_bt) * p.ldq + (size_t)h * DH + 32 * ks + 8 * g);
       }
     }
+#if ATT_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define ATT_ST(i) { asm volatile("" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#else
+#define ATT_ST(i)
+#endif
     for (int kc = 0; kc < nkc; ++kc) {
       // this wave's pieces of chunk kc have landed (they are the newest DMA it issued); after the barrier everybody's have, and nobody reads the other image
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(ATT_ABL & 64)) __builtin_amdgcn_s_barrier();
+      ATT_ST(0)
       const T* Ks = reinterpret_cast<const T*>(att_smem + buf * IMG);
       const T* Vs = Ks + KC * KS;
       const bool more = kc + 1 < nkc;
       const int n_item = more ? item : item + (int)gridDim.x, n_kc = more ? kc + 1 : 0;
       const bool any_next = n_item < items;
-      if (any_next) issue_chunk(n_item, n_kc, buf ^ 1);
+      const bool do_issue = any_next && !((ATT_ABL & 8) && (kc > 0 || item != (int)blockIdx.x));
+      if (do_issue && !(ATT_DMA_STAGGER && wave >= 4)) issue_chunk(n_item, n_kc, buf ^ 1);
 
-#pragma unroll 1
+      ATT_ST(1)
+      constexpr int KPREF = R <= 2 ? ATT_KPREF : 0;
+      Pack8 kfa[KPREF ? 4 : 1][KPREF ? KSTEPS : 1];
+      auto load_k = [&](const T* Kh) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks)
+            kfa[KPREF ? f : 0][KPREF ? ks : 0] = lds_read16(Kh + (16 * f + l15) * KS + (KSWZ ? ((4 * ks + g) ^ l15) * 8 : 32 * ks + 8 * g));
+      };
+      if constexpr (KPREF == 2) { load_k(Ks); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll KPREF == 2 ? 2 : 1
       for (int half = 0; half < 2; ++half) {
+        if (ATT_DMA_STAGGER && half == 1 && wave >= 4 && do_issue) issue_chunk(n_item, n_kc, buf ^ 1);
         const T* Kh = Ks + half * 64 * KS;
         const T* Vh = Vs + half * 64 * VS;
         f32x4 s[R][4];
+        if constexpr (KPREF == 1) { load_k(Kh); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
 #pragma unroll
           for (int r = 0; r < R; ++r) s[r][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
-            const Pack8 kf = lds_read16(Kh + (16 * f + l15) * KS + 32 * ks + 8 * g);
+            Pack8 kf;
+            if constexpr (KPREF) kf = kfa[f][ks];
+            else kf = lds_read16(Kh + (16 * ((ATT_ABL & 2) ? 0 : f) + l15) * KS + (KSWZ ? ((4 * ks + g) ^ l15) * 8 : 32 * ks + 8 * g));
 #pragma unroll
-            for (int r = 0; r < R; ++r) s[r][f] = mfma16<T>(kf, qfr[r][ks], s[r][f]);
+            for (int r = 0; r < R; ++r) {
+              if (ATT_ABL & 16) s[r][f][ks & 3] += __builtin_bit_cast(float, kf.u[0] & 0x3f800000u) * __builtin_bit_cast(float, qfr[r][ks].u[1] & 0x3f800000u);
+              else s[r][f] = mfma16<T>(kf, qfr[r][ks], s[r][f]);
+            }
           }
         }
+        if constexpr (KPREF == 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (half == 0) { load_k(Ks + 64 * KS); __builtin_amdgcn_sched_barrier(0); }
+        }
+        ATT_ST(2)
         float m_new[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -165,8 +221,7 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[r][f][e]);
           mt *= p.scale_log2e;
-          mt = fmaxf(mt, __shfl_xor(mt, 16));
-          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          mt = rows_max(mt);
           m_new[r] = fmaxf(m_run[r], mt);
           if (__builtin_amdgcn_ballot_w64(m_new[r] > m_run[r]) != 0) {  // exact: alpha == 1.0 when no lane's maximum grew (attention128.h)
             const float alpha = fast_exp2(m_run[r] - m_new[r]);
@@ -177,6 +232,7 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
           }
           m_run[r] = m_new[r];
         }
+        ATT_ST(3)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           Pack8 pf[R];
@@ -184,8 +240,9 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
           for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float p0 = fast_exp2(__builtin_fmaf(s[r][2 * s2][e], p.scale_log2e, -m_new[r]));
-              const float p1 = fast_exp2(__builtin_fmaf(s[r][2 * s2 + 1][e], p.scale_log2e, -m_new[r]));
+              float p0 = __builtin_fmaf(s[r][2 * s2][e], p.scale_log2e, -m_new[r]);
+              float p1 = __builtin_fmaf(s[r][2 * s2 + 1][e], p.scale_log2e, -m_new[r]);
+              if (!(ATT_ABL & 1)) { p0 = fast_exp2(p0); p1 = fast_exp2(p1); }
               float_to_elem<T>(pf[r], e, p0);
               float_to_elem<T>(pf[r], 4 + e, p1);
             }
@@ -193,17 +250,29 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
           const int dcol = 4 * (l15 & 3);
 #pragma unroll
           for (int nd = 0; nd < ND; ++nd) {
-            const Pack4 lo = lds_read_tr16(Vh + krow * VS + 16 * nd + dcol);
-            const Pack4 hi = lds_read_tr16(Vh + (krow + 16) * VS + 16 * nd + dcol);
+            const Pack4 lo = lds_read_tr16(Vh + krow * VS + 16 * ((ATT_ABL & 4) ? 0 : nd) + dcol);
+            const Pack4 hi = lds_read_tr16(Vh + (krow + 16) * VS + 16 * ((ATT_ABL & 4) ? 0 : nd) + dcol);
             Pack8 vf;
             vf.u = (u32x4){lo.u[0], lo.u[1], hi.u[0], hi.u[1]};
 #pragma unroll
-            for (int r = 0; r < R; ++r) oacc[r][nd] = mfma16<T>(vf, pf[r], oacc[r][nd]);
+            for (int r = 0; r < R; ++r) {
+              if (ATT_ABL & 32) oacc[r][nd][0] += __builtin_bit_cast(float, vf.u[0] & 0x3f800000u) * __builtin_bit_cast(float, pf[r].u[nd & 3] & 0x3f800000u);
+              else oacc[r][nd] = mfma16<T>(vf, pf[r], oacc[r][nd]);
+            }
           }
         }
+        ATT_ST(4)
       }
       buf ^= 1;
     }
+#if ATT_STAMP
+    if (blockIdx.x == 0 && tid == 0 && item == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias));
+      for (int i = 0; i < 5; ++i) dbg[i] = st_acc[i];
+      dbg[5] = 2ull * nkc;
+      dbg[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       constexpr int DL = DH & 15;

@@ -137,6 +137,19 @@ ECAD_DEV f32x2 gelu_tanh2(f32x2 x) {
   const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + (f32x2){1.0f, 1.0f};
   return x * (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
+// max over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the four 16-lane rows of a wave: the lanes that hold one query row's scores in the attention kernels) without
+// the LDS: __shfl_xor compiles to ds_bpermute_b32, a round trip through the LDS queue behind every fragment read and DMA write of the workgroup (stamped: the
+// row-maximum phase of a 64-key unit took ~1000 cycles).  v_permlane16_swap_b32 a, b exchanges the odd rows of a with the even rows of b, v_permlane32_swap_b32
+// the upper half of a with the lower half of b (gfx950); with b a copy of a, max(a, b) afterwards is the xor-16 / xor-32 butterfly.  Inline asm because the
+// clang builtin returns the first result for both elements here (ROCm 7.2); the s_nop covers the VALU-write -> permlane-read hazard the assembler cannot see.
+ECAD_DEV float rows_max(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a = fmaxf(a, b);
+  b = a;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
 ECAD_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 ECAD_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 

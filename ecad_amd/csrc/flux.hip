@@ -944,27 +944,35 @@ template <typename T> class FluxT : public FluxBase {
     const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
     const int grid = items < num_cus ? items : num_cus;
     if (!attn_generic && attn_dma && a.Nk % 128 == 0 && a.seg_t % 128 == 0) {  // attention_dma.h: same arithmetic, chunks by LDS-DMA, one barrier per chunk
+      const bool split = attn_dma == 2;
+      const int lds_dma = attn_dma_lds_bytes<128>();
+      const void* k2 = (const void*)attn_dma_kernel<T, 128, 2>;
+      const void* k1 = (const void*)attn_dma_kernel<T, 128, 1>;
       if (!attn_dma_attr[0]) {
-        FHIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<128>()));
-        FHIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<128>()));
+        FHIPCHK(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
+        FHIPCHK(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
         attn_dma_attr[0] = true;
       }
-      // Tile-count quantisation: FLUX-1024 has 864 work items of 256 query rows on 256 CUs = 3.375 rounds, i.e. the launch takes 4.  With attn_dma == 2 the
+      auto launch = [&](const void* fn, int n_items, const AttnArgs& aa) {
+        AttnArgs arg = aa;
+        void* params[] = {&arg};
+        return hipLaunchKernel(fn, dim3(n_items < num_cus ? n_items : num_cus), dim3(512), params, lds_dma, s);
+      };
+      // Tile-count quantisation: FLUX-1024 has 864 work items of 256 query rows on 256 CUs = 3.375 rounds, i.e. the launch takes 4.  Split: the
       // whole rounds run as they are and the rest of every (sample, head) as 128-row items (one query fragment per wave, half the MFMAs per item, the same K / V
       // stream) in a second launch that all CUs share: 3 + ~0.6 rounds.
       const int per_bh = (a.Nq + ATT_QB - 1) / ATT_QB;
       const int whole = (items / num_cus) * num_cus;                       // items in whole rounds
       const int keep_qb = whole / (a.B * a.H);                             // 256-row blocks per (sample, head) that stay
-      if (attn_dma == 2 && items > num_cus && items % num_cus != 0 && keep_qb >= 1 && keep_qb < per_bh && whole == keep_qb * a.B * a.H) {
+      if (split && items > num_cus && items % num_cus != 0 && keep_qb >= 1 && keep_qb < per_bh && whole == keep_qb * a.B * a.H) {
         AttnArgs a1 = a, a2 = a;
         a1.q_off = 0; a1.q_cnt = keep_qb * ATT_QB;
         a2.q_off = keep_qb * ATT_QB; a2.q_cnt = a.Nq - a2.q_off;
-        hipLaunchKernelGGL((attn_dma_kernel<T, 128, 2>), dim3(num_cus), dim3(512), attn_dma_lds_bytes<128>(), s, a1);
-        const int items2 = a.B * a.H * ((a2.q_cnt + 127) / 128);
-        hipLaunchKernelGGL((attn_dma_kernel<T, 128, 1>), dim3(items2 < num_cus ? items2 : num_cus), dim3(512), attn_dma_lds_bytes<128>(), s, a2);
+        FHIPCHK(launch(k2, num_cus, a1));
+        FHIPCHK(launch(k1, a.B * a.H * ((a2.q_cnt + 127) / 128), a2));
         return ECAD_OK;
       }
-      hipLaunchKernelGGL((attn_dma_kernel<T, 128, 2>), dim3(grid), dim3(512), attn_dma_lds_bytes<128>(), s, a);
+      FHIPCHK(launch(k2, items, a));
       return ECAD_OK;
     }
     if (!attn_generic) {  // attention128.h: both query fragments of a wave share every K / V fragment read

@@ -177,8 +177,7 @@ ECAD_DEV void g3_attention_epilogue(const GemmArgs<T>& p, char* smem, int m0, in
               for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[r][f][e]);
             mt *= p.att_scale_log2e;
           }
-          mt = fmaxf(mt, __shfl_xor(mt, 16));
-          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          mt = rows_max(mt);
           m_new[r] = fmaxf(m_run[r], mt);
           const float alpha = fast_exp2(m_run[r] - m_new[r]);
           m_run[r] = m_new[r];

@@ -42,7 +42,7 @@ def flux():
         for mode, eng in engs.items():
             out = eng.op_attention(qkv, B, T, N)
             us = timeit(lambda: eng.op_attention(qkv, B, T, N), 10)
-            print(f"FLUX joint S={T + N} {mode:7s}: {us:7.1f} us  {flops / us / 1e6:5.0f} TF  bit-identical to attention128.h: {torch.equal(out, ref)}  finite {bool(torch.isfinite(out.float()).all())}", flush=True)
+            print(f"FLUX joint S={T + N} {mode:10s}: {us:7.1f} us  {flops / us / 1e6:5.0f} TF  bit-identical to attention128.h: {torch.equal(out, ref)}  finite {bool(torch.isfinite(out.float()).all())}", flush=True)
 
 
 def pixart(B, N, label):
@@ -62,7 +62,7 @@ def pixart(B, N, label):
         for mode, eng in engs.items():
             out = run(eng)
             us = timeit(lambda: run(eng), 10 if N > 1000 else 50)
-            print(f"{label} Bt={B} N={N} {mode:7s}: {us:7.1f} us  {flops / us / 1e6:5.0f} TF  bit-identical: {torch.equal(out, ref)}", flush=True)
+            print(f"{label} Bt={B} N={N} {mode:10s}: {us:7.1f} us  {flops / us / 1e6:5.0f} TF  bit-identical: {torch.equal(out, ref)}", flush=True)
 
 
 if __name__ == "__main__":

@@ -74,6 +74,9 @@ template <typename T> struct VaeT : VaeBase {
   int cap_B = 0, cap_h = 0, cap_w = 0;
   bool finalized = false;
   bool async_failed = false;  // an asynchronous call inside a void helper failed: decode() turns it into ECAD_E_HIP
+  static constexpr int GN_MAX_BLOCKS = 2048;  // 1024 x 1024 pixels at 512 per block
+  bool conv_tile128 = false;  // env ECAD_VAE_CONV=tile128: every convolution on the 128 x 128 kernel (A/B against conv3s_kernel)
+  int num_cus = 256;
 
   ~VaeT() override {
     (void)hipSetDevice(dev);  // teardown: nothing to report an error to
@@ -131,6 +134,10 @@ template <typename T> struct VaeT : VaeBase {
     REG("decoder.conv_norm_out.weight", F32, 128, 0) REG("decoder.conv_norm_out.bias", F32, 128, 0)
     REG("decoder.conv_out.weight", CONVOUT, 3, 128) REG("decoder.conv_out.bias", F32, 3, 0)
     VHIPCHK(hipFuncSetAttribute((const void*)conv_gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv3s_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES));
+    if (const char* e = getenv("ECAD_VAE_CONV")) conv_tile128 = strcmp(e, "tile128") == 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount;
     return ECAD_OK;
   }
 
@@ -187,7 +194,7 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipMalloc((void**)&bufB, act_elems * sizeof(T)));
     VHIPCHK(hipMalloc((void**)&bufC, act_elems * sizeof(T)));
     VHIPCHK(hipMalloc((void**)&bufD, (attn_elems > act_elems ? attn_elems : act_elems) * sizeof(T)));
-    VHIPCHK(hipMalloc((void**)&gn_sums, (size_t)B * 512 * 2 * sizeof(float)));
+    VHIPCHK(hipMalloc((void**)&gn_sums, (size_t)B * GN_MAX_BLOCKS * 64 * sizeof(float)));  // per-block partial (sum, sum of squares) of the 32 groups
     VHIPCHK(hipMalloc((void**)&gn_scale, (size_t)B * 512 * sizeof(float)));
     VHIPCHK(hipMalloc((void**)&gn_shift, (size_t)B * 512 * sizeof(float)));
     cap_B = B; cap_h = h; cap_w = w;
@@ -202,16 +209,22 @@ template <typename T> struct VaeT : VaeBase {
     a.in = in; a.w = w_override ? w_override : W_<T>(name + ".weight"); a.bias = no_bias ? nullptr : (b_override ? b_override : W_<float>(name + ".bias"));
     a.resid = resid; a.out = out; a.zero_page = zero_page; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = taps; a.up = up;
     const int M = B * H * W;
+    // 256 x 128 tiles with the 3-stage K loop (conv3s_kernel) once they fill the chip; the 128 x 128 kernel for the small launches (mid-block attention, 8 x 8 latents)
+    if (!conv_tile128 && ((M + C3_BM - 1) / C3_BM) * (cout / C3_BN) >= num_cus && (taps * cin) / 64 >= 4) {
+      hipLaunchKernelGGL((conv3s_kernel<T>), dim3(((M + C3_BM - 1) / C3_BM) * (cout / C3_BN)), dim3(C3_NW * 64), C3_LDS_BYTES, s, a);
+      return ECAD_OK;
+    }
     const int tiles = ((M + 127) / 128) * (cout / 128);
     hipLaunchKernelGGL((conv_gemm_kernel<T>), dim3(tiles), dim3(256), 65536, s, a);
     return ECAD_OK;
   }
   // statistics -> per-(image, channel) scale/shift in gn_scale / gn_shift
   void group_norm_stats(const T* x, const std::string& name, int B, int HW, int C, hipStream_t s) {
-    if (hipMemsetAsync(gn_sums, 0, (size_t)B * 32 * 2 * sizeof(float), s) != hipSuccess) async_failed = true;  // reported by decode()
     const int ppb = HW >= 16384 ? 512 : HW >= 4096 ? 256 : 64;
-    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, x, gn_sums, HW, C, 32, ppb);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, gn_sums, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
+    const int nblk = (HW + ppb - 1) / ppb;
+    if (nblk > GN_MAX_BLOCKS) { async_failed = true; return; }  // reported by decode()
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nblk, B), dim3(256), 0, s, x, gn_sums, HW, C, 32, ppb);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, gn_sums, nblk, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
   }
   void group_norm(const T* x, T* y, const std::string& name, int B, int HW, int C, bool act, hipStream_t s) {
     group_norm_stats(x, name, B, HW, C, s);

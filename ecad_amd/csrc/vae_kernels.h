@@ -159,19 +159,244 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   }
 }
 
+// conv3s_kernel -- the K loop of gemm3s.h on the implicit-GEMM convolution (round 3): 256 x 128 x 64 tiles, eight waves of 64 x 64 (4 x 2), a 3-stage LDS-DMA
+// ring with counted vmcnt (a stage has two K-steps to land), the second fragment set of a step consumed after the next step's barrier, and the six DMA pieces
+// of a wave issued one per pair of MFMAs -- waves 0-3 beside the carried set, waves 4-7 (their SIMD partners) beside the step's first set -- instead of in
+// one block after the barrier.  The A rows are gathered as in conv_gemm_kernel (per-lane source address, zero page for the padding, nearest-2x upsample in
+// the address); a piece's source advances by 64 channels per K-step and is recomputed when the step enters the next tap.  Same accumulation order per output
+// as conv_gemm_kernel (K ascending, fp32), same epilogue arithmetic: the two kernels give identical outputs.  The engine launches it when the pixel count
+// fills 256-row tiles (env ECAD_VAE_CONV=tile128 keeps the 128 x 128 kernel everywhere).
+constexpr int C3_BM = 256, C3_BN = 128, C3_NW = 8, C3_STAGES = 3;
+constexpr int C3_STAGE_BYTES = (C3_BM + C3_BN) * 128;        // 49 152
+constexpr int C3_LDS_BYTES = C3_STAGES * C3_STAGE_BYTES;     // 147 456 (the C tile, 256 x 136 x 2 = 69 632, reuses the ring)
+
+template <typename T>
+__global__ __launch_bounds__(C3_NW * 64, 2) void conv3s_kernel(const ConvArgs p) {
+  constexpr int BM = C3_BM, BN = C3_BN, BK = 64, FM = 4, FN = 4, NSTG = C3_STAGES;
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = C3_STAGE_BYTES;
+  constexpr int A_INST = BM / 8 / C3_NW, B_INST = BN / 8 / C3_NW;  // 4 + 2 one-KiB pieces per wave and stage
+  constexpr int VMW = A_INST + B_INST, CS = BN + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int M = p.B * p.H * p.W;
+  const int tiles_n = p.Cout / BN;
+  const int tiles_m = (M + BM - 1) / BM;
+  int bid = blockIdx.x;
+  {  // workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles: neighbours in n share their A rows in that XCD's L2
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int K = p.taps * p.Cin;
+  const int Hin = p.up ? p.H >> 1 : p.H, Win = p.up ? p.W >> 1 : p.W;
+  const T* in = reinterpret_cast<const T*>(p.in);
+  const T* wgt = reinterpret_cast<const T*>(p.w);
+
+  int pb[A_INST], py[A_INST], px[A_INST], pc[A_INST];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
+    int m = m0 + r;
+    m = m < M ? m : M - 1;
+    pb[i] = m / (p.H * p.W);
+    const int rem = m - pb[i] * p.H * p.W;
+    py[i] = rem / p.W;
+    px[i] = rem - py[i] * p.W;
+    pc[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  }
+  const T* a_cur[A_INST];
+  int a_inc[A_INST];  // elements per K-step: 64 inside the image, 0 on the zero page
+  const T* b_src[B_INST];
+#pragma unroll
+  for (int i = 0; i < B_INST; ++i) {
+    const int r = (wave * B_INST + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = wgt + (size_t)(n0 + r) * K + c * 8;
+  }
+  int tap = 0, c0 = 0;  // of the next stage to issue
+  auto set_tap = [&]() {
+    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      const int sy = p.up ? yy >> 1 : yy, sx = p.up ? xx >> 1 : xx;
+      a_cur[i] = ok ? in + ((size_t)(pb[i] * Hin + sy) * Win + sx) * p.Cin + pc[i] : reinterpret_cast<const T*>(p.zero_page) + (pc[i] & 56);
+      a_inc[i] = ok ? BK : 0;
+    }
+  };
+  auto advance = [&]() {  // the sources of the stage after the one just issued
+    c0 += BK;
+    if (c0 == p.Cin) {
+      c0 = 0;
+      ++tap;
+      if (tap < p.taps) set_tap();
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_INST; ++i) a_cur[i] += a_inc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_INST; ++i) b_src[i] += BK;
+  };
+  auto issue_one = [&](int stg, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    char* abase = smem + stg * STAGE_BYTES;
+    if constexpr (q < A_INST) glds16(a_cur[q], abase + (wave * A_INST + q) * 1024);
+    else glds16(b_src[q - A_INST], abase + A_BYTES + (wave * B_INST + (q - A_INST)) * 1024);
+  };
+  auto issue_all = [&](int stg) { static_for<VMW>([&](auto qc) { issue_one(stg, qc); }); };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int swz = (l15 >> 1) & 7;
+  const int a_row_off = (wm * 64 + l15) * 128, b_row_off = (wn * 64 + l15) * 128;
+  const int nk = K / BK;
+  set_tap();
+  issue_all(0);
+  advance();
+  if (nk > 1) { issue_all(1); advance(); }
+
+  f32x4 bvs[FN];
+  auto load_bias = [&]() {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + 16 * j + 4 * g);
+    }
+  };
+  int stage = 0;
+  Pack8 afp[FM], wfp[FN];  // second fragment set of a step: multiplied after the NEXT step's barrier
+  auto step_top = [&](int kt) {
+    if (kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");  // only the newest stage's pieces of this wave may still be in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto read_set = [&](Pack8 (&af)[FM], Pack8 (&wf)[FN], int stg, int half) {
+    const char* abase = smem + stg * STAGE_BYTES;
+    const char* bbase = abase + A_BYTES;
+    const int coff = ((half * 4 + g) ^ swz) * 16;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
+  };
+  auto mfma_all = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM]) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+  };
+  auto next_stage = [&]() { int ns = stage + NSTG - 1; return ns >= NSTG ? ns - NSTG : ns; };
+  auto step_block = [&](int kt) {
+    step_top(kt);
+    Pack8 af0[FM], wf0[FN];
+    read_set(af0, wf0, stage, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NSTG - 1 < nk) { issue_all(next_stage()); advance(); }
+    if (kt == nk - 2) load_bias();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt > 0) mfma_all(wfp, afp);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(afp, wfp, stage, 1);
+    mfma_all(wf0, af0);
+    stage = stage + 1 >= NSTG ? 0 : stage + 1;
+  };
+  // 16 MFMAs of a fragment set in 8 pairs, one DMA piece in front of each of the first six pairs on the waves whose turn it is
+  auto mfma_dma = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM], int ns, bool mine) {
+    static_for<8>([&](auto gc) {
+      constexpr int gi = decltype(gc)::value;
+      if constexpr (gi < VMW) {
+        if (mine) issue_one(ns, gc);
+      }
+      static_for<2>([&](auto tc) {
+        constexpr int idx = gi * 2 + decltype(tc)::value;
+        constexpr int j = idx / FM, i = idx - j * FM;
+        acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  auto step_stagger = [&](int kt) {
+    step_top(kt);
+    Pack8 af0[FM], wf0[FN];
+    read_set(af0, wf0, stage, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int ns = next_stage();
+    const bool early = wave < C3_NW / 2;
+    mfma_dma(wfp, afp, ns, early);
+    read_set(afp, wfp, stage, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_dma(wf0, af0, ns, !early);
+    advance();
+    stage = stage + 1 >= NSTG ? 0 : stage + 1;
+  };
+  {
+    int kt = 0;
+    step_block(kt++);
+    for (; kt + 2 < nk; ++kt) step_stagger(kt);
+    for (; kt < nk; ++kt) step_block(kt);
+  }
+  mfma_all(wfp, afp);
+  if (nk < 2) load_bias();
+
+  // epilogue: bias in fp32, round, C tile through LDS (the ring: everybody must have left the K loop), 16-byte row stores (+ residual)
+  __syncthreads();
+  T* ctile = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nl = wn * 64 + 16 * j + 4 * g;
+    const f32x4 bv = bvs[j];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wm * 64 + 16 * i + l15;
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) float_to_elem4<T>(o, r, acc[i][j][r] + bv[r]);
+      *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
+    }
+  }
+  __syncthreads();
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* res = reinterpret_cast<const T*>(p.resid);
+  const int cchunk = tid & 15, crow0 = tid >> 4;
+#pragma unroll 4
+  for (int pass = 0; pass < BM / 32; ++pass) {
+    const int ml = pass * 32 + crow0;
+    const int m = m0 + ml;
+    if (m >= M) break;
+    Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+    const size_t off = (size_t)m * p.Cout + n0 + cchunk * 8;
+    if (res) {
+      float a[8], b[8];
+      unpack8<T>(v, a);
+      unpack8<T>(gload16(res + off), b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+      v = pack8<T>(a);
+    }
+    gstore16(out + off, v);
+  }
+}
+
 // ---- GroupNorm statistics over NHWC: sums[b][group][2] += (sum x, sum x^2).  Per-thread partials are folded per group through
 // LDS atomics (ds_add_f32), so a block issues only 2 * groups global atomics (the first version issued 16 per thread onto
 // C * 2 addresses and ran at 1 ms per call on contention alone).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, int HW, int C, int groups, int pix_per_block) {
-  __shared__ float red[64];
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ block_sums, int HW, int C, int groups, int pix_per_block) {
   const int b = blockIdx.y;
   const int cpr = C >> 3;  // 16-byte chunks per pixel
   const int cg = C / groups;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, HW);
-  if (threadIdx.x < 2 * groups) red[threadIdx.x] = 0.f;
-  __syncthreads();
   // thread t owns channel chunk t % cpr and walks pixels with stride 256 / cpr
   const int c = threadIdx.x % cpr, pstep = 256 / cpr, pofs = threadIdx.x / cpr;
   float s[8], q[8];
@@ -199,31 +424,44 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
 #undef ECAD_GN_ACC
   }
-  if (cg >= 8) {
-    float ts = 0.f, tq = 0.f;
+  // fixed-order reduction (round 3: the first version folded the partials with LDS and global atomics, and two decodes of the same latents differed by one
+  // level on ~7 % of the bytes): every thread leaves its partial sums in LDS, thread t < 2 * groups adds the 256 / groups (x 2 for 4-channel groups)
+  // partials of its (group, sum | sum of squares) in thread order, and the block writes ONE row of per-block partials that gn_finalize_kernel adds in block order.
+  __shared__ float part[256][4];
+  {
+    float lo_s = 0.f, lo_q = 0.f, hi_s = 0.f, hi_q = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ts += s[e], tq += q[e];
-    const int gidx = (c * 8) / cg;
-    atomicAdd(&red[2 * gidx], ts);
-    atomicAdd(&red[2 * gidx + 1], tq);
-  } else {  // cg == 4: the chunk spans two groups
-    const int gidx = (c * 8) / cg;
-    atomicAdd(&red[2 * gidx], s[0] + s[1] + s[2] + s[3]);
-    atomicAdd(&red[2 * gidx + 1], q[0] + q[1] + q[2] + q[3]);
-    atomicAdd(&red[2 * gidx + 2], s[4] + s[5] + s[6] + s[7]);
-    atomicAdd(&red[2 * gidx + 3], q[4] + q[5] + q[6] + q[7]);
+    for (int e = 0; e < 4; ++e) lo_s += s[e], lo_q += q[e], hi_s += s[4 + e], hi_q += q[4 + e];
+    part[threadIdx.x][0] = lo_s; part[threadIdx.x][1] = lo_q; part[threadIdx.x][2] = hi_s; part[threadIdx.x][3] = hi_q;
   }
   __syncthreads();
-  if (threadIdx.x < 2 * groups) atomicAdd(&sums[(size_t)b * groups * 2 + threadIdx.x], red[threadIdx.x]);
+  if (threadIdx.x < 2 * groups) {
+    const int gi = threadIdx.x >> 1, which = threadIdx.x & 1;
+    float tot = 0.f;
+    if (cg >= 8) {
+      const int c_lo = gi * cg / 8, c_hi = (gi + 1) * cg / 8;
+      for (int po = 0; po < pstep; ++po)
+        for (int cc = c_lo; cc < c_hi; ++cc) tot += part[po * cpr + cc][which] + part[po * cpr + cc][2 + which];
+    } else {  // cg == 4: chunk gi / 2, its lower or upper half
+      const int cc = gi >> 1, half = gi & 1;
+      for (int po = 0; po < pstep; ++po) tot += part[po * cpr + cc][2 * half + which];
+    }
+    block_sums[((size_t)b * gridDim.x + blockIdx.x) * groups * 2 + threadIdx.x] = tot;
+  }
 }
 
 // scale[b][c] = rstd * gamma[c], shift[b][c] = beta[c] - mean * rstd * gamma[c]   (eps 1e-6)
-__global__ void gn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void gn_finalize_kernel(const float* __restrict__ block_sums, int nblk, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ scale, float* __restrict__ shift, int C, int HW, int groups, float eps) {
   const int b = blockIdx.x, c = threadIdx.x + blockIdx.y * blockDim.x;
   if (c >= C) return;
   const int cg = C / groups, gi = c / cg;
-  const float s = sums[((size_t)b * groups + gi) * 2], q = sums[((size_t)b * groups + gi) * 2 + 1];
+  float s = 0.f, q = 0.f;
+  for (int k = 0; k < nblk; ++k) {  // block order: the same sum on every launch
+    const float* row = block_sums + ((size_t)b * nblk + k) * groups * 2 + 2 * gi;
+    s += row[0];
+    q += row[1];
+  }
   const float n = (float)HW * (float)cg;
   const float mean = s / n;
   const float var = fmaxf(q / n - mean * mean, 0.f);

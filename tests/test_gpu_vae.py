@@ -41,6 +41,26 @@ def test_hip_vae_decoder_matches_pytorch(B, h, w):
     assert float(d.float().mean()) < 0.6 and frac_bad < 0.01
 
 
+def test_conv3s_tiles_give_the_bytes_of_the_128_tile_kernel_and_decodes_repeat(monkeypatch):
+    """vae_kernels.h: conv3s_kernel (256 x 128 tiles, 3-stage ring, staggered DMA issue) takes every convolution whose tiles fill the chip -- here all of the
+    64^2 .. 256^2 stages (B 3: with a ragged last tile) -- with conv_gemm_kernel's K order and epilogue arithmetic: the image must be the same byte for byte.
+    That is testable because the decoder is reproducible: GroupNorm statistics are reduced in a fixed order (they were summed with atomics until round 3,
+    and two decodes of the same latents differed by one level on ~7 % of the bytes).  The PyTorch comparison above runs on the default, i.e. on conv3s_kernel."""
+    from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
+
+    for B in (4, 3):
+        lat = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(7)) * 0.36
+        out = {}
+        for mode in ("tile128", "conv3s", "conv3s-again"):
+            monkeypatch.setenv("ECAD_VAE_CONV", mode.split("-")[0])
+            vae = HipVaeDecoder.random_init(3, device=0)
+            out[mode] = vae.decode_to_uint8(lat.cuda()).cpu()
+            del vae
+        assert int(out["conv3s"].max()) - int(out["conv3s"].min()) > 60
+        assert torch.equal(out["conv3s"], out["conv3s-again"])
+        assert torch.equal(out["tile128"], out["conv3s"])
+
+
 def test_hip_flux_vae_geometry_matches_pytorch():
     """FLUX VAE: 16 latent channels, no post_quant_conv, z = latents / scaling + shift."""
     from ecad_amd.pipelines.vae_decoder import HipVaeDecoder

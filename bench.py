@@ -591,6 +591,28 @@ def main():
             dt, dt_lat = per_call(png_ready), per_call(latents_only)
             res["png_ready_images_per_s"] = batch / dt
             res["png_ready_ms_per_image"] = 1000.0 * dt / batch
+            if pool is not None:
+                # the same tail with the batches in flight the headline line has (what PixArtAlphaImageGenerator(contexts=N).generate_from_saved_prompts does):
+                # while the host waits for batch i's bytes and builds its PIL images, the other contexts' denoising loops keep the GPU busy
+                def png_ready_in_flight(n_batches):
+                    pend = [pool.submit(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=use_graph) for _ in range(min(len(pool), n_batches))]
+                    left = n_batches - len(pend)
+                    while pend:
+                        lat_k, st_k = pend.pop(0)
+                        torch.cuda.current_stream().wait_stream(st_k)
+                        arr = vae.decode_to_uint8(lat_k).cpu().numpy()
+                        if left > 0:  # this context's output has been consumed: it may start its next batch
+                            pend.append(pool.submit(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=use_graph))
+                            left -= 1
+                        _ = [Image.fromarray(a) for a in arr]
+
+                png_ready_in_flight(len(pool))
+                torch.cuda.synchronize()
+                nb = 3 * len(pool)
+                t1 = time.perf_counter()
+                png_ready_in_flight(nb)
+                torch.cuda.synchronize()
+                res["png_ready_batches_in_flight_images_per_s"] = nb * batch / (time.perf_counter() - t1)
             res["config"]["decode_tail_ms_per_batch"] = 1000.0 * (dt - dt_lat)  # against one batch at a time on the same context
             res["config"]["decode_tail"] = "HIP AutoencoderKL decoder (ecad_vae_decode, random-init SD-VAE geometry) -> uint8 NHWC -> host -> PIL; the reference's 84.09 ms/image (A6000) includes this tail"
             log(f"png-ready: {batch / dt:.1f} img/s")

@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libecad_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ECAD_DTYPE_F16, ECAD_DTYPE_BF16, ECAD_DTYPE_F32 = 0, 1, 2
 ECAD_E_INVALID, ECAD_E_HIP, ECAD_E_NOT_READY, ECAD_E_UNSUPPORTED = -1, -2, -3, -4
@@ -120,6 +120,7 @@ SIGNATURES = {
     "ecad_finalize_weights": (_I, [_P]),
     "ecad_share_weights": (_I, [_P, _P]),
     "ecad_set_ln_fold": (_I, [_P, _I]),
+    "ecad_set_batches_in_flight": (_I, [_P, _I]),
     "ecad_set_fp8": (_I, [_P, _I]),
     "ecad_set_added_cond": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I]),
     "ecad_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),

@@ -70,6 +70,7 @@ struct EngineBase {
   virtual int share_weights(EngineBase* src) = 0;
   virtual int set_fp8(int on) = 0;
   virtual int set_ln_fold(int on) = 0;
+  virtual int set_batches_in_flight(int n) = 0;
   virtual int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
   virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st) = 0;
@@ -314,6 +315,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : strcmp(at, "dma4") == 0 ? 2 : 0; }
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_LATENCY_ATTN")) latency_attn = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_FILL")) latency_fill = atoi(l) > 0 ? atoi(l) : latency_fill;
     if (const char* l = getenv("ECAD_ATTN_WIDE")) attn_wide = atoi(l) != 0;
     if (const char* gh = getenv("ECAD_GEMM_HALF")) {  // A/B switch: 1 = the two attention out-projections, 2 = + FF2, 3 = + cross-attention Q when it runs unfused
@@ -541,6 +543,14 @@ template <typename T> class EngineT : public EngineBase {
     if ((on != 0) != ln_fold) { stash_current(); ln_fold = on != 0; }
     return ECAD_OK;
   }
+  // How many image batches the caller keeps in flight on this GPU (execution contexts): the few-rows rule counts the other batches' tiles
+  // as well -- latency tiles fill an idle chip, but with four batches of 4 images in flight they cost a quarter of the throughput (140 against 192 images/s).
+  // Plan sets are keyed by it (the captured graphs hold different kernels).
+  int set_batches_in_flight(int n) override {
+    if (n < 1 || n > 64) return fail(ECAD_E_INVALID, "batches in flight: %d", n);
+    if (n != in_flight) { stash_current(); in_flight = n; }
+    return ECAD_OK;
+  }
   int set_fp8(int on) override {
     if (on && weights_shared) return fail(ECAD_E_UNSUPPORTED, "fp8 weight copies are per engine: not on a context that borrows its weights");
     if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; drop_all_plans(); }
@@ -684,7 +694,7 @@ template <typename T> class EngineT : public EngineBase {
   std::string make_key() const {
     std::string k((const char*)bits.data(), bits.size());
     k.append((const char*)custom_mask.data(), custom_mask.size());
-    const int geo[11] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0, ln_fold ? 1 : 0};
+    const int geo[12] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0, ln_fold ? 1 : 0, in_flight};
     k.append((const char*)geo, sizeof geo);
     return k;
   }
@@ -1168,9 +1178,11 @@ template <typename T> class EngineT : public EngineBase {
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
   bool latency_tiles = true;
+  bool latency_attn = true;  // the attention-fused query projections take the latency tile too (env ECAD_LATENCY_ATTN=0: they keep the 256-row tile)
+  int in_flight = 1;  // image batches the caller keeps in flight on this GPU (ecad_set_batches_in_flight)
   int latency_fill = 50;  // "few" = the 256-row tiles of the launch cover at most this percentage of the CUs (env ECAD_LATENCY_FILL)
   bool g3q_attr[4][KC_COUNT] = {};
-  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * 100 <= num_cus * latency_fill; }
+  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * in_flight * 100 <= num_cus * latency_fill; }
   template <int EPI, int TAG> int launch_quarter(const GemmArgs<T>& g, hipStream_t s) {
     if (!g3q_attr[EPI][TAG]) {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
@@ -1219,7 +1231,7 @@ template <typename T> class EngineT : public EngineBase {
     if (g.N % G3_BN || g.rows_per_batch % G3_BM || g.M % G3_BM || DH != 72 || !g.att_k || !g.att_v || !g.att_out || g.att_nk < 1 || g.att_ldo % 4 || g.att_ldk % 8)
       return fail(ECAD_E_UNSUPPORTED, "fused attention needs 256-row tiles inside one sample and head_dim 72");
     if (EPI == EPI_BIAS_ATTN && g.att_nk % G3A_KC) return fail(ECAD_E_UNSUPPORTED, "fused self-attention needs a key count that is a multiple of 128");
-    if (gemm_impl_cls[TAG] == 5 || few_rows(g)) {  // few rows: 64 query rows x two heads per workgroup, four times the workgroups (the same arithmetic per row)
+    if (gemm_impl_cls[TAG] == 5 || (latency_attn && few_rows(g))) {  // few rows: 64 query rows x two heads per workgroup, four times the workgroups (the same arithmetic per row)
       if (!g3qa_attr[EPI - EPI_BIAS_ATTN]) {
         HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
         g3qa_attr[EPI - EPI_BIAS_ATTN] = true;
@@ -1859,6 +1871,7 @@ const char* ecad_last_error(const EcadEngine* e) { return e ? e->impl->err.c_str
 int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) { ENG(e); if (!name || !ptr || !shape) return E->fail(ECAD_E_INVALID, "NULL argument"); return E->load_weight(name, ptr, dtype, shape, ndim); }
 int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights(); }
 int ecad_set_ln_fold(EcadEngine* e, int on) { ENG(e); return E->set_ln_fold(on); }
+int ecad_set_batches_in_flight(EcadEngine* e, int n) { ENG(e); return E->set_batches_in_flight(n); }
 int ecad_share_weights(EcadEngine* e, EcadEngine* donor) {
   ENG(e);
   if (!donor) return E->fail(ECAD_E_INVALID, "NULL donor");

@@ -98,6 +98,11 @@ class EcadEngine:
         """LayerNorm folded into the consumer GEMMs of the whole-loop plan (default on): switch it off where every schedule runs for one batch only."""
         self._chk(self.lib.ecad_set_ln_fold(self._h, int(bool(on))))
 
+    def set_batches_in_flight(self, n: int) -> None:
+        """How many image batches the caller keeps in flight on this GPU: the few-rows rule (64-row latency tiles while a launch would leave half the chip idle)
+        counts the other batches' tiles too.  ``EngineContexts`` sets it for its engines."""
+        self._chk(self.lib.ecad_set_batches_in_flight(self._h, int(n)))
+
     def new_context(self) -> "EcadEngine":
         """A further execution context on the same GPU: same configuration, the SAME weights (``ecad_share_weights``: no copy, this engine must outlive
         it), the same schedule; its own workspaces, cache arena, plans and hipGraph.  Batches submitted to different contexts on different streams overlap
@@ -364,6 +369,8 @@ class EngineContexts:
         self.engines = [engine] + [engine.new_context() for _ in range(n - 1)]
         self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(n)]
         self._turn = 0
+        for e in self.engines:  # the few-rows rule counts all the batches in flight: latency tiles only while the chip would otherwise idle
+            e.set_batches_in_flight(n)
 
     def __len__(self) -> int:
         return len(self.engines)
@@ -393,3 +400,5 @@ class EngineContexts:
         for e in self.engines[1:]:
             e.close()
         self.engines = self.engines[:1]
+        if self.engines[0]._h and self.engines[0]._h.value:
+            self.engines[0].set_batches_in_flight(1)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ECAD_ABI_VERSION 3
+#define ECAD_ABI_VERSION 4
 
 enum {
   ECAD_OK = 0,
@@ -102,6 +102,11 @@ int ecad_share_weights(EcadEngine* e, EcadEngine* donor);
  * built on the first ecad_run_schedule of a (schedule, timestep grid) -- a few milliseconds that a caller running each schedule for one batch only (the genetic
  * search's candidate evaluation under ecad/genetic) does not get back.  Results with and without the fold agree to the rounding that moved (3e-3 on final latents). */
 int ecad_set_ln_fold(EcadEngine* e, int on);
+/* How many image batches the caller keeps in flight on this GPU (this context and the ones sharing its weights; default 1).  With few rows per launch (batch 1-8) the
+ * engine runs its GEMMs on 64-row latency tiles while the launch's 256-row tiles would cover at most half the chip; the tiles of the other batches in
+ * flight count towards that half, so that a caller that fills the GPU with several small batches keeps the throughput kernels.  Results do not depend on it (both
+ * tile shapes are the same arithmetic).  ECAD_E_INVALID outside 1..64. */
+int ecad_set_batches_in_flight(EcadEngine* e, int n);
 /* Opt-in OCP fp8 (e4m3) for the block GEMMs (QKV, attention out-projections, cross-attention Q, FF1, FF2): e4m3 weight copies with
  * per-output-channel scales at finalize, activations quantised per row in front of each GEMM (csrc/gemm3s8.h).  Call before
  * ecad_finalize_weights.  Default off (env ECAD_FP8=1 sets the default): the reference computes in fp16, which stays the precision of

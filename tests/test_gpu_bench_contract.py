@@ -42,6 +42,7 @@ def test_bench_line_contract():
     assert c["kind"] == "port" and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # the rate comparable to the reference's own latency numbers (VAE decode + PIL inside) is reported by default, beside and below `value`
     assert 0 < d["png_ready_images_per_s"] < d["value"]
+    assert 0 < d["png_ready_batches_in_flight_images_per_s"] < d["value"]  # the decode tail with the headline's batches in flight
     s = d["secondary"]["alpha256_batch1_latency"]
     assert "error" not in s and s["value"] > 0 and "batch=1 " in s["workload"]
 

@@ -547,6 +547,40 @@ def test_latency_tiles_for_few_rows_are_the_same_arithmetic(monkeypatch, dtype, 
     assert torch.equal(res["1"][1], res["0"][1])
 
 
+def test_batches_in_flight_pick_the_tile_shape_not_the_result(monkeypatch):
+    """ecad_set_batches_in_flight: the few-rows rule counts the tiles of all the batches a caller keeps in flight, so a pool of execution contexts with
+    small batches runs the 256-row throughput kernels while a single small batch runs the 64-row latency tiles.  Same arithmetic either way: the latents are equal
+    bit for bit, the plan sets (and their graphs) are kept apart, and a count outside 1..64 is refused."""
+    from ecad_amd.engine import EcadEngine, EngineContexts
+
+    monkeypatch.setenv("ECAD_LATENCY_TILES", "1")
+    layers, steps, B = 2, 4, 2
+    bits = rand_bits(steps, layers, 0.6, seed=21)
+    bits[0] = True
+    eng, w, cfg = make_pair(layers, bits, max_batch=2 * B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    inp, enc, mask = cfg_inputs(B)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    alone = eng.run_schedule(*args).clone()            # M = 1024 rows: 32 tiles of 256 x 144 <= half the chip -> latency tiles
+    caps = eng.stats()["graph_captures"]
+    eng.set_batches_in_flight(8)                       # 8 x 32 tiles: the throughput kernels
+    crowded = eng.run_schedule(*args).clone()
+    assert eng.stats()["graph_captures"] == caps + 1   # its own plan set and graph
+    assert torch.equal(alone, crowded)
+    eng.set_batches_in_flight(1)
+    assert torch.equal(eng.run_schedule(*args), alone) and eng.stats()["graph_captures"] == caps + 1  # the first plan set came back from the stash
+    with pytest.raises(ValueError, match="batches in flight"):
+        eng.set_batches_in_flight(0)
+    pool = EngineContexts(eng, 2)                      # a pool announces itself to its engines, and takes the announcement back
+    out = pool.submit(*args)[0]
+    pool.wait()
+    assert torch.equal(out, alone)
+    pool.close()
+    assert torch.equal(eng.run_schedule(*args), alone)
+    eng.close()
+
+
 def test_execution_contexts_share_weights_and_keep_results_bit_identical():
     """ecad_share_weights / EngineContexts: further execution contexts read the first engine's weight arena (no copy), keep their own cache arena,
     plans and hipGraph, and run on their own streams, so several image batches are in flight at once.  Six different batches submitted to three contexts

@@ -315,6 +315,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : strcmp(at, "dma4") == 0 ? 2 : 0; }
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_EPI_DIRECT")) epi_direct = atoi(l);
     if (const char* l = getenv("ECAD_LATENCY_ATTN")) latency_attn = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_FILL")) latency_fill = atoi(l) > 0 ? atoi(l) : latency_fill;
     if (const char* l = getenv("ECAD_ATTN_WIDE")) attn_wide = atoi(l) != 0;
@@ -775,7 +776,7 @@ template <typename T> class EngineT : public EngineBase {
     o.kind = Op<T>::GEMM; o.cls = cls; o.epi = epi;
     o.g.A = A; o.g.W = W; o.g.bias = bias; o.g.C = C; o.g.resid = nullptr; o.g.gate_table = nullptr; o.g.gate_mod = nullptr;
     o.g.gate_mod_stride = 0; o.g.rows_per_batch = N > 0 ? N : 1; o.g.M = M; o.g.N = Nn; o.g.K = K; o.g.lda = lda; o.g.ldw = K; o.g.ldc = ldc; o.g.ldr = ldc;
-    o.g.variant = gemm_variant;
+    o.g.variant = gemm_variant; o.g.epi_direct = epi_direct;
     o.flops = 2.0 * M * (double)Nn * K;
     o.bytes = ((double)M * K + (double)Nn * K + (double)M * Nn) * sizeof(T);
     return o;
@@ -1178,6 +1179,7 @@ template <typename T> class EngineT : public EngineBase {
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
   bool latency_tiles = true;
+  int epi_direct = 1;  // gemm2w.h epilogues straight from the registers: 0 none, 1 the GELU epilogue (FF1), 2 the plain ones too (env ECAD_EPI_DIRECT)
   bool latency_attn = true;  // the attention-fused query projections take the latency tile too (env ECAD_LATENCY_ATTN=0: they keep the 256-row tile)
   int in_flight = 1;  // image batches the caller keeps in flight on this GPU (ecad_set_batches_in_flight)
   int latency_fill = 50;  // "few" = the 256-row tiles of the launch cover at most this percentage of the CUs (env ECAD_LATENCY_FILL)
@@ -1709,7 +1711,7 @@ template <typename T> class EngineT : public EngineBase {
     GemmArgs<T> g{};
     g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
     g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K; g.lda = K; g.ldw = K; g.ldc = Nn; g.ldr = Nn;
-    g.variant = gemm_variant;
+    g.variant = gemm_variant; g.epi_direct = epi_direct;
     if (epi == EPI_BIAS_CACHE_RESID && !resid) return fail(ECAD_E_INVALID, "epilogue 3 needs resid");
     int rc = launch_gemm(epi, KC_GEMM_SMALL, g, s);
     if (rc) return rc;
@@ -1730,7 +1732,7 @@ template <typename T> class EngineT : public EngineBase {
       return fail(ECAD_E_INVALID, "fused query projection + attention: x / wq / k / v / out must be 16-byte aligned and ld_kv (%lld) a multiple of 8 >= %d", (long long)ld_kv, D);
     GemmArgs<T> g{};
     g.A = (const T*)x; g.W = (const T*)wq; g.bias = bq; g.C = nullptr; g.M = Bt_ * n_tokens; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.ldr = D;
-    g.rows_per_batch = n_tokens; g.variant = gemm_variant;
+    g.rows_per_batch = n_tokens; g.variant = gemm_variant; g.epi_direct = epi_direct;
     g.att_k = (const T*)k; g.att_v = (const T*)v; g.att_out = (T*)out; g.att_bias = tail ? key_bias : nullptr; g.att_ldk = (int)ld_kv; g.att_ldo = D; g.att_nk = n_keys;
     g.att_scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
     const int rc = launch_gemm(tail ? EPI_BIAS_ATTN_TAIL : EPI_BIAS_ATTN, site, g, s);
@@ -1747,7 +1749,8 @@ template <typename T> class EngineT : public EngineBase {
     g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
     g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K;
     g.lda = lda > 0 ? (int)lda : K; g.ldw = K; g.ldc = ldc > 0 ? (int)ldc : Nn; g.ldr = Nn;
-    g.variant = (kernel >> 8) ? (kernel >> 8) - 1 : gemm_variant;  // bits 8+ of `kernel`: 1 + schedule variant to force (A/B in one process); 0 = the engine's
+    g.variant = (kernel >> 8) ? ((kernel >> 8) - 1) & 3 : gemm_variant;  // bits 8+ of `kernel`: 1 + schedule variant to force (A/B in one process); 0 = the engine's
+    g.epi_direct = (kernel >> 8) && (((kernel >> 8) - 1) & 12) ? ((((kernel >> 8) - 1) & 4) ? 2 : 0) : epi_direct;  // + 4: direct epilogue forced on, + 8: forced off
     kernel &= 0xff;
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
     if (kernel == 3) {

@@ -52,6 +52,7 @@ template <typename T> struct GemmArgs {
   float ln_eps, ln_inv_d;
   // read-modify-write epilogue (gemm3s.h): also publish (sum x, sum x^2) of the tile's 144 columns of the UPDATED hidden states, [N / 144][M][2] floats
   float* stat_out;
+  int epi_direct;  // gemm2w.h plain / GELU / SiLU epilogues: 1 = rows leave straight from the registers (permlane-transposed 16-byte stores), 0 = through a C tile in LDS
   int variant;  // K-loop schedule of gemm3s.h / gemm2w.h: 0 = every wave issues its LDS-DMA pieces in one block after the barrier (round 1),
                 // 1 = staggered: pieces interleaved one per MFMA group, waves 0-3 in the first half of the step, waves 4-7 in the second
 };

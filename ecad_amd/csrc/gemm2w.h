@@ -334,6 +334,48 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // ---- direct epilogue (round 3; plain / GELU): no C tile in LDS and no barrier.  A lane holds 4 consecutive columns of a row per 16-column fragment
+  // (8 bytes in the storage type); v_permlane16_swap_b32 between the packed registers of fragments j and j+1 exchanges the odd 16-lane rows of one with the
+  // even rows of the other (lanes l and l ^ 16 = the same row m, column groups 4g and 4(g ^ 1)), after which the lanes with even g hold 8 consecutive
+  // columns of fragment j and the lanes with odd g 8 of fragment j+1: one global_store_dwordx4 per fragment pair writes 64 contiguous bytes of each of
+  // 16 rows (a full HBM burst), the ninth fragment goes out in 8-byte stores.  Same values as the staged path, bit for bit.
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {  // (SiLU: only the small adaLN GEMMs; hipcc contracts acc + bias into its first multiply differently there)
+    if (p.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1)) {  // 1: the GELU epilogue only (FF1: +4 % in the pipeline; the plain wide K,V launch measured 4 % SLOWER direct), 2: all
+      auto cvt = [&](int i, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const f32x4 bv = bvs[j];
+        Pack4 o;
+        if constexpr (EPI == EPI_BIAS_GELU) {
+          const f32x2 v01 = gelu_tanh2((f32x2){acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]});
+          const f32x2 v23 = gelu_tanh2((f32x2){acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]});
+          float_to_elem4<T>(o, 0, v01[0]); float_to_elem4<T>(o, 1, v01[1]); float_to_elem4<T>(o, 2, v23[0]); float_to_elem4<T>(o, 3, v23[1]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) float_to_elem4<T>(o, r, acc[i][j][r] + bv[r]);
+        }
+        return o;
+      };
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + l15;
+        T* crow = p.C + (size_t)(m < p.M ? m : 0) * p.ldc + n0 + wn * 144;
+        static_for<FN / 2>([&](auto pc) {
+          constexpr int j = 2 * decltype(pc)::value;
+          Pack4 a = cvt(i, std::integral_constant<int, j>{}), b = cvt(i, std::integral_constant<int, j + 1>{});
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[0]), "+v"(b.u[0]));
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[1]), "+v"(b.u[1]));
+          Pack8 v;
+          v.u = (u32x4){a.u[0], a.u[1], b.u[0], b.u[1]};
+          if (m < p.M) gstore16(crow + 16 * (j + (g & 1)) + 8 * (g >> 1), v);
+        });
+        if constexpr (FN & 1) {
+          const Pack4 o = cvt(i, std::integral_constant<int, FN - 1>{});
+          if (m < p.M) *reinterpret_cast<u32x2*>(crow + 16 * (FN - 1) + 4 * g) = o.u;
+        }
+      }
+      return;
+    }
+  }
   __syncthreads();
 #ifdef G_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -304,7 +304,8 @@ class EcadEngine:
     def op_gemm_ex(self, kernel: str, site: str, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None,
                    sched: int | None = None):
         """``op_gemm`` on a named kernel / call-site instantiation (``ecad_op_gemm_ex``); ``a`` and ``out`` may be column slices (row stride > width).
-        ``sched``: force K-loop schedule variant 0 / 1 (default: the engine's own, env ECAD_GEMM_SCHED)."""
+        ``sched``: force K-loop schedule variant 0 / 1 (default: the engine's own, env ECAD_GEMM_SCHED); + 4: gemm2w's direct (register) epilogue for every
+        epilogue kind, + 8: its staged epilogue (default: direct for the GELU epilogue, env ECAD_EPI_DIRECT)."""
         M, K = a.shape
         N = w.shape[0]
         if out is None and epi != 3:

@@ -97,6 +97,30 @@ def test_gemm_every_kernel_by_call_site(dtype_name, kernel, site, epi, M, N, K):
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("epi,M,N", [(1, 8192, 4608), (1, 600, 4608), (0, 1000, 2304), (0, 300, 576)])
+def test_gemm2w_direct_epilogue_stores_the_staged_epilogues_bytes(dtype_name, epi, M, N):
+    """gemm2w.h (round 3): rows leave straight from the accumulator registers -- v_permlane16_swap between the packed registers of two neighbouring 16-column
+    fragments turns a lane's two 8-byte pieces into one 16-byte piece, one store per fragment pair writes 64 contiguous bytes of 16 rows -- instead of through a
+    C tile in LDS behind a barrier (the default for the GELU epilogue of FF1).  `sched` + 4 forces it for every epilogue, + 8 forces the staged path: the same
+    bytes, ragged last tile and a strided output included, and nothing outside the output columns is touched."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    K = 1152
+    a, w = _r((M, K), dt, 1.0, 51), _r((N, K), dt, 0.05, 52)
+    bias = _r((N,), torch.float32, 0.5, 53)
+    outs = []
+    for sched in (8, 4):
+        buf = torch.full((M, N + 64), 3.0, dtype=dt, device="cuda")
+        eng.op_gemm_ex("wide288", "ff1" if epi == 1 else ("attn1_kv" if N == 2304 else "small"), epi, a, w, bias, out=buf[:, 32 : 32 + N], sched=sched)
+        assert bool((buf[:, :32] == 3.0).all()) and bool((buf[:, 32 + N :] == 3.0).all())
+        outs.append(buf[:, 32 : 32 + N].clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = a.float() @ w.float().t() + bias
+    ref = F.gelu(ref, approximate="tanh") if epi == 1 else ref
+    assert within(tile_rel_l2(outs[1], ref), TOL[dtype_name])
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
     """The split QKV launch of the engine: Q on 256x144 tiles into columns [0, D), K,V on 256x288 tiles into columns [D, 3D) of one [M, 3D] buffer
     (row stride 3D on the output) -- together they must equal one fused projection, and neither may touch the other's columns."""

@@ -316,6 +316,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : strcmp(at, "dma4") == 0 ? 2 : 0; }
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
     if (const char* l = getenv("ECAD_EPI_DIRECT")) epi_direct = atoi(l);
+    if (const char* l = getenv("ECAD_GEMM2W_WALK")) gemm2w_walk = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_ATTN")) latency_attn = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_FILL")) latency_fill = atoi(l) > 0 ? atoi(l) : latency_fill;
     if (const char* l = getenv("ECAD_ATTN_WIDE")) attn_wide = atoi(l) != 0;
@@ -1179,6 +1180,7 @@ template <typename T> class EngineT : public EngineBase {
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
   bool latency_tiles = true;
+  bool gemm2w_walk = true;  // gemm2w.h with the direct epilogue: grid = CUs, every workgroup walks its tiles (env ECAD_GEMM2W_WALK=0: one workgroup per tile)
   int epi_direct = 1;  // gemm2w.h epilogues straight from the registers: 0 none, 1 the GELU epilogue (FF1), 2 the plain ones too (env ECAD_EPI_DIRECT)
   bool latency_attn = true;  // the attention-fused query projections take the latency tile too (env ECAD_LATENCY_ATTN=0: they keep the 256-row tile)
   int in_flight = 1;  // image batches the caller keeps in flight on this GPU (ecad_set_batches_in_flight)
@@ -1203,7 +1205,9 @@ template <typename T> class EngineT : public EngineBase {
           g2_attr[EPI][TAG] = true;
         }
         const int tiles2 = ((g.M + G2_BM - 1) / G2_BM) * (g.N / G2_BN);
-        hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);
+        // direct epilogue (LDS-free): one workgroup per CU walks its tiles and fetches the next tile's first K-step under the epilogue (gemm2w.h)
+        const bool walk = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && g.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1) && gemm2w_walk && tiles2 > num_cus && tiles2 % num_cus == 0;
+        hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(walk ? num_cus : tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);
         return ECAD_OK;
       }
     }

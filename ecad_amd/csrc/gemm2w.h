@@ -35,32 +35,52 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   const int tiles_n = p.N / G2_BN;
   const int tiles_m = (p.M + G2_BM - 1) / G2_BM;
   const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  tile_coords(bid, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * G2_BM, n0 = tn * G2_BN;
-
+  // tile id -> origin: ids are dealt to the XCDs in contiguous runs (tile_coords, gemm.h)
+  auto origin = [&](int v, int& om0, int& on0) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int tm, tn;
+    tile_coords(bid, tiles_m, tiles_n, tm, tn);
+    om0 = tm * G2_BM;
+    on0 = tn * G2_BN;
+  };
   const T* a_src[A_INST];
   const T* b_src[5];
+  auto set_sources = [&](int sm0, int sn0) {
+    // `ln` is opaque to the optimizer: otherwise the lane-dependent halves of these nine addresses are hoisted out of the tile loop and stay live through
+    // the K loop and the epilogue of every tile (26 spilled VGPRs in a kernel that sits at 255)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
-  for (int i = 0; i < A_INST; ++i) {
-    const int r = (wave * A_INST + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    int row = m0 + r;
-    row = row < p.M ? row : p.M - 1;
-    a_src[i] = p.A + (size_t)row * p.lda + c * 8;
-  }
+    for (int i = 0; i < A_INST; ++i) {
+      const int r = (wave * A_INST + i) * 8 + (ln >> 3);
+      const int c = (ln & 7) ^ ((r >> 1) & 7);
+      int row = sm0 + r;
+      row = row < p.M ? row : p.M - 1;
+      a_src[i] = p.A + (size_t)row * p.lda + c * 8;
+    }
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    int inst = wave + i * G2_NW;
-    inst = inst < B_TOTAL ? inst : B_TOTAL - 1;
-    const int r = inst * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    b_src[i] = p.W + (size_t)(n0 + r) * p.ldw + c * 8;
+    for (int i = 0; i < 5; ++i) {
+      int inst = wave + i * G2_NW;
+      inst = inst < B_TOTAL ? inst : B_TOTAL - 1;
+      const int r = inst * 8 + (ln >> 3);
+      const int c = (ln & 7) ^ ((r >> 1) & 7);
+      b_src[i] = p.W + (size_t)(sn0 + r) * p.ldw + c * 8;
+    }
+  };
+  // Tile loop (round 3): the grid may be smaller than the tile count (FF1 with the direct epilogue: one workgroup per CU walks its 2 .. 8 tiles).  The direct
+  // epilogue leaves the LDS alone, so the first K-step of the NEXT tile is requested before this tile's epilogue starts: no pipeline fill, no workgroup turnover,
+  // and the stores drain under the next K loop.
+  bool pre_issued = false;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+  int m0, n0;
+  origin(vb, m0, n0);
+  set_sources(m0, n0);  // (recomputed rather than kept across the previous tile's epilogue: 18 live registers there are 18 spills)
+  if (pre_issued) {     // K-step 0 is already on its way
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) a_src[i] += GEMM_BK;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b_src[i] += GEMM_BK;
   }
   auto issue = [&](int stage) {
     char* abase = smem + stage * G2_STAGE_BYTES;
@@ -111,7 +131,8 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long st_c1 = 0, st_c2 = 0, st_ca = 0, st_cb = 0;
 #endif
-  issue(0);
+  if (!pre_issued) issue(0);
+  pre_issued = false;
 #ifndef G2_NO_XBAR
   // the last PN columns of a step's second fragment set are consumed after the NEXT barrier (4 * PN MFMAs of pipe work while the barrier
   // resolves and the new stage's first fragments arrive); the full set does not fit next to 144 accumulators (PN = 2: 254 VGPRs, no spills).
@@ -292,6 +313,16 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #ifdef G_STAMP
   st_c2 = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    // the last K-step read stage (nk - 1) & 1; with an even step count stage 0 is free for the next tile's first step (the source registers are dead here)
+    if (vb + (int)gridDim.x < nwg && p.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1) && !(nk & 1)) {
+      int xm0, xn0;
+      origin(vb + (int)gridDim.x, xm0, xn0);
+      set_sources(xm0, xn0);
+      issue(0);
+      pre_issued = true;
+    }
+  }
 #ifdef G2_BREAK_TILE
   // deliberately wrong build for checking the parity net (never shipped): tile column 1 loses one 16-column fragment of its second column half
   if (tn == 1 && wn == 1)
@@ -373,7 +404,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
           if (m < p.M) *reinterpret_cast<u32x2*>(crow + 16 * (FN - 1) + 4 * g) = o.u;
         }
       }
-      return;
+      continue;
     }
   }
   __syncthreads();
@@ -495,6 +526,8 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0; dbg[6] = st_ca - st_c2; dbg[7] = st_cb - st_ca;
   }
 #endif
+  if (vb + (int)gridDim.x < nwg) __syncthreads();  // staged epilogue: the C tile has been read before the next tile's DMA overwrites it
+  }  // tile loop
 }
 
 }  // namespace ecad

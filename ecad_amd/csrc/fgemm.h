@@ -59,6 +59,7 @@ template <typename T> struct FGemmArgs {
   float rope_eps;
   T* C2;                // FEPI_QKV_ROPE_MLP: gelu(mlp) output
   int ldc2, n_split;
+  int epi_direct;       // GELU tiles leave straight from the registers (permlane-transposed 16-byte stores, gemm2w.h) instead of through the C tile in LDS
 };
 
 ECAD_DEV int seg_batch(int m, int seg0, int rpb0, int rpb1) { return m < seg0 ? m / rpb0 : (m - seg0) / rpb1; }
@@ -257,6 +258,43 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;
   const int l15 = lane & 15, g = lane >> 4;
+  // ---- direct epilogue of the GELU tiles (round 3, gemm2w.h has the description): FF1 of the joint blocks and the proj_mlp columns of the single blocks' stacked GEMM
+  if constexpr (EPI == FEPI_BIAS_GELU || EPI == FEPI_QKV_ROPE_MLP) {
+    if (p.epi_direct && (EPI == FEPI_BIAS_GELU || n0 >= p.n_split)) {
+      T* cbase = EPI == FEPI_QKV_ROPE_MLP ? p.C2 : p.C;
+      const int ld = EPI == FEPI_QKV_ROPE_MLP ? p.ldc2 : p.ldc;
+      const int c0 = (EPI == FEPI_QKV_ROPE_MLP ? n0 - p.n_split : n0) + wn * (BN / 2);
+      f32x4 bvs[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * (BN / 2) + 16 * j + 4 * g);
+      }
+      auto cvt = [&](int i, int j) {
+        const f32x2 v01 = gelu_tanh2((f32x2){acc[i][j][0] + bvs[j][0], acc[i][j][1] + bvs[j][1]});
+        const f32x2 v23 = gelu_tanh2((f32x2){acc[i][j][2] + bvs[j][2], acc[i][j][3] + bvs[j][3]});
+        Pack4 o;
+        float_to_elem4<T>(o, 0, v01[0]); float_to_elem4<T>(o, 1, v01[1]); float_to_elem4<T>(o, 2, v23[0]); float_to_elem4<T>(o, 3, v23[1]);
+        return o;
+      };
+      static_assert(FN % 2 == 0, "fragment pairs");
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + l15;
+        T* crow = cbase + (size_t)(m < p.M ? m : 0) * ld + c0;
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+          Pack4 a = cvt(i, j), b = cvt(i, j + 1);
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[0]), "+v"(b.u[0]));
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[1]), "+v"(b.u[1]));
+          Pack8 v;
+          v.u = (u32x4){a.u[0], a.u[1], b.u[0], b.u[1]};
+          if (m < p.M) gstore16(crow + 16 * (j + (g & 1)) + 8 * (g >> 1), v);
+        }
+      }
+      return;
+    }
+  }
   // ---- epilogue 1: wave's 64 x BN/2 block -> row-major C tile in LDS (bias, activation, rounding)
   T* ctile = reinterpret_cast<T*>(smem);
 #pragma unroll

@@ -202,6 +202,7 @@ template <typename T> class FluxT : public FluxBase {
   float* sxn8 = nullptr;      // [R]
   bool f8_engine_attr = false;
   bool fuse_rope = true;      // env ECAD_FLUX_FUSE=0: separate qk_norm_rope pass and separate single-block QKV / proj_mlp GEMMs (A/B)
+  int epi_direct = 1;  // GELU tiles of the block GEMMs stored straight from the registers (fgemm.h; env ECAD_FLUX_EPI_DIRECT=0: through the C tile)
   bool attn_generic = false;  // env ECAD_FLUX_ATTN=generic: the d_h-templated kernel of attention.h (A/B)
   int attn_dma = 2;           // attention_dma.h (K / V chunks by LDS-DMA into a double-buffered image) with the partial last round of work items run as 128-row
                               // items in a second launch; env ECAD_FLUX_ATTN=dma: one launch, =shared: attention128.h, =generic: attention.h
@@ -345,6 +346,7 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     FHIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     if (fp8 && D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
+    if (const char* e = getenv("ECAD_FLUX_EPI_DIRECT")) epi_direct = atoi(e);
     if (const char* e = getenv("ECAD_FLUX_ATTN")) { attn_generic = strcmp(e, "generic") == 0; attn_dma = strcmp(e, "dma") == 0 ? 1 : strcmp(e, "dma-split") == 0 ? 2 : (strcmp(e, "shared") == 0 || strcmp(e, "generic") == 0) ? 0 : attn_dma; }
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
 
@@ -934,7 +936,9 @@ template <typename T> class FluxT : public FluxBase {
     }
     return ECAD_OK;
   }
-  int launch_gemm(int epi, int bn, const FGemmArgs<T>& g, hipStream_t s) {
+  int launch_gemm(int epi, int bn, const FGemmArgs<T>& g_in, hipStream_t s) {
+    FGemmArgs<T> g = g_in;
+    g.epi_direct = epi_direct;
     if (g.K % GEMM_BK || g.M < 1 || g.N % bn) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K %% 64, N %% %d)", g.M, g.N, g.K, bn);
     if (g.A2 && (g.k_split % GEMM_BK || g.k_split <= 0 || g.k_split >= g.K)) return fail(ECAD_E_INVALID, "bad k_split %d", g.k_split);
     return bn == 256 ? launch_gemm_bn<256>(epi, g, s) : launch_gemm_bn<128>(epi, g, s);

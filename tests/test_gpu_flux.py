@@ -60,6 +60,27 @@ def test_fgemm_bias_and_activations(op_engine, dtype, tol, bn, M, N, K):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("bn", [128, 256])
+def test_fgemm_gelu_tiles_stored_from_the_registers_are_the_staged_bytes(monkeypatch, dtype, tol, bn):
+    """fgemm.h (round 3): the GELU tiles leave straight from the accumulator registers (v_permlane16_swap between neighbouring fragments -> 16-byte stores of 64
+    contiguous bytes per row) instead of through the C tile in LDS; ECAD_FLUX_EPI_DIRECT=0 keeps the staged path.  Same bytes, ragged last row tile included."""
+    M, N, K = 1000, 768, 512
+    g = torch.Generator().manual_seed(77 + bn)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dtype).cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ECAD_FLUX_EPI_DIRECT", mode)
+        eng = make_engine(tiny_cfg(1, 1), dtype)
+        outs[mode] = eng.op_gemm(1, bn, A, W, bias).clone()
+        torch.cuda.synchronize()
+        del eng
+    assert torch.equal(outs["0"], outs["1"])
+    assert rel_l2(outs["1"].float(), torch.nn.functional.gelu(A.float() @ W.float().T + bias, approximate="tanh")) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("bn", [128, 256])
 def test_fgemm_split_a_gated_residual_two_segments(op_engine, dtype, tol, bn):
     """proj_out of the single-stream block: A = [attn | gelu(mlp)] from two buffers; resid += gate[b] * out with the
     [text | image] row layout (text rows of all samples first)."""

@@ -594,13 +594,16 @@ def main():
             if pool is not None:
                 # the same tail with the batches in flight the headline line has (what PixArtAlphaImageGenerator(contexts=N).generate_from_saved_prompts does):
                 # while the host waits for batch i's bytes and builds its PIL images, the other contexts' denoising loops keep the GPU busy
+                dec_stream = torch.cuda.Stream(device=local_rank, priority=-1)  # the decode of a finished batch goes in front of the other batches' denoising launches
+
                 def png_ready_in_flight(n_batches):
                     pend = [pool.submit(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=use_graph) for _ in range(min(len(pool), n_batches))]
                     left = n_batches - len(pend)
                     while pend:
                         lat_k, st_k = pend.pop(0)
-                        torch.cuda.current_stream().wait_stream(st_k)
-                        arr = vae.decode_to_uint8(lat_k).cpu().numpy()
+                        dec_stream.wait_stream(st_k)
+                        with torch.cuda.stream(dec_stream):
+                            arr = vae.decode_to_uint8(lat_k, stream=dec_stream).cpu().numpy()
                         if left > 0:  # this context's output has been consumed: it may start its next batch
                             pend.append(pool.submit(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=use_graph))
                             left -= 1

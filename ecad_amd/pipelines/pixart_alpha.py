@@ -193,7 +193,17 @@ class PixArtAlphaPipeline:
     def decode(self, latents: torch.Tensor, output_type: str = "pil"):
         """VAE decode when a VAE module is attached (stays PyTorch/MIOpen); otherwise a linear latent->RGB preview."""
         if self.vae is not None and hasattr(self.vae, "decode_to_uint8"):  # native decoder: latents -> uint8 NHWC in one call
-            arr = self.vae.decode_to_uint8(latents).cpu().numpy()
+            if getattr(self, "_pool", None) is not None and latents.is_cuda:
+                # several batches in flight: the decode of a finished batch runs on a high-priority stream, in front of the other batches' denoising launches
+                # (bench.py, same box: PNG-ready 158 images/s with the decode queued behind them on the default stream, 174 this way, 166.6 one batch at a time)
+                if getattr(self, "_decode_stream", None) is None:
+                    self._decode_stream = torch.cuda.Stream(device=latents.device, priority=-1)
+                self._decode_stream.wait_stream(torch.cuda.current_stream(latents.device))
+                latents.record_stream(self._decode_stream)
+                with torch.cuda.stream(self._decode_stream):
+                    arr = self.vae.decode_to_uint8(latents, stream=self._decode_stream).cpu().numpy()
+            else:
+                arr = self.vae.decode_to_uint8(latents).cpu().numpy()
             if output_type == "np":
                 return arr
             if output_type == "pt":

@@ -64,8 +64,9 @@ static_assert(attn_dma_lds_bytes<128>() <= 160 * 1024, "two images of the d_h 12
 
 // R = query fragments (16 rows each) per wave: 2 (256 query rows per work item, as attention128.h) or 4 (512 rows: every K / V fragment read feeds four MFMAs and a
 // chunk is staged once for twice the rows; fits the 72-wide head only -- d_h 128 would need 144 accumulator + 64 query + 64 score registers).  DESIGN 5d.
-template <typename T, int DHC, int R = 2>
-__global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
+// NW = waves per workgroup: 8 (two per SIMD, <= 256 registers each) or 4 (one per SIMD with the whole 512-register file: eight query fragments per wave at d_h 72).
+template <typename T, int DHC, int R = 2, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void attn_dma_kernel(const AttnArgs p) {
   constexpr bool KSWZ = ATT_KSWZ && DHC == 128;
   constexpr int KC = A128_KC, KS = KSWZ ? 128 : AttCfg<DHC>::KS, VS = AttCfg<DHC>::VS, DH = DHC, ND = AttCfg<DHC>::ND, KSTEPS = AttCfg<DHC>::KSTEPS;
   constexpr int NDO = DH / 16 + (DH % 16 ? 1 : 0);
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
   constexpr int K_INST = KC * KS * 2 / 1024, V_INST = KC * VS * 2 / 1024;  // 1-KiB DMA instructions per image: 34 + 36 (d_h 128), 26 + 20 (d_h 72)
   static_assert(KC * KS * 2 % 1024 == 0 && KC * VS * 2 % 1024 == 0, "image regions in whole DMA instructions");
   constexpr int N_INST = K_INST + V_INST;
-  constexpr int NI = (N_INST + 7) / 8;             // per wave: 9 (d_h 128) / 6 (d_h 72)
+  constexpr int NI = (N_INST + NW - 1) / NW;       // per wave (8 waves): 9 (d_h 128) / 6 (d_h 72)
   constexpr int IMG = attn_dma_image_bytes<DHC>();
   extern __shared__ __attribute__((aligned(16))) char att_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,16 +86,16 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
   const T* K = reinterpret_cast<const T*>(p.k);
   const T* V = reinterpret_cast<const T*>(p.v);
   T* O = reinterpret_cast<T*>(p.out);
-  constexpr int QB = 8 * 16 * R;  // query rows per work item
+  constexpr int QB = NW * 16 * R;  // query rows per work item
   const int q_cnt = p.q_cnt > 0 ? p.q_cnt : p.Nq;  // a launch may cover a slice of the query rows of every (sample, head): see launch_attn in flux.hip
   const int nqb = (q_cnt + QB - 1) / QB;
   const int nkc = p.Nk / KC;
   const int items = p.B * p.H * nqb;
 
   // both images: zeros everywhere, 1.0 in column DH of every V row; the DMA never touches a pad
-  for (int i = tid; i < 2 * IMG / 16; i += 512) reinterpret_cast<u32x4*>(att_smem)[i] = (u32x4){0, 0, 0, 0};
+  for (int i = tid; i < 2 * IMG / 16; i += NW * 64) reinterpret_cast<u32x4*>(att_smem)[i] = (u32x4){0, 0, 0, 0};
   __syncthreads();
-  for (int i = tid; i < 2 * KC; i += 512) {
+  for (int i = tid; i < 2 * KC; i += NW * 64) {
     T* Vs = reinterpret_cast<T*>(att_smem + (i / KC) * IMG) + KC * KS;
     Vs[(i % KC) * VS + DH] = (T)1.0f;
   }
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
   bool live[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int inst = wave + 8 * j;
+    const int inst = wave + NW * j;
     const bool isv = inst >= K_INST;
     const int piece = (isv ? inst - K_INST : inst) * 64 + lane;
     const int row = piece / (isv ? VPR : KPR), col = piece - row * (isv ? VPR : KPR);
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(512) void attn_dma_kernel(const AttnArgs p) {
     char* img = att_smem + buf * IMG;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int inst = wave + 8 * j;
+      const int inst = wave + NW * j;
       if (inst < N_INST) {                                  // wave-uniform
         const char* src = (inst >= K_INST ? vb : kb) + off[j];
         if (live[j]) glds16(src, img + inst * 1024);        // pad lanes are off: their 16 bytes of the image keep the prologue's contents

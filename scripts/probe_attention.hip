@@ -13,7 +13,7 @@
 using namespace ecad;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <typename T> static float run(const char* name, const void* fn, int lds, int B, int H, int N, int dh, int rows_per_item, int reps) {
+template <typename T> static float run(const char* name, const void* fn, int lds, int B, int H, int N, int dh, int rows_per_item, int reps, int threads = 512) {
   const size_t D = (size_t)H * dh, rows = (size_t)B * N;
   std::vector<unsigned short> h(rows * 3 * D);
   unsigned x = 12345u;
@@ -42,7 +42,7 @@ template <typename T> static float run(const char* name, const void* fn, int lds
   float best = 1e9f;
   for (int it = 0; it < 4; ++it) {
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < reps; ++r) CK(hipLaunchKernel(fn, dim3(items < cus ? items : cus), dim3(512), params, lds, 0));
+    for (int r = 0; r < reps; ++r) CK(hipLaunchKernel(fn, dim3(items < cus ? items : cus), dim3(threads), params, lds, 0));
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (it) best = ms / reps < best ? ms / reps : best;
@@ -67,6 +67,11 @@ int main(int argc, char** argv) {
   run<bf16_t>("flux  dma  d128 R2 (B2 H24 S4608)", (const void*)attn_dma_kernel<bf16_t, 128, 2>, attn_dma_lds_bytes<128>(), 2, 24, 4608, 128, 256, reps);
   run<f16_t>("sigma dma  d72  R2 (B8 H16 N4096)", (const void*)attn_dma_kernel<f16_t, 72, 2>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 256, reps);
   run<f16_t>("sigma dma  d72  R4", (const void*)attn_dma_kernel<f16_t, 72, 4>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 512, reps);
+#ifdef ATT_TRY_NW4
+  run<f16_t>("sigma dma  d72  R8, 4 waves", (const void*)attn_dma_kernel<f16_t, 72, 8, 4>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 512, reps, 256);
+  run<f16_t>("sigma dma  d72  R4, 4 waves", (const void*)attn_dma_kernel<f16_t, 72, 4, 4>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 256, reps, 256);
+  run<bf16_t>("flux  dma  d128 R4, 4 waves", (const void*)attn_dma_kernel<bf16_t, 128, 4, 4>, attn_dma_lds_bytes<128>(), 2, 24, 4608, 128, 256, reps, 256);
+#endif
 #if ATT_ABL == 0 || ATT_STAMP
   run<bf16_t>("flux  pipe d128 R2", (const void*)attn_pipe_kernel<bf16_t, 128, 2>, attn_pipe_lds_bytes<128>(), 2, 24, 4608, 128, 256, reps);
   run<f16_t>("sigma pipe d72  R2", (const void*)attn_pipe_kernel<f16_t, 72, 2>, attn_pipe_lds_bytes<72>(), 8, 16, 4096, 72, 256, reps);

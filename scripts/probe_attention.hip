@@ -67,6 +67,12 @@ int main(int argc, char** argv) {
   run<bf16_t>("flux  dma  d128 R2 (B2 H24 S4608)", (const void*)attn_dma_kernel<bf16_t, 128, 2>, attn_dma_lds_bytes<128>(), 2, 24, 4608, 128, 256, reps);
   run<f16_t>("sigma dma  d72  R2 (B8 H16 N4096)", (const void*)attn_dma_kernel<f16_t, 72, 2>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 256, reps);
   run<f16_t>("sigma dma  d72  R4", (const void*)attn_dma_kernel<f16_t, 72, 4>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 512, reps);
+#ifdef ATT_TRY_NW12
+  run<f16_t>("sigma dma  d72  R2, 12 waves", (const void*)attn_dma_kernel<f16_t, 72, 2, 12>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 384, reps, 768);
+  run<f16_t>("sigma dma  d72  R2, 16 waves", (const void*)attn_dma_kernel<f16_t, 72, 2, 16>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 512, reps, 1024);
+  run<f16_t>("sigma dma  d72  R1, 16 waves", (const void*)attn_dma_kernel<f16_t, 72, 1, 16>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 256, reps, 1024);
+  run<bf16_t>("flux  dma  d128 R1, 16 waves", (const void*)attn_dma_kernel<bf16_t, 128, 1, 16>, attn_dma_lds_bytes<128>(), 2, 24, 4608, 128, 256, reps, 1024);
+#endif
 #ifdef ATT_TRY_NW4
   run<f16_t>("sigma dma  d72  R8, 4 waves", (const void*)attn_dma_kernel<f16_t, 72, 8, 4>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 512, reps, 256);
   run<f16_t>("sigma dma  d72  R4, 4 waves", (const void*)attn_dma_kernel<f16_t, 72, 4, 4>, attn_dma_lds_bytes<72>(), 8, 16, 4096, 72, 256, reps, 256);

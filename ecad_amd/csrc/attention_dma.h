@@ -40,22 +40,15 @@ namespace ecad {
 #ifndef ATT_ABL
 #define ATT_ABL 0
 #endif
-// Probe switches (scripts/probe_attention.hip): ATT_KSWZ -- d_h 128 K image in unpadded 256-byte rows with the 16-byte column XOR-swizzled by the row (conflict-free
-// ds_read_b128; the padded 272-byte rows are 2-way on one slot per lane group); ATT_DMA_STAGGER -- waves 4-7 issue their DMA pieces after the first 64 keys.
+// Probe switch (scripts/probe_attention.hip): ATT_KSWZ -- d_h 128 K image in unpadded 256-byte rows with the 16-byte column XOR-swizzled by the row (conflict-free
+// ds_read_b128; the padded 272-byte rows are 2-way on one slot per lane group): -2 %.  Measured and removed again: the DMA pieces of waves 4-7 issued
+// half a chunk later (+6 %), all K fragments of a unit requested in one batch in front of its S MFMAs (+4 %: the wait moves into the row-maximum phase).
 #ifndef ATT_KSWZ
 #define ATT_KSWZ 0
-#endif
-#ifndef ATT_DMA_STAGGER
-#define ATT_DMA_STAGGER 0
 #endif
 // ATT_STAMP: wave 0 of workgroup 0 sums s_memtime deltas per loop phase into p.bias (reused as a u64[8] debug buffer): wait+barrier, DMA issue, S, softmax, PV, units
 #ifndef ATT_STAMP
 #define ATT_STAMP 0
-#endif
-// ATT_KPREF 1: all K fragments of a 64-key unit requested in one batch in front of the unit's S MFMAs (one exposed LDS latency per unit instead of one per pair of
-// reads); 2: the batch of the chunk's second unit is requested before the first unit's softmax and PV (two query fragments per wave only: 64 more registers)
-#ifndef ATT_KPREF
-#define ATT_KPREF 0
 #endif
 
 template <int DHC> constexpr int attn_dma_image_bytes() { return A128_KC * (AttCfg<DHC>::KS + AttCfg<DHC>::VS) * 2; }
@@ -172,45 +165,27 @@ __global__ __launch_bounds__(NW * 64) void attn_dma_kernel(const AttnArgs p) {
       const int n_item = more ? item : item + (int)gridDim.x, n_kc = more ? kc + 1 : 0;
       const bool any_next = n_item < items;
       const bool do_issue = any_next && !((ATT_ABL & 8) && (kc > 0 || item != (int)blockIdx.x));
-      if (do_issue && !(ATT_DMA_STAGGER && wave >= 4)) issue_chunk(n_item, n_kc, buf ^ 1);
+      if (do_issue) issue_chunk(n_item, n_kc, buf ^ 1);
 
       ATT_ST(1)
-      constexpr int KPREF = R <= 2 ? ATT_KPREF : 0;
-      Pack8 kfa[KPREF ? 4 : 1][KPREF ? KSTEPS : 1];
-      auto load_k = [&](const T* Kh) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks)
-            kfa[KPREF ? f : 0][KPREF ? ks : 0] = lds_read16(Kh + (16 * f + l15) * KS + (KSWZ ? ((4 * ks + g) ^ l15) * 8 : 32 * ks + 8 * g));
-      };
-      if constexpr (KPREF == 2) { load_k(Ks); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll KPREF == 2 ? 2 : 1
+#pragma unroll 1
       for (int half = 0; half < 2; ++half) {
-        if (ATT_DMA_STAGGER && half == 1 && wave >= 4 && do_issue) issue_chunk(n_item, n_kc, buf ^ 1);
         const T* Kh = Ks + half * 64 * KS;
         const T* Vh = Vs + half * 64 * VS;
         f32x4 s[R][4];
-        if constexpr (KPREF == 1) { load_k(Kh); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
 #pragma unroll
           for (int r = 0; r < R; ++r) s[r][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
-            Pack8 kf;
-            if constexpr (KPREF) kf = kfa[f][ks];
-            else kf = lds_read16(Kh + (16 * ((ATT_ABL & 2) ? 0 : f) + l15) * KS + (KSWZ ? ((4 * ks + g) ^ l15) * 8 : 32 * ks + 8 * g));
+            const Pack8 kf = lds_read16(Kh + (16 * ((ATT_ABL & 2) ? 0 : f) + l15) * KS + (KSWZ ? ((4 * ks + g) ^ l15) * 8 : 32 * ks + 8 * g));
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               if (ATT_ABL & 16) s[r][f][ks & 3] += __builtin_bit_cast(float, kf.u[0] & 0x3f800000u) * __builtin_bit_cast(float, qfr[r][ks].u[1] & 0x3f800000u);
               else s[r][f] = mfma16<T>(kf, qfr[r][ks], s[r][f]);
             }
           }
-        }
-        if constexpr (KPREF == 2) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (half == 0) { load_k(Ks + 64 * KS); __builtin_amdgcn_sched_barrier(0); }
         }
         ATT_ST(2)
         float m_new[R];

@@ -131,7 +131,12 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long st_c1 = 0, st_c2 = 0, st_ca = 0, st_cb = 0;
 #endif
-  if (!pre_issued) issue(0);
+  if (!pre_issued) {
+    // a later tile of the walk whose first K-step was not requested early (odd step count: the last step read stage 0): every wave must have left the previous
+    // tile's K loop before its ring is overwritten (the direct epilogue has no barrier of its own; the staged one ends with one)
+    if (vb != (int)blockIdx.x) __syncthreads();
+    issue(0);
+  }
   pre_issued = false;
 #ifndef G2_NO_XBAR
   // the last PN columns of a step's second fragment set are consumed after the NEXT barrier (4 * PN MFMAs of pipe work while the barrier

@@ -97,15 +97,16 @@ def test_gemm_every_kernel_by_call_site(dtype_name, kernel, site, epi, M, N, K):
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
-@pytest.mark.parametrize("epi,M,N", [(1, 8192, 4608), (1, 600, 4608), (0, 1000, 2304), (0, 300, 576)])
-def test_gemm2w_direct_epilogue_stores_the_staged_epilogues_bytes(dtype_name, epi, M, N):
+@pytest.mark.parametrize("epi,M,N,K", [(1, 8192, 4608, 1152), (1, 600, 4608, 1152), (0, 1000, 2304, 1152), (0, 300, 576, 1152), (1, 65536, 576, 320), (1, 32768, 1152, 128)])
+def test_gemm2w_direct_epilogue_stores_the_staged_epilogues_bytes(dtype_name, epi, M, N, K):
     """gemm2w.h (round 3): rows leave straight from the accumulator registers -- v_permlane16_swap between the packed registers of two neighbouring 16-column
     fragments turns a lane's two 8-byte pieces into one 16-byte piece, one store per fragment pair writes 64 contiguous bytes of 16 rows -- instead of through a
     C tile in LDS behind a barrier (the default for the GELU epilogue of FF1).  `sched` + 4 forces it for every epilogue, + 8 forces the staged path: the same
-    bytes, ragged last tile and a strided output included, and nothing outside the output columns is touched."""
+    bytes, ragged last tile and a strided output included, and nothing outside the output columns is touched.  With more tiles than CUs (a multiple of them) one
+    workgroup per CU walks its tiles and requests the next tile's first K-step under the epilogue: 8192 x 4608 (2 tiles per workgroup), 65536 x 576 x 320 (2 tiles,
+    an ODD number of K-steps: no early request, a barrier instead) and 32768 x 1152 x 128 (2 tiles of two K-steps)."""
     eng = small_engine(dtype_name)
     dt = getattr(torch, dtype_name)
-    K = 1152
     a, w = _r((M, K), dt, 1.0, 51), _r((N, K), dt, 0.05, 52)
     bias = _r((N,), torch.float32, 0.5, 53)
     outs = []

@@ -485,6 +485,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
         if (EPI == EPI_BIAS_SILU) v = silu(v);
         float_to_elem4<T>(o, r, v);
       }
+#ifdef G3_ABL_NOCTILE
+      if (EPI == EPI_BIAS_CACHE_RESID) { if (o.u[0] == 0x12345678u) *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u; } else
+#endif
       *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
     }
   }
@@ -512,6 +515,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
     if (id >= CHUNKS || m >= p.M) continue;
     const int n = n0 + cchunk * 8;
     Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+#ifdef G3_ABL_NOCTILE
+    if (EPI == EPI_BIAS_CACHE_RESID) v.u = (u32x4){0x1c001c00u ^ (unsigned)it, 0x1c001c00u, 0x1c001c00u, 0x1c001c00u};  // ablation build (wrong results): the read-modify-write epilogue without its C-tile round trip -- measured: no change end to end
+#endif
     if (EPI == EPI_BIAS_CACHE_RESID) {
       if (p.C) gstore16_nt(p.C + (size_t)m * p.ldc + n, v);
       T* rp = p.resid + (size_t)m * p.ldr + n;

@@ -317,6 +317,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
     if (const char* l = getenv("ECAD_EPI_DIRECT")) epi_direct = atoi(l);
     if (const char* l = getenv("ECAD_GEMM2W_WALK")) gemm2w_walk = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_WIDE_FILL")) wide_fill_rule = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_ATTN")) latency_attn = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_FILL")) latency_fill = atoi(l) > 0 ? atoi(l) : latency_fill;
     if (const char* l = getenv("ECAD_ATTN_WIDE")) attn_wide = atoi(l) != 0;
@@ -1182,6 +1183,7 @@ template <typename T> class EngineT : public EngineBase {
   bool latency_tiles = true;
   bool gemm2w_walk = true;  // gemm2w.h with the direct epilogue: grid = CUs, every workgroup walks its tiles (env ECAD_GEMM2W_WALK=0: one workgroup per tile)
   int epi_direct = 1;  // gemm2w.h epilogues straight from the registers: 0 none, 1 the GELU epilogue (FF1), 2 the plain ones too (env ECAD_EPI_DIRECT)
+  bool wide_fill_rule = true;  // env ECAD_WIDE_FILL=0: wide call sites keep their 256x288 tiles however few
   bool latency_attn = true;  // the attention-fused query projections take the latency tile too (env ECAD_LATENCY_ATTN=0: they keep the 256-row tile)
   int in_flight = 1;  // image batches the caller keeps in flight on this GPU (ecad_set_batches_in_flight)
   int latency_fill = 50;  // "few" = the 256-row tiles of the launch cover at most this percentage of the CUs (env ECAD_LATENCY_FILL)
@@ -1199,7 +1201,9 @@ template <typename T> class EngineT : public EngineBase {
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
     if (gemm_impl_cls[TAG] == 5 || (few_rows(g) && gemm_impl_cls[TAG] != 4)) return launch_quarter<EPI, TAG>(g, s);
     if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
-      if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0) {  // wide 256x288 tiles
+      // wide 256x288 tiles -- unless they would leave half the chip idle (FF1 at batch 4-7 alone on the GPU: 128-224 tiles): then the 256x144 tiles below, twice as many
+      const bool wide_underfills = g.N % G3_BN == 0 && ((g.M + G2_BM - 1) / G2_BM) * (g.N / G2_BN) * in_flight * 2 <= num_cus && !tile128_mode && wide_fill_rule;
+      if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0 && !wide_underfills) {
         if (!g2_attr[EPI][TAG]) {
           HIPCHK(hipFuncSetAttribute((const void*)gemm2w_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
           g2_attr[EPI][TAG] = true;
@@ -1220,7 +1224,7 @@ template <typename T> class EngineT : public EngineBase {
       hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3H_BM, G3H_NW, G3H_STAGES>), dim3(tilesh), dim3(G3H_NW * 64), G3H_LDS_BYTES, s, g);
       return ECAD_OK;
     }
-    if (gemm_impl_cls[TAG] == 0) {
+    if (gemm_impl_cls[TAG] == 0 || (gemm_impl_cls[TAG] == 2 && g.N % G3_BN == 0)) {  // (2: a wide call site whose wide tiles would underfill the chip)
       if (!g3_attr[EPI][TAG]) {
         HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
         g3_attr[EPI][TAG] = true;

@@ -317,6 +317,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
     if (const char* l = getenv("ECAD_EPI_DIRECT")) epi_direct = atoi(l);
     if (const char* l = getenv("ECAD_GEMM2W_WALK")) gemm2w_walk = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_TAIL_SPLIT")) tail_split = atoi(l) != 0;
     if (const char* l = getenv("ECAD_WIDE_FILL")) wide_fill_rule = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_ATTN")) latency_attn = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_FILL")) latency_fill = atoi(l) > 0 ? atoi(l) : latency_fill;
@@ -1188,13 +1189,14 @@ template <typename T> class EngineT : public EngineBase {
   int in_flight = 1;  // image batches the caller keeps in flight on this GPU (ecad_set_batches_in_flight)
   int latency_fill = 50;  // "few" = the 256-row tiles of the launch cover at most this percentage of the CUs (env ECAD_LATENCY_FILL)
   bool g3q_attr[4][KC_COUNT] = {};
-  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * in_flight * 100 <= num_cus * latency_fill; }
+  static int rows_of(const GemmArgs<T>& g) { return (g.m_end ? g.m_end : g.M) - g.m_begin; }  // rows this launch covers (tail split below)
+  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((rows_of(g) + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * in_flight * 100 <= num_cus * latency_fill; }
   template <int EPI, int TAG> int launch_quarter(const GemmArgs<T>& g, hipStream_t s) {
     if (!g3q_attr[EPI][TAG]) {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
       g3q_attr[EPI][TAG] = true;
     }
-    const int tq = ((g.M + G3Q_BM - 1) / G3Q_BM) * (g.N / G3_BN);
+    const int tq = ((rows_of(g) + G3Q_BM - 1) / G3Q_BM) * (g.N / G3_BN);
     hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3(tq), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
     return ECAD_OK;
   }
@@ -1202,13 +1204,13 @@ template <typename T> class EngineT : public EngineBase {
     if (gemm_impl_cls[TAG] == 5 || (few_rows(g) && gemm_impl_cls[TAG] != 4)) return launch_quarter<EPI, TAG>(g, s);
     if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
       // wide 256x288 tiles -- unless they would leave half the chip idle (FF1 at batch 4-7 alone on the GPU: 128-224 tiles): then the 256x144 tiles below, twice as many
-      const bool wide_underfills = g.N % G3_BN == 0 && ((g.M + G2_BM - 1) / G2_BM) * (g.N / G2_BN) * in_flight * 2 <= num_cus && !tile128_mode && wide_fill_rule;
+      const bool wide_underfills = g.N % G3_BN == 0 && ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN) * in_flight * 2 <= num_cus && !tile128_mode && wide_fill_rule;
       if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0 && !wide_underfills) {
         if (!g2_attr[EPI][TAG]) {
           HIPCHK(hipFuncSetAttribute((const void*)gemm2w_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
           g2_attr[EPI][TAG] = true;
         }
-        const int tiles2 = ((g.M + G2_BM - 1) / G2_BM) * (g.N / G2_BN);
+        const int tiles2 = ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN);
         // direct epilogue (LDS-free): one workgroup per CU walks its tiles and fetches the next tile's first K-step under the epilogue (gemm2w.h)
         const bool walk = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && g.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1) && gemm2w_walk && tiles2 > num_cus && tiles2 % num_cus == 0;
         hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(walk ? num_cus : tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);
@@ -1220,7 +1222,7 @@ template <typename T> class EngineT : public EngineBase {
         HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3H_BM, G3H_NW, G3H_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3H_LDS_BYTES));
         g3h_attr[EPI][TAG] = true;
       }
-      const int tilesh = ((g.M + G3H_BM - 1) / G3H_BM) * (g.N / G3_BN);
+      const int tilesh = ((rows_of(g) + G3H_BM - 1) / G3H_BM) * (g.N / G3_BN);
       hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3H_BM, G3H_NW, G3H_STAGES>), dim3(tilesh), dim3(G3H_NW * 64), G3H_LDS_BYTES, s, g);
       return ECAD_OK;
     }
@@ -1229,7 +1231,7 @@ template <typename T> class EngineT : public EngineBase {
         HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
         g3_attr[EPI][TAG] = true;
       }
-      const int tiles3 = ((g.M + G3_BM - 1) / G3_BM) * (g.N / G3_BN);
+      const int tiles3 = ((rows_of(g) + G3_BM - 1) / G3_BM) * (g.N / G3_BN);
       hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
       return ECAD_OK;
     }
@@ -1246,14 +1248,14 @@ template <typename T> class EngineT : public EngineBase {
         HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
         g3qa_attr[EPI - EPI_BIAS_ATTN] = true;
       }
-      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3((g.M / G3Q_BM) * (g.N / G3_BN)), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3((rows_of(g) / G3Q_BM) * (g.N / G3_BN)), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
       return ECAD_OK;
     }
     if (!g3a_attr[EPI - EPI_BIAS_ATTN]) {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
       g3a_attr[EPI - EPI_BIAS_ATTN] = true;
     }
-    const int tiles3 = (g.M / G3_BM) * (g.N / G3_BN);
+    const int tiles3 = (rows_of(g) / G3_BM) * (g.N / G3_BN);
     hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
     return ECAD_OK;
   }
@@ -1263,8 +1265,27 @@ template <typename T> class EngineT : public EngineBase {
   // whatever the tile count), not the tile count, is what small batches wait for.  Off by default so that the small-batch engine tests keep
   // exercising the kernels the headline configuration runs.
   bool use_tile128(const GemmArgs<T>& g) const { return tile128_mode == 2 && g.N % 128 == 0; }
+  // Tail split (round 3): a launch of w whole rounds of 256-row tiles plus a last round that would leave at least half the CUs idle (batch 100:
+  // 1600 tiles of the N = 1152 GEMMs = 6.25 rounds) goes out as two launches over row ranges -- the w whole rounds as they are, and the remaining rows as a
+  // problem of their own, which the few-rows / wide-underfill rules then put on 64-row latency tiles or 256 x 144 tiles.  Only with one batch in flight (with
+  // more, the other batches' kernels fill the idle CUs).  Same arithmetic per row, so results do not depend on it (env ECAD_TAIL_SPLIT=0: off).
+  bool tail_split = true;
   int launch_gemm(int epi, int cls, const GemmArgs<T>& g, hipStream_t s) {
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
+    if (tail_split && in_flight == 1 && !g.m_begin && !g.m_end && g.N % G3_BN == 0 && !use_tile128(g) && g.M % G3_BM == 0) {
+      const bool wide_site = cls == KC_GEMM_FF1 || cls == KC_GEMM_TEXTKV || cls == KC_GEMM_SMALL || cls == KC_GEMM_KV1;
+      const int tn_sel = wide_site && gemm_impl_cls[cls] == 2 && g.N % G2_BN == 0 ? g.N / G2_BN : g.N / G3_BN;
+      const int total = (g.M / G3_BM) * tn_sel, whole = total / num_cus, rem = total % num_cus;
+      if (whole >= 1 && rem > 0 && rem * 2 <= num_cus && (whole * num_cus) % tn_sel == 0 && gemm_impl_cls[cls] != 4 && gemm_impl_cls[cls] != 5) {
+        GemmArgs<T> part = g;
+        part.m_end = (whole * num_cus / tn_sel) * G3_BM;
+        int rc = launch_gemm(epi, cls, part, s);
+        if (rc) return rc;
+        part.m_begin = part.m_end;
+        part.m_end = g.M;
+        return launch_gemm(epi, cls, part, s);
+      }
+    }
     if (epi == EPI_BIAS_ATTN && cls == KC_GEMM_QKV) return launch_g3_attn<EPI_BIAS_ATTN, KC_GEMM_QKV>(g, s);
     if (epi == EPI_BIAS_ATTN_TAIL && cls == KC_GEMM_Q2) return launch_g3_attn<EPI_BIAS_ATTN_TAIL, KC_GEMM_Q2>(g, s);
     if (epi == EPI_BIAS_ATTN || epi == EPI_BIAS_ATTN_TAIL) return fail(ECAD_E_INVALID, "fused attention epilogue on call site %d", cls);

@@ -52,6 +52,8 @@ template <typename T> struct GemmArgs {
   float ln_eps, ln_inv_d;
   // read-modify-write epilogue (gemm3s.h): also publish (sum x, sum x^2) of the tile's 144 columns of the UPDATED hidden states, [N / 144][M][2] floats
   float* stat_out;
+  int m_begin, m_end;  // this launch covers rows [m_begin, m_end) of the M-row problem (m_end 0: up to M); both multiples of 256 when set: engine.hip splits a launch whose
+                       // last round of tiles would leave most CUs idle into whole rounds + a tail that takes the few-rows kernels
   int epi_direct;  // gemm2w.h plain / GELU / SiLU epilogues: 1 = rows leave straight from the registers (permlane-transposed 16-byte stores), 0 = through a C tile in LDS
   int variant;  // K-loop schedule of gemm3s.h / gemm2w.h: 0 = every wave issues its LDS-DMA pieces in one block after the barrier (round 1),
                 // 1 = staggered: pieces interleaved one per MFMA group, waves 0-3 in the first half of the step, waves 4-7 in the second

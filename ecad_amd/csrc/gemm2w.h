@@ -33,7 +33,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   const int wm = wave & 3, wn = wave >> 2;  // waves w and w+4 share a SIMD: one of each column half per SIMD
   const int l15 = lane & 15, g = lane >> 4;
   const int tiles_n = p.N / G2_BN;
-  const int tiles_m = (p.M + G2_BM - 1) / G2_BM;
+  const int tiles_m = ((p.m_end ? p.m_end : p.M) - p.m_begin + G2_BM - 1) / G2_BM;
   const int nwg = tiles_m * tiles_n;
   // tile id -> origin: ids are dealt to the XCDs in contiguous runs (tile_coords, gemm.h)
   auto origin = [&](int v, int& om0, int& on0) {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     int tm, tn;
     tile_coords(bid, tiles_m, tiles_n, tm, tn);
-    om0 = tm * G2_BM;
+    om0 = p.m_begin + tm * G2_BM;
     on0 = tn * G2_BN;
   };
   const T* a_src[A_INST];

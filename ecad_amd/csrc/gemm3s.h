@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
   const int tiles_n = p.N / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_m = ((p.m_end ? p.m_end : p.M) - p.m_begin + BM - 1) / BM;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   }
   int tm, tn;
   tile_coords(bid, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
 
   const T* a_src[A_INST];
   const T* b_src[B_INST_MAX];

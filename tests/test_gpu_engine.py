@@ -547,6 +547,46 @@ def test_latency_tiles_for_few_rows_are_the_same_arithmetic(monkeypatch, dtype, 
     assert torch.equal(res["1"][1], res["0"][1])
 
 
+def test_tail_split_of_a_partial_last_round_is_the_same_arithmetic(monkeypatch):
+    """20 images (M = 10240 rows) are 320 tiles of the N = 1152 GEMMs -- one whole round of the 256 CUs and a quarter of a second one.  The engine launches
+    the whole rounds and the remaining rows separately (row ranges of one problem: `GemmArgs::m_begin / m_end`), and the tail takes the few-rows kernels (64-row
+    latency tiles, or 256 x 144 tiles for the wide call sites).  Per-step outputs and whole-loop latents must equal the single-launch engine's bit for bit, with the
+    LayerNorm fold, the fused attention launches and the cache gate in play."""
+    from ecad_amd.engine import EcadEngine
+
+    monkeypatch.setenv("ECAD_LATENCY_TILES", "1")
+    layers, steps, B = 2, 5, 20
+    bits = rand_bits(steps, layers, 0.6, seed=31)
+    bits[0] = True
+    cfg = PixArtConfig(num_layers=layers)
+    w = make_weights(cfg, seed=4)
+    inp, enc, mask = cfg_inputs(B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ECAD_TAIL_SPLIT", mode)
+        eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
+        eng.load_state_dict(w)
+        eng.set_schedule(bits)
+        eng.begin_image_batch(enc.cuda(), mask.cuda(), 32, 32)
+        g = torch.Generator().manual_seed(6)
+        per_step = []
+        for s in range(steps):
+            x = torch.randn(2 * B, 4, 32, 32, generator=g)
+            t = torch.tensor([999.0 - 50 * s] * (2 * B))
+            per_step.append(eng.step(s, x.cuda(), t.cuda()).cpu())
+        a = eng.run_schedule(enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5, use_graph=True)
+        b = eng.run_schedule(enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
+        assert torch.equal(a, b)
+        res[mode] = (per_step, a.cpu(), eng.stats()["ln_folded"])
+        eng.close()
+    assert res["1"][2] == res["0"][2] > 0
+    for x, y in zip(res["1"][0], res["0"][0]):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+    assert torch.equal(res["1"][1], res["0"][1])
+
+
 def test_batches_in_flight_pick_the_tile_shape_not_the_result(monkeypatch):
     """ecad_set_batches_in_flight: the few-rows rule counts the tiles of all the batches a caller keeps in flight, so a pool of execution contexts with
     small batches runs the 256-row throughput kernels while a single small batch runs the 64-row latency tiles.  Same arithmetic either way: the latents are equal

@@ -1221,7 +1221,9 @@ template <typename T> class FluxT : public FluxBase {
     }
     return ECAD_OK;
   }
-  int launch_gemm8(int epi, int bn, const FGemm8Args<T>& q, hipStream_t s) {
+  int launch_gemm8(int epi, int bn, const FGemm8Args<T>& q_in, hipStream_t s) {
+    FGemm8Args<T> q = q_in;
+    q.e.epi_direct = epi_direct;  // the GELU tiles of the fp8 GEMMs share fgemm.h's epilogue
     if (q.e.K % GEMM8_BK || q.e.M < 1 || q.e.N % bn) return fail(ECAD_E_INVALID, "fp8 gemm shape M=%d N=%d K=%d unsupported", q.e.M, q.e.N, q.e.K);
     return bn == 256 ? launch_gemm8_bn<256>(epi, q, s) : launch_gemm8_bn<128>(epi, q, s);
   }

@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libecad_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ECAD_DTYPE_F16, ECAD_DTYPE_BF16, ECAD_DTYPE_F32 = 0, 1, 2
 ECAD_E_INVALID, ECAD_E_HIP, ECAD_E_NOT_READY, ECAD_E_UNSUPPORTED = -1, -2, -3, -4
@@ -61,6 +61,9 @@ class EcadStats(C.Structure):
         ("ln_folded", C.c_int32),
         ("fold_preps", C.c_int32),
         ("fold_bytes", C.c_int64),
+        ("fold_arena_bytes", C.c_int64),
+        ("fold_refused", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -123,6 +126,7 @@ SIGNATURES = {
     "ecad_set_batches_in_flight": (_I, [_P, _I]),
     "ecad_set_fp8": (_I, [_P, _I]),
     "ecad_set_added_cond": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I]),
+    "ecad_set_attention_bias": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ecad_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),
     "ecad_begin_image_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ecad_step": (_I, [_P, _I, _P, _P, _P, _P]),

@@ -71,6 +71,13 @@ template <typename T> ECAD_DEV float round_elem(float v);
 template <> ECAD_DEV float round_elem<f16_t>(float v) { return (float)(f16_t)v; }
 template <> ECAD_DEV float round_elem<bf16_t>(float v) { return (float)(bf16_t)v; }
 
+// fp16 saturation of the FLUX block outputs: `if hidden_states.dtype == torch.float16: hidden_states = hidden_states.clip(-65504, 65504)`
+// (cached_flux_transformer_block.py:127-128,288-289): an overflowed sum (+-inf after rounding to fp16) becomes +-65504; bf16 is left alone; NaN stays NaN.
+template <typename T> ECAD_DEV float clip_half(float v) {
+  if constexpr (std::is_same<T, f16_t>::value) return v > 65504.0f ? 65504.0f : (v < -65504.0f ? -65504.0f : v);
+  else return v;
+}
+
 // D(16x16) += A(16x32) * B(32x16); lane l holds A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15];
 // D[row 4(l>>4)+r][col l&15] in element r.
 template <typename T> ECAD_DEV f32x4 mfma16(const Pack8& a, const Pack8& b, f32x4 c);

@@ -509,10 +509,11 @@ template <typename T> __global__ void silu_kernel(const T* __restrict__ x, T* __
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (T)silu((float)x[i]);
 }
 
-// mask (1 keep / 0 discard) -> additive bias (1 - m) * -10000  (pixart_transformer_2d_edited.py:282-289)
-static __global__ void mask_bias_kernel(const uint8_t* __restrict__ mask, float* __restrict__ bias, int n) {
+// mask (1 keep / 0 discard) -> additive bias (1 - m) * -10000  (pixart_transformer_2d_edited.py:282-289); a bias handed over as such (`user`, :271-279: a 3-D
+// encoder_attention_mask is added as given) takes its place
+static __global__ void mask_bias_kernel(const uint8_t* __restrict__ mask, const float* __restrict__ user, float* __restrict__ bias, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) bias[i] = mask ? (1.0f - (float)(mask[i] != 0)) * -10000.0f : 0.f;
+  if (i < n) bias[i] = user ? user[i] : mask ? (1.0f - (float)(mask[i] != 0)) * -10000.0f : 0.f;
 }
 
 // ---- Timesteps(256, flip_sin_to_cos, shift 0): out[m] = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) i / 128)

@@ -72,6 +72,7 @@ struct EngineBase {
   virtual int set_ln_fold(int on) = 0;
   virtual int set_batches_in_flight(int n) = 0;
   virtual int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt) = 0;
+  virtual int set_attention_bias(const float* self_bias, const float* enc_bias, int Bt, int N, int T, hipStream_t st) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
   virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st) = 0;
   virtual int step(int step_idx, const void* latents, const float* timestep, void* out, hipStream_t st) = 0;
@@ -131,7 +132,14 @@ template <typename T> class EngineT : public EngineBase {
   // ---- weights
   char* warena = nullptr;
   size_t warena_bytes = 0, warena_used = 0;
-  bool weights_shared = false;  // ecad_share_weights: warena and every pointer into it belong to another engine (which must outlive this one)
+  bool weights_shared = false;  // ecad_share_weights: warena and every pointer into it came from another engine
+  // The arena is owned jointly by the engine that loaded the weights and every context that borrows them (ecad_share_weights): the last one to go frees it, so
+  // destroying the donor first leaves the borrowers intact.  `gen` counts changes of the arena's content (ecad_load_weights / ecad_finalize_weights on the owner):
+  // a borrower that sees a generation it has not lowered its plans for drops them (plan sets, hipGraph, the LayerNorm-fold copies W' / c1 / c2 are all
+  // derived from the weights) before it runs anything.
+  struct SharedArena { char* base; int refs; uint64_t gen; bool finalized; };
+  SharedArena* sarena = nullptr;
+  uint64_t seen_gen = 0;
   struct Dest { void* ptr; bool f32; int64_t rows, cols, ld; bool loaded; };
   std::map<std::string, Dest> dests;
   struct Blk {
@@ -174,18 +182,25 @@ template <typename T> class EngineT : public EngineBase {
   bool fold_plan_on = false;          // build_plans: this plan set folds (geometry, dtype mode and kernels permit it, arena acquired)
   float* hstat = nullptr;             // [D / 144][max rows][2]: per-row partial (sum x, sum x^2) of the hidden states, written by the read-modify-write GEMMs
   struct FoldArena { char* base = nullptr; size_t cap = 0; };
-  std::vector<FoldArena> fold_pool;   // arenas of parked / evicted plan sets, recycled (grow-only): no hipFree (a device-wide sync) on a schedule change
+  std::vector<FoldArena> fold_pool;   // arenas of parked / evicted plan sets, recycled: no hipFree (a device-wide sync) on a schedule change while they fit the budget
+  size_t fold_budget = (size_t)24 << 30;  // bytes this engine may hold in fold arenas (live + parked plan sets + pool); env ECAD_LN_FOLD_BUDGET_MB.  An all-executed 20-step
+                                      // schedule needs ~10 GB per plan set, `ours_fast` 3.3 GB; a plan set that does not fit is lowered WITHOUT the fold (same results
+                                      // within the fold's tolerance, ~1.5 % slower) instead of failing
   FoldArena fold_cur;                 // pre-scaled weights W', c1, c2 of the live plan set
   std::vector<FoldDesc> fold_descs;   // one per folded (step, block, attn1 | ff); uploaded behind the weights in fold_cur
   size_t fold_used = 0;
   bool fold_built = false;            // the arena holds what fold_descs describe, for the timesteps in ts_host
   size_t fold_prep_ops = 0;           // plan_run[n_begin .. n_begin + fold_prep_ops) = timestep MLP + comb vectors: what the prep needs before the first replay
   size_t fold_prep_begin = 0;
-  int ln_folded = 0, fold_preps = 0;
+  int ln_folded = 0, fold_preps = 0, fold_refused = 0;
   std::vector<float> fold_ts;         // the timesteps the arena was prepared for
   bool use_comb = true;  // env ECAD_LN_COMB=0: LN reads table + modulation separately (fp32 sum), as the per-step plans do
   float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
   uint8_t* mask_buf;
+  // additive attention biases handed over as such (forward(attention_mask=..., encoder_attention_mask=<3-D bias>), pixart_transformer_2d_edited.py:255-291):
+  // one float per (sample, key), broadcast over heads and queries.  self: [Bt][N] for attn1; enc: [Bt][T] replaces the bias derived from the 0/1 mask.
+  float *self_bias_buf = nullptr, *enc_bias_user = nullptr;
+  bool self_bias_on = false, enc_bias_on = false;
   SrcDesc* desc_dev = nullptr;
   size_t desc_cap = 0;
   // ---- schedule / plans
@@ -265,7 +280,9 @@ template <typename T> class EngineT : public EngineBase {
     if (desc_dyn_dev) (void)hipFree(desc_dyn_dev);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
-    if (warena && !weights_shared) (void)hipFree(warena);  // a borrowed arena belongs to the engine it came from
+    if (sarena) {
+      if (--sarena->refs == 0) { (void)hipFree(sarena->base); delete sarena; }
+    } else if (warena) (void)hipFree(warena);
     if (pos) (void)hipFree(pos);
     if (ws) (void)hipFree(ws);
     for (void* q : w8allocs) (void)hipFree(q);
@@ -311,6 +328,7 @@ template <typename T> class EngineT : public EngineBase {
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
     if (const char* l = getenv("ECAD_LN_COMB")) use_comb = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LN_FOLD")) ln_fold = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_LN_FOLD_BUDGET_MB")) fold_budget = (size_t)(atoll(l) > 0 ? atoll(l) : 0) << 20;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
     if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : strcmp(at, "dma4") == 0 ? 2 : 0; }
@@ -332,6 +350,7 @@ template <typename T> class EngineT : public EngineBase {
       if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
       if (strcmp(gi, "tile128") == 0) tile128_mode = 2;
       if (strcmp(gi, "wide") == 0) gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_SMALL] = 2;
+      if (strcmp(gi, "classic") && strcmp(gi, "tile128") && strcmp(gi, "wide")) return fail(ECAD_E_INVALID, "ECAD_GEMM=%s: unknown (classic | tile128 | wide; 'persistent' was retired in round 3)", gi);
     }
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
@@ -346,6 +365,7 @@ template <typename T> class EngineT : public EngineBase {
     warena_bytes = (per_blk_T * L + glob_T) * sizeof(T) + (per_blk_f * L + glob_f) * sizeof(float) + (size_t)(L * 16 + 64) * 256;
     HIPCHK(hipMalloc((void**)&warena, warena_bytes));
     HIPCHK(hipMemset(warena, 0, warena_bytes));
+    sarena = new SharedArena{warena, 1, 0, false};
     blk.resize(L);
     w_kv2_all = walloc<T>((size_t)L * 2 * d * d);
     b_kv2_all = walloc<float>((size_t)L * 2 * d);
@@ -441,6 +461,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t o_cond = take(Bm * 3 * sizeof(float)), o_szemb = take(Bm * d * sizeof(T));
     const size_t o_comb = take(max_steps * (size_t)L * 4 * d * sizeof(T));
     const size_t o_hstat = take((d / 144 + 1) * M * 2 * sizeof(float));
+    const size_t o_sbias = take(M * sizeof(float)), o_ebias = take(Mt * sizeof(float));
     ws_bytes = off;
     HIPCHK(hipMalloc((void**)&ws, ws_bytes));
     HIPCHK(hipMemset(ws, 0, ws_bytes));
@@ -453,6 +474,7 @@ template <typename T> class EngineT : public EngineBase {
     cond_dev = (float*)(ws + o_cond); size_emb = (T*)(ws + o_szemb);
     comb = (T*)(ws + o_comb);
     hstat = (float*)(ws + o_hstat);
+    self_bias_buf = (float*)(ws + o_sbias); enc_bias_user = (float*)(ws + o_ebias);
     st.workspace_bytes = (int64_t)ws_bytes;
     st.cache_arena_bytes = (int64_t)((size_t)L * 3 * M * d * sizeof(T));
 
@@ -504,6 +526,7 @@ template <typename T> class EngineT : public EngineBase {
     if (e != hipSuccess) return fail(ECAD_E_HIP, "weight conversion failed: %s", hipGetErrorString(e));
     d.loaded = true;
     finalized = false;
+    sarena->finalized = false; ++sarena->gen;  // contexts that borrow this arena re-lower before their next run (weights_current)
     return ECAD_OK;
   }
 
@@ -511,8 +534,23 @@ template <typename T> class EngineT : public EngineBase {
     for (auto& kv : dests)
       if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "weight '%s' was never loaded", kv.first.c_str());
     finalized = true;
+    sarena->finalized = true; seen_gen = ++sarena->gen;
     drop_all_plans();
     if (fp8) return build_fp8_weights();
+    return ECAD_OK;
+  }
+  // a context that borrows its weights: has the owner changed them since this context last lowered its plans?
+  int weights_current() {
+    if (!weights_shared) return ECAD_OK;
+    if (!sarena->finalized) { finalized = false; return fail(ECAD_E_NOT_READY, "the engine this context borrows its weights from is loading new ones: call ecad_finalize_weights on it first"); }
+    finalized = true;
+    if (seen_gen != sarena->gen) {
+      if (graph_exec || graph || !plan_lru.empty()) (void)hipDeviceSynchronize();  // a graph of the old weights may still be in flight
+      drop_all_plans();
+      fold_release_current();
+      batch_begun = false;
+      seen_gen = sarena->gen;
+    }
     return ECAD_OK;
   }
   // Second (third ...) execution context on the same GPU: this engine keeps its own workspaces, cache arena, plans and hipGraph but reads the weights of
@@ -536,7 +574,11 @@ template <typename T> class EngineT : public EngineBase {
     for (int k = 0; k < 2; ++k) { rb(w_sz1[k]); rb(w_sz2[k]); rb(b_sz1[k]); rb(b_sz2[k]); }
     for (auto& kv : dests) { kv.second.ptr = reinterpret_cast<char*>(kv.second.ptr) + delta; kv.second.loaded = true; }
     (void)hipFree(warena);
+    delete sarena;
     warena = src->warena;
+    sarena = src->sarena;
+    ++sarena->refs;
+    seen_gen = sarena->gen;
     weights_shared = true;
     finalized = true;
     return ECAD_OK;
@@ -575,6 +617,24 @@ template <typename T> class EngineT : public EngineBase {
     }
     HIPCHK(hipMemcpy(cond_dev, cond_host.data(), cond_host.size() * sizeof(float), hipMemcpyHostToDevice));
     cond_bt = Bt_;
+    return ECAD_OK;
+  }
+  // attention_mask / encoder_attention_mask of forward when they arrive as additive biases (or, for self-attention, at all): the reference turns a 2-D 0/1
+  // mask into (1 - m) * -10000 and adds a 3-D [B, 1, keys] bias as given (pixart_transformer_2d_edited.py:271-291); the host does the first, this the second.
+  // Per (sample, key) floats on the device, copied on `st`; NULL switches that bias off.  Plans are keyed by which biases are on: with a self-attention bias
+  // attn1 runs as Q/K/V projections + the masked stand-alone attention kernel (the fused tails take no key bias on self-attention).
+  int set_attention_bias(const float* self_bias, const float* enc_bias, int Bt_, int N_, int T_, hipStream_t s) override {
+    HIPCHK(hipSetDevice(dev));
+    if (Bt_ < 1 || Bt_ > cfg.max_batch) return fail(ECAD_E_INVALID, "batch %d outside [1, max_batch=%d]", Bt_, cfg.max_batch);
+    if (self_bias && (N_ < 1 || N_ > cfg.max_tokens)) return fail(ECAD_E_INVALID, "self-attention bias: %d keys outside [1, max_tokens=%d]", N_, cfg.max_tokens);
+    if (enc_bias && (T_ < 1 || T_ > cfg.max_text_tokens)) return fail(ECAD_E_INVALID, "encoder attention bias: %d keys outside [1, max_text_tokens=%d]", T_, cfg.max_text_tokens);
+    if ((self_bias != nullptr) != self_bias_on || (enc_bias != nullptr) != enc_bias_on) {
+      stash_current();
+      self_bias_on = self_bias != nullptr; enc_bias_on = enc_bias != nullptr;
+      batch_begun = false;
+    }
+    if (self_bias) HIPCHK(hipMemcpyAsync(self_bias_buf, self_bias, (size_t)Bt_ * N_ * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (enc_bias) HIPCHK(hipMemcpyAsync(enc_bias_user, enc_bias, (size_t)Bt_ * T_ * sizeof(float), hipMemcpyDeviceToDevice, s));
     return ECAD_OK;
   }
   int quant_weight(const T* w, size_t rows, int K) {
@@ -673,22 +733,37 @@ template <typename T> class EngineT : public EngineBase {
     e.ge = nullptr; e.g = nullptr; e.dd = nullptr; e.fold = FoldArena{};
   }
   // an arena of at least `need` bytes: the smallest pooled one that fits, else a new allocation (the largest pooled one goes first, so the pool does not grow)
-  int fold_acquire(size_t need) {
+  size_t fold_held() const {
+    size_t t = fold_cur.cap;
+    for (auto& a : fold_pool) t += a.cap;
+    for (auto& e : plan_lru) t += e.fold.cap;
+    return t;
+  }
+  // false: no arena (over the budget, or the device is out of memory) -- the caller lowers the plan set without the fold
+  bool fold_acquire(size_t need) {
     int best = -1;
     for (int i = 0; i < (int)fold_pool.size(); ++i)
       if (fold_pool[i].cap >= need && (best < 0 || fold_pool[i].cap < fold_pool[best].cap)) best = i;
-    if (best >= 0) { fold_cur = fold_pool[best]; fold_pool.erase(fold_pool.begin() + best); return ECAD_OK; }
-    if (!fold_pool.empty()) {
+    if (best >= 0) { fold_cur = fold_pool[best]; fold_pool.erase(fold_pool.begin() + best); return true; }
+    fold_cur = FoldArena{};
+    const size_t cap = need + (need >> 3);
+    // nothing pooled fits: pooled arenas go (largest first) until the new one fits the budget; parked plan sets keep theirs
+    for (bool first = true; !fold_pool.empty() && (first || fold_held() + cap > fold_budget); first = false) {  // (one always goes, so that the pool does not grow)
       int big = 0;
       for (int i = 1; i < (int)fold_pool.size(); ++i) if (fold_pool[i].cap > fold_pool[big].cap) big = i;
       (void)hipFree(fold_pool[big].base);
       fold_pool.erase(fold_pool.begin() + big);
     }
-    fold_cur = FoldArena{};
-    const size_t cap = need + (need >> 3);
-    HIPCHK(hipMalloc((void**)&fold_cur.base, cap));
+    if (fold_held() + cap > fold_budget) return false;
+    if (hipMalloc((void**)&fold_cur.base, cap) != hipSuccess) {
+      (void)hipGetLastError();  // out of device memory is not an error of this call: the plan set runs unfolded
+      for (auto& a : fold_pool) (void)hipFree(a.base);
+      fold_pool.clear();
+      fold_cur = FoldArena{};
+      return false;
+    }
     fold_cur.cap = cap;
-    return ECAD_OK;
+    return true;
   }
   void fold_release_current() {
     if (fold_cur.base) fold_pool.push_back(fold_cur);
@@ -698,7 +773,8 @@ template <typename T> class EngineT : public EngineBase {
   std::string make_key() const {
     std::string k((const char*)bits.data(), bits.size());
     k.append((const char*)custom_mask.data(), custom_mask.size());
-    const int geo[12] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0, ln_fold ? 1 : 0, in_flight};
+    const int geo[13] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0, ln_fold ? 1 : 0, in_flight,
+                         (self_bias_on ? 1 : 0) | (enc_bias_on ? 2 : 0)};
     k.append((const char*)geo, sizeof geo);
     return k;
   }
@@ -886,8 +962,8 @@ template <typename T> class EngineT : public EngineBase {
         // Long sequences (N >= 1024, e.g. Sigma-1024's 4096 tokens): the attention kernel with FOUR query fragments per wave (attention_dma.h R = 4: K / V staged
         // once per 512 query rows, every fragment read feeds four MFMAs) beats the fused tail, whose 256-row tile fixes two fragments per wave: Sigma-1024 shape 750
         // against 850 us stand-alone, and the Q round trip it reintroduces is 2 % of that launch.  env ECAD_ATTN_WIDE=0: fused tail at every length.
-        const bool wide_items = attn_wide && !fp8 && DH == 72 && N >= 1024 && N % 512 == 0 && split_qkv && (2 * D) % G2_BN == 0 && attn_shared;
-        const bool fuse1 = fuse_attn && !wide_items && !fp8 && DH == 72 && split_qkv && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0;
+        const bool wide_items = attn_wide && !fp8 && DH == 72 && N >= 1024 && N % 512 == 0 && split_qkv && (2 * D) % G2_BN == 0 && attn_shared && !self_bias_on;
+        const bool fuse1 = fuse_attn && !wide_items && !fp8 && DH == 72 && split_qkv && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0 && !self_bias_on;
         const bool fold1 = fold_plan && (fuse1 || wide_items) && cb && pend.empty() && stats_ok;
         const T* a_in = xn;
         const T* w_in = B.w_qkv;
@@ -930,8 +1006,8 @@ template <typename T> class EngineT : public EngineBase {
         } else {
           push_gemm(ops, mk_gemm(KC_GEMM_QKV, EPI_BIAS, xn, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D), true);
         }
-        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0; a.i0 = wide_items ? 1 : 0;
-        a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
+        Op<T> a; a.kind = Op<T>::ATTN; a.cls = KC_ATTN_SELF; a.attn_masked = (N % 128) != 0 || self_bias_on; a.i0 = wide_items ? 1 : 0;
+        a.a.q = qkv; a.a.k = qkv + D; a.a.v = qkv + 2 * D; a.a.out = attn_o; a.a.bias = self_bias_on ? self_bias_buf : nullptr; a.a.ldq = a.a.ldk = a.a.ldv = 3 * D; a.a.ldo = D;
         a.a.B = Bt; a.a.H = NH; a.a.Nq = N; a.a.Nk = N; a.a.dh = DH; a.a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
         a.flops = attn1_flops; a.bytes = 4.0 * M * (double)D * sizeof(T);
         ops.push_back(a);
@@ -1042,7 +1118,7 @@ template <typename T> class EngineT : public EngineBase {
 
   void emit_begin(std::vector<Op<T>>& ops) {
     const int Mt = Bt * Tt;
-    Op<T> m; m.kind = Op<T>::MASKBIAS; m.cls = KC_MISC; m.p0 = mask_buf; m.p2 = bias_buf; m.i0 = Mt;
+    Op<T> m; m.kind = Op<T>::MASKBIAS; m.cls = KC_MISC; m.p0 = mask_buf; m.p1 = enc_bias_on ? enc_bias_user : nullptr; m.p2 = bias_buf; m.i0 = Mt;
     ops.push_back(m);
     // caption projection, hoisted: step-invariant (pixart_transformer_2d_edited.py:315-321)
     ops.push_back(mk_gemm(KC_GEMM_CAPTION, EPI_BIAS_GELU, enc_buf, w_c1, b_c1, ctx_mid, Mt, D, CAP, CAP, D));
@@ -1087,7 +1163,7 @@ template <typename T> class EngineT : public EngineBase {
         for (int b_ = 0; b_ < L; ++b_) { n1 += executed[((size_t)s_ * L + b_) * 3 + 0]; n2 += executed[((size_t)s_ * L + b_) * 3 + 2]; }
       const size_t need = n1 * ((size_t)3 * D * D * sizeof(T) + 2 * (((size_t)3 * D * 4 + 255) & ~(size_t)255) + 256) +
                           n2 * ((size_t)4 * D * D * sizeof(T) + 2 * (((size_t)4 * D * 4 + 255) & ~(size_t)255) + 256) + (n1 + n2 + 1) * sizeof(FoldDesc) + 4096;
-      if (int rc = fold_acquire(need)) return rc;
+      if (!fold_acquire(need)) { fold_plan_on = false; ++fold_refused; }
     }
     { Op<T> d; d.kind = Op<T>::DUP; d.cls = KC_MISC; plan_run.push_back(d); }
     for (int s = 0; s < steps; ++s) {
@@ -1138,6 +1214,7 @@ template <typename T> class EngineT : public EngineBase {
     const int n = (H_ / P) * (W_ / P);
     if (n > cfg.max_tokens) return fail(ECAD_E_INVALID, "%d image tokens exceed max_tokens %d", n, cfg.max_tokens);
     if (T_ < 1 || T_ > cfg.max_text_tokens) return fail(ECAD_E_INVALID, "text tokens %d outside [1, %d]", T_, cfg.max_text_tokens);
+    if (int rcw = weights_current()) return rcw;
     if (!plan_valid || Bt_ != Bt || H_ != Hl || W_ != Wl || T_ != Tt) {
       stash_current();
       Bt = Bt_; Hl = H_; Wl = W_; Tt = T_; N = n;
@@ -1448,7 +1525,7 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::COMB:
         hipLaunchKernelGGL((comb_mod_kernel<T>), dim3(steps, L), dim3(256), 0, s, blk[0].sst, (int64_t)(L > 1 ? blk[1].sst - blk[0].sst : 0), (const T*)mod_all, comb, L, D);
         break;
-      case Op<T>::MASKBIAS: hipLaunchKernelGGL(mask_bias_kernel, dim3((o.i0 + 255) / 256), dim3(256), 0, s, (const uint8_t*)o.p0, (float*)o.p2, o.i0); break;
+      case Op<T>::MASKBIAS: hipLaunchKernelGGL(mask_bias_kernel, dim3((o.i0 + 255) / 256), dim3(256), 0, s, (const uint8_t*)o.p0, (const float*)o.p1, (float*)o.p2, o.i0); break;
       case Op<T>::FINAL: {
         FinalProj fq{};
         fq.w = w_proj; fq.bias = b_proj; fq.out = o.call_out ? call_out : o.p2; fq.gh = Hl / P; fq.gw = Wl / P; fq.P = P; fq.Cout = COUT;
@@ -1538,6 +1615,7 @@ template <typename T> class EngineT : public EngineBase {
 
   int step(int step_idx, const void* latents, const float* timestep, void* out, hipStream_t s) override {
     HIPCHK(hipSetDevice(dev));
+    if (int rcw = weights_current()) return rcw;
     if (!batch_begun || !plan_valid) return fail(ECAD_E_NOT_READY, "ecad_begin_image_batch must be called before ecad_step");
     if (step_idx < 0 || step_idx >= steps) return fail(ECAD_E_INVALID, "step_idx %d outside [0, %d)", step_idx, steps);
     if (!latents || !timestep || !out) return fail(ECAD_E_INVALID, "NULL pointer argument");
@@ -1678,8 +1756,8 @@ template <typename T> class EngineT : public EngineBase {
     int rc;
     if (which == 1) {
       if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_QKV, mk_gemm(KC_GEMM_QKV, EPI_BIAS, (const T*)x, B.w_qkv, B.b_qkv, qkv, M, 3 * D, D, D, 3 * D).g, s))) return rc;
-      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D; a.Nk = N; a.bias = nullptr;
-      if ((rc = launch_attn(a, (N % 128) != 0, s))) return rc;
+      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D; a.Nk = N; a.bias = self_bias_on ? self_bias_buf : nullptr;
+      if ((rc = launch_attn(a, (N % 128) != 0 || self_bias_on, s))) return rc;
       if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_SMALL, mk_gemm(KC_GEMM_SMALL, EPI_BIAS, attn_o, B.w_o1, B.b_o1, (T*)out, M, D, D, D, D).g, s))) return rc;
     } else {
       if ((rc = launch_gemm(EPI_BIAS, KC_GEMM_Q2, mk_gemm(KC_GEMM_Q2, EPI_BIAS, (const T*)x, B.w_q2, B.b_q2, qc, M, D, D, D, D).g, s))) return rc;
@@ -1716,6 +1794,7 @@ template <typename T> class EngineT : public EngineBase {
     *s = st;
     s->plan_builds = plan_builds; s->graph_captures = graph_captures; s->dynamic_step_plans = dynamic_steps; s->plan_sets_cached = (int32_t)plan_lru.size();
     s->ln_folded = ln_folded; s->fold_preps = fold_preps; s->fold_bytes = (int64_t)fold_used;
+    s->fold_arena_bytes = (int64_t)fold_held(); s->fold_refused = fold_refused;
     return ECAD_OK;
   }
   int set_profiling(int on) override {
@@ -1911,6 +1990,7 @@ int ecad_share_weights(EcadEngine* e, EcadEngine* donor) {
 }
 int ecad_set_fp8(EcadEngine* e, int on) { ENG(e); return E->set_fp8(on); }
 int ecad_set_added_cond(EcadEngine* e, const float* resolution, const float* aspect_ratio, int Bt) { ENG(e); return E->set_added_cond(resolution, aspect_ratio, Bt); }
+int ecad_set_attention_bias(EcadEngine* e, const float* self_bias_dev, const float* enc_bias_dev, int Bt, int N, int T, void* stream) { ENG(e); return E->set_attention_bias(self_bias_dev, enc_bias_dev, Bt, N, T, (hipStream_t)stream); }
 int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks) { ENG(e); if (!bits) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bits, steps, blocks); }
 int ecad_begin_image_batch(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, void* stream) { ENG(e); return E->begin_batch(Bt, H, W, enc, mask, T, (hipStream_t)stream); }
 int ecad_step(EcadEngine* e, int step_idx, const void* lat, const float* ts, void* out, void* stream) { ENG(e); return E->step(step_idx, lat, ts, out, (hipStream_t)stream); }

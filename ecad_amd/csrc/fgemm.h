@@ -59,6 +59,7 @@ template <typename T> struct FGemmArgs {
   float rope_eps;
   T* C2;                // FEPI_QKV_ROPE_MLP: gelu(mlp) output
   int ldc2, n_split;
+  int clip16;           // FEPI_BIAS_GATE_RESID: the updated rows are a FLUX block's output: fp16 saturates at +-65504 (cached_flux_transformer_block.py:127-128,288-289)
   int epi_direct;       // GELU tiles leave straight from the registers (permlane-transposed 16-byte stores, gemm2w.h) instead of through the C tile in LDS
 };
 
@@ -367,6 +368,10 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] += o[e];
       }
+      if (p.clip16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = clip_half<T>(h[e]);
+      }
       gstore16(p.resid + (size_t)m * p.ldr + n, pack8<T>(h));
     }
     return;
@@ -394,6 +399,10 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] += o[e];
+      }
+      if (p.clip16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = clip_half<T>(h[e]);
       }
       gstore16(rp, pack8<T>(h));
     } else if (EPI == FEPI_QKV_ROPE || EPI == FEPI_QKV_ROPE_MLP) {

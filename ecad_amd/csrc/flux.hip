@@ -571,8 +571,9 @@ template <typename T> class FluxT : public FluxBase {
   Range r_img() const { return Range{hs + (size_t)B * Tt * D, xn + (size_t)B * Tt * D, B * N, 0, 1, N, (size_t)B * Tt}; }
   Range r_txt() const { return Range{hs, xn, B * Tt, B * Tt, Tt, 1, 0}; }
   Range r_all() const { return Range{hs, xn, B * (Tt + N), B * Tt, Tt, N, 0}; }
-  void set_resid(FOp<T>& o, const Range& r, T* cache_slot, const T* gate) {
+  void set_resid(FOp<T>& o, const Range& r, T* cache_slot, const T* gate, bool block_output = false) {
     o.epi = FEPI_BIAS_GATE_RESID;
+    o.g.clip16 = block_output ? 1 : 0;  // fp16: the block's output saturates (cached_flux_transformer_block.py:127-128,288-289)
     o.g.C = cache_slot; o.g.ldc = D; o.g.resid = r.h; o.g.ldr = D; o.g.gate = gate; o.g.gate_stride = (int64_t)MODW;
     o.g.seg0 = r.seg0; o.g.rows_per_batch0 = r.rpb0; o.g.rows_per_batch1 = r.rpb1;
     o.bytes += (double)o.g.M * D * sizeof(T) * (cache_slot ? 3 : 2);
@@ -744,8 +745,8 @@ template <typename T> class FluxT : public FluxBase {
         push_gemm(ops, ot);
         tag_lane(ops, mark, 1);
       } else {
-        pend_img.push_back(FluxSrc{cj(i, 0) + BT * D, m(2)});
-        pend_txt.push_back(FluxSrc{cj(i, 0), m(8)});
+        pend_img.push_back(FluxSrc{cj(i, 0) + BT * D, m(2), 0});
+        pend_txt.push_back(FluxSrc{cj(i, 0), m(8), 0});
       }
       if (exf(s, i, 1)) {
         emit_ln(ops, RI, pend_img, m(3), m(4));
@@ -754,18 +755,18 @@ template <typename T> class FluxT : public FluxBase {
         set_resid(o, RI, wlive_f(s, i, 1) ? cj(i, 1) : nullptr, m(5));
         push_gemm(ops, o);
       } else {
-        pend_img.push_back(FluxSrc{cj(i, 1), m(5)});
+        pend_img.push_back(FluxSrc{cj(i, 1), m(5), 0});
       }
       if (exf(s, i, 2)) {
         mark = ops.size();
         emit_ln(ops, RT, pend_txt, m(9), m(10));
         push_gemm(ops, mk_gemm(FC_GEMM_FF1, FEPI_BIAS_GELU, RT.xn, D, b.w_ff1_t, b.b_ff1_t, ffmid, 4 * D, (int)BT, 4 * D, D));
         FOp<T> o = mk_gemm(FC_GEMM_FF2, 0, ffmid, 4 * D, b.w_ff2_t, b.b_ff2_t, nullptr, D, (int)BT, D, 4 * D);
-        set_resid(o, RT, wlive_f(s, i, 2) ? cj(i, 2) : nullptr, m(11));
+        set_resid(o, RT, wlive_f(s, i, 2) ? cj(i, 2) : nullptr, m(11), true);  // encoder_hidden_states leaves the joint block here (:285-289)
         push_gemm(ops, o);
         tag_lane(ops, mark, 1);
       } else {
-        pend_txt.push_back(FluxSrc{cj(i, 2), m(11)});
+        pend_txt.push_back(FluxSrc{cj(i, 2), m(11), 1});
       }
     }
     // cat([text, image]) is the layout itself; pending per-stream replays are flushed before the rows are treated as one matrix
@@ -803,10 +804,10 @@ template <typename T> class FluxT : public FluxBase {
         o.g.A2 = cs(i, 1);  // K columns >= D of the concatenation come from the gelu(mlp) slot
         o.g.lda2 = 4 * D;
         o.g.k_split = D;
-        set_resid(o, RA, wlive_s(s, i, 2) ? cs(i, 2) : nullptr, m(2));
+        set_resid(o, RA, wlive_s(s, i, 2) ? cs(i, 2) : nullptr, m(2), true);  // the single block's output (:126-128)
         push_gemm(ops, o);
       } else {
-        pend_all.push_back(FluxSrc{cs(i, 2), m(2)});
+        pend_all.push_back(FluxSrc{cs(i, 2), m(2), 1});
       }
     }
     // hidden_states[:, T:] -> norm_out (AdaLayerNormContinuous: chunk order scale, shift) -> proj_out   (:301-304)

@@ -15,6 +15,7 @@ namespace ecad {
 struct FluxSrc {
   const void* cache;  // [M, D] rows aligned with the hidden-state rows this launch covers
   const void* gate;   // T[b * gate_stride + d] or null (gate 1)
+  int64_t clip16;     // 1: the sum with this source is a FLUX block's output: fp16 saturates at +-65504 (cached_flux_transformer_block.py:127-128,288-289)
 };
 
 struct FluxRowArgs {
@@ -66,6 +67,10 @@ __global__ __launch_bounds__(256) void flux_ln_modulate_kernel(const FluxRowArgs
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[i][e] = round_elem<T>(x[i][e] + cf[e]);
+          }
+          if (d.clip16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[i][e] = clip_half<T>(x[i][e]);
           }
         }
       }
@@ -163,6 +168,10 @@ __global__ __launch_bounds__(256) void flux_replay_kernel(const FluxRowArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = round_elem<T>(acc[e] + cf[e]);
       }
+      if (d.clip16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = clip_half<T>(acc[e]);
+      }
     }
     gstore16(hp, pack8<T>(acc));
   }
@@ -208,6 +217,12 @@ __global__ __launch_bounds__(256) void flux_replay_rows_kernel(const FluxRowArgs
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[j][e] = round_elem<T>(acc[j][e] + cf[e]);
         }
+      }
+      if (d.clip16) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j][e] = clip_half<T>(acc[j][e]);
       }
     }
 #pragma unroll

@@ -74,7 +74,7 @@ template <typename T> struct VaeT : VaeBase {
   int cap_B = 0, cap_h = 0, cap_w = 0;
   bool finalized = false;
   bool async_failed = false;  // an asynchronous call inside a void helper failed: decode() turns it into ECAD_E_HIP
-  static constexpr int GN_MAX_BLOCKS = 2048;  // 1024 x 1024 pixels at 512 per block
+  int gn_blocks_cap = 0;  // per-block partial sums the GroupNorm statistics may write: sized by ensure_acts for the largest stage of the geometry it was given
   bool conv_tile128 = false;  // env ECAD_VAE_CONV=tile128: every convolution on the 128 x 128 kernel (A/B against conv3s_kernel)
   int num_cus = 256;
 
@@ -194,7 +194,10 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipMalloc((void**)&bufB, act_elems * sizeof(T)));
     VHIPCHK(hipMalloc((void**)&bufC, act_elems * sizeof(T)));
     VHIPCHK(hipMalloc((void**)&bufD, (attn_elems > act_elems ? attn_elems : act_elems) * sizeof(T)));
-    VHIPCHK(hipMalloc((void**)&gn_sums, (size_t)B * GN_MAX_BLOCKS * 64 * sizeof(float)));  // per-block partial (sum, sum of squares) of the 32 groups
+    // per-block partial (sum, sum of squares) of the 32 groups: the largest stage has 64 h w pixels at 512 per block (group_norm_stats), the small ones at most 64 blocks
+    const size_t blocks_max = (64 * tokens + 511) / 512;
+    gn_blocks_cap = (int)(blocks_max > 64 ? blocks_max : 64);
+    VHIPCHK(hipMalloc((void**)&gn_sums, (size_t)B * gn_blocks_cap * 64 * sizeof(float)));
     VHIPCHK(hipMalloc((void**)&gn_scale, (size_t)B * 512 * sizeof(float)));
     VHIPCHK(hipMalloc((void**)&gn_shift, (size_t)B * 512 * sizeof(float)));
     cap_B = B; cap_h = h; cap_w = w;
@@ -222,7 +225,7 @@ template <typename T> struct VaeT : VaeBase {
   void group_norm_stats(const T* x, const std::string& name, int B, int HW, int C, hipStream_t s) {
     const int ppb = HW >= 16384 ? 512 : HW >= 4096 ? 256 : 64;
     const int nblk = (HW + ppb - 1) / ppb;
-    if (nblk > GN_MAX_BLOCKS) { async_failed = true; return; }  // reported by decode()
+    if (nblk > gn_blocks_cap) { async_failed = true; return; }  // cannot happen for a geometry ensure_acts has sized the buffers for; decode() reports it
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nblk, B), dim3(256), 0, s, x, gn_sums, HW, C, 32, ppb);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, gn_sums, nblk, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
   }
@@ -311,7 +314,7 @@ template <typename T> struct VaeT : VaeBase {
     hipLaunchKernelGGL((vae_conv_out_kernel<T>), dim3((H / CO_TH) * (Wd / CO_TW), B), dim3(256), 0, s, cur, gn_scale, gn_shift, W_<T>("decoder.conv_out.weight"),
                        W_<float>("decoder.conv_out.bias"), out, B, H, Wd);
     VHIPCHK(hipGetLastError());
-    if (async_failed) { async_failed = false; return fail(ECAD_E_HIP, "hipMemsetAsync of the GroupNorm sums failed"); }
+    if (async_failed) { async_failed = false; return fail(ECAD_E_INVALID, "internal: a GroupNorm stage needs more partial-sum blocks than ensure_acts sized for"); }
     return ECAD_OK;
   }
 };

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from typing import Mapping
 
 import numpy as np
@@ -75,6 +76,7 @@ class EcadEngine:
         if fp8 is not None:  # None: the library default (env ECAD_FP8)
             self._chk(self.lib.ecad_set_fp8(self._h, int(fp8)))
         self.fp8 = fp8
+        self.ln_fold = os.environ.get("ECAD_LN_FOLD", "1") != "0"  # the library's default (set_ln_fold changes it)
 
     # -- errors ---------------------------------------------------------------------------
     def _raise(self, rc: int, handle="self"):
@@ -97,6 +99,7 @@ class EcadEngine:
     def set_ln_fold(self, on: bool) -> None:
         """LayerNorm folded into the consumer GEMMs of the whole-loop plan (default on): switch it off where every schedule runs for one batch only."""
         self._chk(self.lib.ecad_set_ln_fold(self._h, int(bool(on))))
+        self.ln_fold = bool(on)
 
     def set_batches_in_flight(self, n: int) -> None:
         """How many image batches the caller keeps in flight on this GPU: the few-rows rule (64-row latency tiles while a launch would leave half the chip idle)
@@ -111,7 +114,7 @@ class EcadEngine:
             raise ValueError("fp8 weight copies are per engine: create the second engine and load the weights into it")
         ctx = EcadEngine(**self._ctor)
         ctx._chk(self.lib.ecad_share_weights(ctx._h, self._h))
-        ctx._donor = self
+        ctx._donor = self  # (the weight arena itself is owned jointly on the C side: closing this engine first leaves the context usable)
         if self._bits is not None:
             ctx.set_schedule(self._bits)
         return ctx
@@ -155,6 +158,27 @@ class EcadEngine:
             raise ValueError(f"resolution has {res.shape[0]} rows but aspect_ratio has {ar.shape[0]}")
         fp = C.POINTER(C.c_float)
         self._chk(self.lib.ecad_set_added_cond(self._h, res.ctypes.data_as(fp), ar.ctypes.data_as(fp), res.shape[0]))
+
+    # -- attention biases ---------------------------------------------------------------------
+    def set_attention_bias(self, self_bias: torch.Tensor | None, enc_bias: torch.Tensor | None, stream=None) -> None:
+        """Additive attention biases, one float per (sample, key), broadcast over heads and queries: ``self_bias`` [Bt, N] for the self-attention of every block
+        (the reference's ``attention_mask`` after ``_create_attention_mask``, pixart_transformer_2d_edited.py:255-279), ``enc_bias`` [Bt, T] in place of the bias
+        derived from the 0/1 ``encoder_attention_mask`` (a 3-D mask is a bias already and is added as given, :281-291).  ``None`` switches a bias off.  Must
+        precede ``begin_image_batch`` / ``run_schedule`` of the batch it applies to; stays in force until changed."""
+        def prep(b):
+            if b is None:
+                return None
+            b = b.to(device=self.device, dtype=torch.float32).contiguous()
+            if b.dim() != 2:
+                raise ValueError(f"attention bias must be [batch, keys], got {tuple(b.shape)}")
+            return b
+        sb, eb = prep(self_bias), prep(enc_bias)
+        Bt = sb.shape[0] if sb is not None else eb.shape[0] if eb is not None else 1
+        if sb is not None and eb is not None and sb.shape[0] != eb.shape[0]:
+            raise ValueError("self- and encoder attention biases disagree on the batch size")
+        self._keep_bias = (sb, eb)
+        self._chk(self.lib.ecad_set_attention_bias(self._h, _ptr(sb), _ptr(eb), int(Bt), int(sb.shape[1]) if sb is not None else 0,
+                                                   int(eb.shape[1]) if eb is not None else 0, _stream_ptr(stream)))
 
     # -- per batch ------------------------------------------------------------------------
     def _prep_enc(self, enc: torch.Tensor, mask: torch.Tensor | None):
@@ -398,6 +422,8 @@ class EngineContexts:
             st.synchronize()
 
     def close(self) -> None:
+        for st in self.streams:  # a context's graph may still be running: its engine (hipGraphExec, workspaces) goes only after its stream has drained
+            st.synchronize()
         for e in self.engines[1:]:
             e.close()
         self.engines = self.engines[:1]

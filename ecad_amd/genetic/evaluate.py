@@ -50,9 +50,12 @@ def evaluate_population(X: np.ndarray, score_fn: Callable[[int, np.ndarray], flo
 
 
 def engine_score_fn(engine, enc, mask, latents, timesteps, coefs, guidance: float = 4.5):
-    """score_fn over a fixed prompt/latent batch on this rank's engine (reference latents from the all-true schedule)."""
+    """score_fn over a fixed prompt/latent batch on this rank's engine (reference latents from the all-true schedule).  The engine's LayerNorm fold is
+    switched off for the search (every candidate schedule runs for ONE batch: the fold's per-schedule weight preparation would never be amortised);
+    ``score.restore()`` puts the engine's previous setting back -- call it before the engine goes on to serve a fixed schedule."""
     steps = len(timesteps)
-    engine.set_ln_fold(False)  # every candidate schedule runs for ONE batch here: the fold's per-schedule weight preparation would never be amortised
+    fold_before = getattr(engine, "ln_fold", True)
+    engine.set_ln_fold(False)
     engine.set_schedule(np.ones((steps, engine.cfg.num_layers, 3), dtype=np.uint8))
     ref = engine.run_schedule(enc, mask, latents, timesteps, coefs, guidance)
 
@@ -60,6 +63,7 @@ def engine_score_fn(engine, enc, mask, latents, timesteps, coefs, guidance: floa
         engine.set_schedule(bits)
         return latent_fidelity_score(engine.run_schedule(enc, mask, latents, timesteps, coefs, guidance), ref)
 
+    score.restore = lambda: engine.set_ln_fold(fold_before)
     return score
 
 

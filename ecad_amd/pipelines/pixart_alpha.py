@@ -111,6 +111,7 @@ class PixArtAlphaPipeline:
             tr.engine.set_added_cond(added_cond_kwargs["resolution"], added_cond_kwargs["aspect_ratio"])
 
         if self.native_loop and cfg_on and not getattr(tr, "uses_plugins", False):  # a schedule with compute plug-ins calls back into Python: per-step path
+            tr.engine.set_attention_bias(None, None)  # the pipeline passes a 0/1 text mask and no self-attention mask (pass_through.py:332-339)
             lat = tr.engine.run_schedule(enc, mask, latents.float(), timesteps.numpy().astype(np.float32), self.scheduler.coefficient_table(), guidance_scale, use_graph=True)
             latents = lat.to(tr.dtype)
             if callback is not None:
@@ -176,6 +177,8 @@ class PixArtAlphaPipeline:
             res, ar = torch.tensor([[float(height), float(width)]]).repeat(2 * B, 1), torch.tensor([[float(height / width)]]).repeat(2 * B, 1)
             for e in pool.engines:
                 e.set_added_cond(res, ar)
+        for e in pool.engines:
+            e.set_attention_bias(None, None)
         lat, stream = pool.submit(enc, mask, latents.float(), timesteps.numpy().astype(np.float32), self.scheduler.coefficient_table(), guidance_scale, use_graph=True)
         tr._begun_key = None
         return {"latents": lat, "stream": stream, "output_type": output_type, "callback": callback, "callback_steps": callback_steps, "timesteps": timesteps}
@@ -183,6 +186,7 @@ class PixArtAlphaPipeline:
     def finish(self, handle: dict):
         """Second half: wait for that batch only, fire the per-step callbacks in order (the schedule counters end where ``__call__`` leaves them), decode."""
         torch.cuda.current_stream().wait_stream(handle["stream"])
+        handle["latents"].record_stream(torch.cuda.current_stream())  # allocated on the context's stream, read here on the caller's: keep the block until this read is done
         latents = handle["latents"].to(self.transformer.dtype)
         if handle["callback"] is not None:
             for i, t in enumerate(handle["timesteps"]):

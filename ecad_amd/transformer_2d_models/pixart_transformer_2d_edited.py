@@ -267,6 +267,17 @@ class PixArtTransformer2DEdited:
     def eval(self):
         return self
 
+    @staticmethod
+    def _as_key_bias(mask: Optional[torch.Tensor], dtype: torch.dtype, what: str) -> Optional[torch.Tensor]:
+        """[batch, keys] fp32 additive bias from the reference's `attention_mask` / `encoder_attention_mask` argument (:271-291)."""
+        if mask is None:
+            return None
+        if mask.ndim == 2:  # 1 = keep, 0 = discard -> +0 / -10000.0, computed in the model dtype as the reference does
+            return ((1 - mask.to(dtype)) * -10000.0).float()
+        if mask.ndim == 3 and mask.shape[1] == 1:
+            return mask[:, 0, :].float()
+        raise ValueError(f"{what}: expected a [batch, keys] mask or a [batch, 1, keys] bias, got {tuple(mask.shape)} (a bias that varies with the query row is not supported by the native engine; no ECAD caller passes one)")
+
     # -- reference: forward (:160-253) ----------------------------------------------------------
     @torch.no_grad()
     def forward(
@@ -282,23 +293,33 @@ class PixArtTransformer2DEdited:
     ):
         if self.cache_schedule is None:
             raise ValueError("no cache schedule attached (call _post_init / from_pretrained with cache_schedule=)")
-        if attention_mask is not None:
-            raise ValueError("self-attention masks are not supported by the native engine (PixArt passes None)")
         if encoder_hidden_states is None or timestep is None:
             raise ValueError("encoder_hidden_states and timestep are required")
         if self.use_additional_conditions and (added_cond_kwargs is None or added_cond_kwargs.get("resolution") is None or added_cond_kwargs.get("aspect_ratio") is None):
             raise ValueError("`added_cond_kwargs` cannot be None when using additional conditions for `adaln_single`.")  # reference :208-211
         step = self.cache_schedule.curr_step
-        enc_mask = encoder_attention_mask
-        if enc_mask is not None and enc_mask.ndim == 3:  # already a bias [B,1,T]: 0 keep / -10000 discard
-            enc_mask = (enc_mask[:, 0, :] > -1.0).to(torch.uint8)
-        key = (encoder_hidden_states.data_ptr(), tuple(encoder_hidden_states.shape), tuple(hidden_states.shape))
-        if step == 0 or self._begun_key != key:
-            # step-invariant work (caption projection, text K/V) is hoisted to the start of the batch
+        # reference: _create_attention_mask (:255-291).  A 2-D mask (1 keep / 0 discard) becomes the bias (1 - m) * -10000 in the model dtype; a 3-D tensor
+        # IS a bias already ([batch, 1, keys], broadcast over heads and queries) and is added to the scores as given.
+        self_bias = self._as_key_bias(attention_mask, hidden_states.dtype, "attention_mask")
+        enc_mask, enc_bias = encoder_attention_mask, None
+        if enc_mask is not None and enc_mask.ndim == 3:
+            enc_bias, enc_mask = self._as_key_bias(enc_mask, hidden_states.dtype, "encoder_attention_mask"), None
+        # What the step-invariant work of a batch (caption projection, text K/V: hoisted to its first forward) was computed from.  The tensors are held, so
+        # their storage cannot be recycled under the key, and an in-place update bumps `_version`.
+        def ident(t):
+            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+        key = (ident(encoder_hidden_states), ident(encoder_attention_mask), ident(attention_mask), tuple(hidden_states.shape))
+        if self._begun_key != key:
+            # A new batch: the engine recomputes the hoisted work and starts from empty caches.  (The reference drops its caches only in the callback after the
+            # last step, image_generator.py:193-202 -- so a forward that arrives at step 0 again with the SAME inputs and no callback in between reads the warm
+            # caches there, and here: nothing is reset below.  With different inputs and no callback the reference would replay the previous prompt's
+            # sub-layer outputs; the engine starts clean instead.)
             if self.use_additional_conditions:
                 self.engine.set_added_cond(added_cond_kwargs["resolution"], added_cond_kwargs["aspect_ratio"])
+            self.engine.set_attention_bias(self_bias, enc_bias)
             self.engine.begin_image_batch(encoder_hidden_states, enc_mask, hidden_states.shape[-2], hidden_states.shape[-1])
             self._begun_key = key
+            self._begun_refs = (encoder_hidden_states, encoder_attention_mask, attention_mask)
             self._ctx = None
             for blk in self.transformer_blocks:
                 blk.reset_cache()

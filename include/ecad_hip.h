@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ECAD_ABI_VERSION 4
+#define ECAD_ABI_VERSION 5
 
 enum {
   ECAD_OK = 0,
@@ -72,6 +72,9 @@ typedef struct EcadStats {
   int32_t ln_folded;             /* LayerNorm + modulate launches of the whole-loop plan folded into their consumer GEMMs */
   int32_t fold_preps;            /* times the pre-scaled weights of a plan set were (re)built: once per (schedule, timestep grid) */
   int64_t fold_bytes;            /* bytes of pre-scaled weights + c1 / c2 vectors the live plan set uses */
+  int64_t fold_arena_bytes;      /* device memory this engine holds for such copies right now: live + parked plan sets + recycling pool (bounded by ECAD_LN_FOLD_BUDGET_MB, default 24576) */
+  int32_t fold_refused;          /* plan sets lowered WITHOUT the fold because their copies did not fit that budget / the device */
+  int32_t reserved0;
 } EcadStats;
 
 typedef struct EcadEngine EcadEngine;
@@ -119,6 +122,14 @@ int ecad_set_fp8(EcadEngine* e, int on);
  * aspect_ratio_host [Bt]: host arrays, copied.  ecad_step honours per-sample values; ecad_run_schedule requires one value for the
  * whole batch (what the pipeline passes) and returns ECAD_E_INVALID otherwise. */
 int ecad_set_added_cond(EcadEngine* e, const float* resolution_host, const float* aspect_ratio_host, int Bt);
+/* Replaces the `attention_mask` argument of PixArtTransformer2DEdited.forward and an `encoder_attention_mask` that arrives as a bias
+ * (pixart_transformer_2d_edited.py:166-167,213-215,255-291): the reference converts a 2-D 0/1 mask into (1 - m) * -10000 and adds a 3-D
+ * [B, 1, keys] bias to the attention scores as given, broadcast over heads and queries.  The caller does the first conversion (same rounding as the
+ * reference: in the model dtype) and hands over one float per (sample, key): self_bias_dev [Bt][N] for the self-attention of every block,
+ * enc_bias_dev [Bt][T] in place of the bias ecad_begin_image_batch / ecad_run_schedule would derive from their 0/1 mask.  Device pointers, copied on
+ * `stream`; NULL switches that bias off (the default).  Must precede ecad_begin_image_batch / ecad_run_schedule of the batch it applies to and stays in
+ * force until changed.  A bias that depends on the query row is not representable here (ECAD has no caller that passes one). */
+int ecad_set_attention_bias(EcadEngine* e, const float* self_bias_dev, const float* enc_bias_dev, int Bt, int N, int T, void* stream);
 
 /* ---- schedule --------------------------------------------------------------------------- */
 

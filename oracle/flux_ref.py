@@ -172,6 +172,13 @@ class FluxOracle:
     def lin(self, x: torch.Tensor, name: str) -> torch.Tensor:
         return self.q(F.linear(x, self.w[name + ".weight"], self.w[name + ".bias"]))
 
+    clip_fp16 = True  # tests switch it off to show that an input really overflows
+
+    def clip(self, x: torch.Tensor) -> torch.Tensor:
+        """`if hidden_states.dtype == torch.float16: hidden_states = hidden_states.clip(-65504, 65504)` (cached_flux_transformer_block.py:127-128,288-289):
+        the fp16 sum has overflowed to +-inf by then (self.q rounds to the storage type), the clip brings it back to the largest half."""
+        return x.clamp(-65504.0, 65504.0) if (self.round_dtype == torch.float16 and self.clip_fp16) else x
+
     def layer_norm(self, x: torch.Tensor) -> torch.Tensor:
         return self.q(F.layer_norm(x, (x.shape[-1],), eps=self.cfg.norm_eps))
 
@@ -247,7 +254,7 @@ class FluxOracle:
         ctx = self.q(ctx + self.q(c_gate_msa * ca))
         nc = self.q(self.q(self.layer_norm(ctx) * (1 + c_scale_mlp)) + c_shift_mlp)
         cff = self._gated(step, str(i), "full_ff_context", bool(flags[2]), lambda: self.feed_forward(b + ".ff_context", nc))
-        ctx = self.q(ctx + self.q(c_gate_mlp * cff))
+        ctx = self.clip(self.q(ctx + self.q(c_gate_mlp * cff)))  # :285-289 (only the text stream is clipped in the joint block)
         return ctx, h
 
     # -- single block (:103-131) ------------------------------------------
@@ -269,7 +276,7 @@ class FluxOracle:
         a = self._gated(step, name, "single_attn", bool(flags[0]), lambda: self.single_attention(b + ".attn", nh, cos, sin))
         cat = torch.cat([a, mlp], dim=2)
         out = self._gated(step, name, "single_proj_out", bool(flags[2]), lambda: self.lin(cat, b + ".proj_out"))
-        return self.q(h + self.q(gate * out))
+        return self.clip(self.q(h + self.q(gate * out)))  # :126-128
 
     # -- forward (flux_transformer_2d_edited.py:216-326) ---------------------
     def forward(self, latents, enc, pooled, timestep_x1000, guidance_x1000, ids, step: int, flags_full, flags_single) -> torch.Tensor:

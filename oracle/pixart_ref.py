@@ -258,7 +258,7 @@ class PixArtOracle:
         self.cache.entries[key] = out
         return out
 
-    def block(self, i: int, step: int, flags, h, enc, enc_bias, mod):
+    def block(self, i: int, step: int, flags, h, enc, enc_bias, mod, self_bias=None):
         """CachedTransformerBlock.forward, ada_norm_single (:167-324)."""
         b = f"transformer_blocks.{i}"
         B = h.shape[0]
@@ -267,7 +267,7 @@ class PixArtOracle:
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = tbl.chunk(6, dim=1)
 
         nh = self.q(self.layer_norm(h) * (1 + scale_msa) + shift_msa)
-        a1 = self._gated(step, i, "attn1", bool(flags[0]), lambda: self.attention(b + ".attn1", nh, nh, None))
+        a1 = self._gated(step, i, "attn1", bool(flags[0]), lambda: self.attention(b + ".attn1", nh, nh, self_bias))
         h = self.q(self.q(gate_msa * a1) + h)
 
         a2 = self._gated(step, i, "attn2", bool(flags[1]), lambda: self.attention(b + ".attn2", h, enc, enc_bias))
@@ -279,16 +279,25 @@ class PixArtOracle:
         return h
 
     # -- forward (pixart_transformer_2d_edited.py:160-253) -------------------
-    def forward(self, latents, enc, enc_mask, timestep, step: int, step_flags, added_cond: dict | None = None) -> torch.Tensor:
-        """One noise prediction.  ``step_flags``: [blocks, 3] bools for this step."""
+    def _mask_to_bias(self, mask):
+        """_create_attention_mask (:255-291): a 2-D mask (1 keep / 0 discard) becomes the additive bias (1 - m) * -10000 with a singleton query dimension;
+        a 3-D tensor is taken to be such a bias already and passes through unchanged."""
+        if mask is None:
+            return None
+        if mask.ndim == 2:
+            return self.q(((1 - mask.float()) * -10000.0)[:, None, :])
+        return mask.float()
+
+    def forward(self, latents, enc, enc_mask, timestep, step: int, step_flags, added_cond: dict | None = None, attention_mask=None) -> torch.Tensor:
+        """One noise prediction.  ``step_flags``: [blocks, 3] bools for this step.  ``enc_mask`` / ``attention_mask``: [B, keys] masks or [B, 1, keys] biases."""
         cfg = self.cfg
-        enc_bias = ((1 - enc_mask.float()) * -10000.0)[:, None, :]  # :255-291
-        enc_bias = self.q(enc_bias)
+        enc_bias = self._mask_to_bias(enc_mask)
+        self_bias = self._mask_to_bias(attention_mask)
         h = self.patch_embed(self.q(latents.float()))
         mod, embedded = self.adaln_single(timestep, added_cond)
         ctx = self.caption_projection(self.q(enc.float()))
         for i in range(cfg.num_layers):
-            h = self.block(i, step, step_flags[i], h, ctx, enc_bias, mod)
+            h = self.block(i, step, step_flags[i], h, ctx, enc_bias, mod, self_bias)
         return self.create_output(h, embedded, latents.shape[-2] // cfg.patch_size, latents.shape[-1] // cfg.patch_size)
 
     def create_output(self, h, embedded, gh: int | None = None, gw: int | None = None):  # :332-376; (height, width) of the token grid from :301-304

@@ -15,6 +15,8 @@ Outputs (data only -- inputs and expected outputs):
                                      with metrics.by_inference_step (bits via the
                                      reference's FluxCacheSchedule.to_numpy)
   tests/golden/flux_vectors.json     FluxCacheSchedule / FluxPopulationIOManager vectors
+  tests/golden/dit_graph_vectors.json  node order and wiring of the reference's DEFAULT DiT fx graph (graph/pixart_builder.py:96-124,187-204) for 28 blocks,
+                                     and its output on seeded affine stand-in blocks next to the plain `for block in blocks` loop
   tests/golden/alpha1024_vectors.json  per-step MACs of the PixArt-alpha 1024-MS schedules (the micro-conditioned
                                      checkpoint: N = 4096 and the resolution / aspect-ratio embedders)
 """
@@ -289,7 +291,54 @@ def alpha1024_golden():
     print(f"alpha1024_vectors.json: {len(out)} schedule(s)")
 
 
+def dit_graph_golden():
+    """the default DiT schedule's fx graph is the sequential loop over the 28 blocks -- captured from the reference's own builder."""
+    import torch
+    from torch import nn
+
+    from ecad.schedulers.dit_scheduler.generators.pixart_schedule_generators import gen_default as dit_gen_default
+    from ecad.utils import PixArtForwardArgs
+
+    num_blocks, steps = 28, 20
+    sch = next(dit_gen_default(num_blocks, steps))
+    g = torch.Generator().manual_seed(11)
+    scale = (1.0 + 0.1 * torch.randn(num_blocks, generator=g)).tolist()
+    shift = (0.1 * torch.randn(num_blocks, generator=g)).tolist()
+
+    class Affine(nn.Module):  # order-sensitive stand-in for a transformer block: x -> a_i x + b_i
+        def __init__(self, i):
+            super().__init__()
+            self.i = i
+
+        def forward(self, hidden_states=None, **kw):
+            return hidden_states * scale[self.i] + shift[self.i]
+
+    blocks = nn.ModuleList(Affine(i) for i in range(num_blocks))
+    sch.update_transformer_blocks(blocks)
+    x = torch.randn(2, 4, 8, generator=g)
+    seq = x.clone()
+    for b in blocks:
+        seq = b(hidden_states=seq)
+    per_step = {}
+    for step in (0, 7, steps - 1):
+        gm = sch.schedule[step]
+        nodes = [[n.op, n.target if isinstance(n.target, str) else getattr(n.target, "__name__", str(n.target)), n.name] for n in gm.graph.nodes]
+        wiring = {n.name: n.kwargs["hidden_states"].name for n in gm.graph.nodes if n.op == "call_module"}
+        out = sch.forward(PixArtForwardArgs(hidden_states=x.clone(), attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, timestep=None,
+                                            cross_attention_kwargs=None), step)
+        per_step[f"{step:03}"] = {"nodes": nodes, "call_module_order": [n[1] for n in nodes if n[0] == "call_module"], "hidden_states_input_of": wiring,
+                                 "equals_sequential_loop": bool(torch.equal(out, seq))}
+    out = {"num_blocks": num_blocks, "num_inference_steps": steps, "name": sch.name, "steps": per_step, "stub_scale": scale, "stub_shift": shift,
+           "x": x.tolist(), "sequential_out": seq.tolist()}
+    with open(OUT / "dit_graph_vectors.json", "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("dit_graph_vectors.json written:", [v["equals_sequential_loop"] for v in per_step.values()])
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["dit_graph"]:
+        dit_graph_golden()
+        sys.exit(0)
     if sys.argv[1:] == ["alpha1024"]:
         alpha1024_golden()
         sys.exit(0)
@@ -297,3 +346,4 @@ if __name__ == "__main__":
     schedule_vectors()
     flux_golden()
     alpha1024_golden()
+    dit_graph_golden()

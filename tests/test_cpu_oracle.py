@@ -124,6 +124,71 @@ def test_masked_text_tokens_do_not_matter(tiny):
     assert torch.allclose(a, b, atol=1e-5)
 
 
+def test_oracle_executes_exactly_the_components_the_pinned_rule_predicts():
+    """The gate of the oracle's module graph (PixArtOracle._gated_default, restating cached_transformer_block.py:340-360) tied to the rule pinned on the
+    reference's 1090 measured schedules (schedule_ref.resolve_executed): on `ours_fast` (reduced width, 28 blocks, 20 steps) the SET of (step, block,
+    component) evaluations is the same, not just their count."""
+    bits = S.bits_from_schedule_json(ROOT / "schedules/schedules_in_paper/pixart_alpha_256/ours_fast.json")
+    cfg = PixArtConfig(num_layers=28, num_attention_heads=2, attention_head_dim=8, caption_channels=32, sample_size=8)
+    m = PixArtOracle(cfg, make_weights(cfg, seed=2))
+    g = torch.Generator().manual_seed(0)
+    enc, mask = torch.randn(2, 5, cfg.caption_channels, generator=g), torch.ones(2, 5, dtype=torch.int64)
+    for s in range(bits.shape[0]):
+        m.forward(torch.randn(2, 4, 8, 8, generator=g), enc, mask, torch.full((2,), 999.0 - 50 * s), s, bits[s])
+    comp = {"attn1": 0, "attn2": 1, "ff": 2}
+    ran = {(s, b, comp[c]) for s, b, c in m.cache.executed_log}
+    want = {tuple(int(v) for v in idx) for idx in np.argwhere(S.resolve_executed(bits))}
+    assert len(m.cache.executed_log) == len(ran) == 599
+    assert ran == want
+    assert (0, 17, 0) in ran and not bits[0, 17, 0]  # the forced recompute inside ours_fast itself (flag false, cache empty)
+
+
+def test_default_dit_graph_of_the_reference_is_the_sequential_block_loop():
+    """SURVEY 8(c) fixture 5, captured by tests/golden/make_golden.py from the reference's own builder (graph/pixart_builder.py:96-124,187-204): the fx graph of
+    the default DiT schedule calls transformer_block_0 .. 27 in order, each on its predecessor's output, at every step; on order-sensitive stand-in blocks it
+    returns what `for block in blocks` returns.  That loop is what the oracle and the engine hard-wire."""
+    gold = json.load(open(GOLD / "dit_graph_vectors.json"))
+    n = gold["num_blocks"]
+    assert n == 28 and gold["name"] == "default" and set(gold["steps"]) == {"000", "007", "019"}
+    for step in gold["steps"].values():
+        assert step["call_module_order"] == [f"transformer_block_{i}" for i in range(n)]
+        assert step["equals_sequential_loop"] is True
+        wiring = step["hidden_states_input_of"]
+        assert wiring["_0_0"] == "_0_0_input_func"
+        feeds = {node[2]: node for node in step["nodes"]}
+        for i in range(1, n):  # block i reads an identity of block i - 1's output and nothing else
+            assert wiring[f"_{i}_0"] == f"_{i}_0_input_func" and feeds[f"_{i}_0_input_func"][1] == "identity"
+    x = torch.tensor(gold["x"])
+    for a, b in zip(gold["stub_scale"], gold["stub_shift"]):
+        x = x * a + b
+    assert torch.equal(x, torch.tensor(gold["sequential_out"]))
+    # the oracle visits the blocks in that order
+    cfg = PixArtConfig(num_layers=n, num_attention_heads=2, attention_head_dim=8, caption_channels=32, sample_size=8)
+    m = PixArtOracle(cfg, make_weights(cfg, seed=2))
+    g = torch.Generator().manual_seed(0)
+    m.forward(torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 5, 32, generator=g), torch.ones(1, 5, dtype=torch.int64), torch.tensor([500.0]), 0, np.ones((n, 3), bool))
+    assert [b for _, b, c in m.cache.executed_log if c == "ff"] == list(range(n))
+
+
+def test_attention_masks_as_the_reference_converts_them(tiny):
+    """_create_attention_mask (pixart_transformer_2d_edited.py:255-291): a 2-D mask and the 3-D bias (1 - m) * -10000 built from it are the same thing, for the
+    self-attention mask and for the encoder mask; a soft 3-D bias is added as given (it changes the result, a binarised one would not)."""
+    cfg, w = tiny
+    x, enc, mask = _inputs(cfg)
+    t = torch.tensor([100.0, 100.0])
+    flags = np.ones((cfg.num_layers, 3), bool)
+    g = torch.Generator().manual_seed(3)
+    self_mask = (torch.rand(2, 256, generator=g) > 0.4).to(torch.int64)
+    self_mask[:, 0] = 1
+    a = PixArtOracle(cfg, w).forward(x, enc, mask, t, 0, flags, attention_mask=self_mask)
+    b = PixArtOracle(cfg, w).forward(x, enc, ((1 - mask.float()) * -10000.0)[:, None, :], t, 0, flags, attention_mask=((1 - self_mask.float()) * -10000.0)[:, None, :])
+    plain = PixArtOracle(cfg, w).forward(x, enc, mask, t, 0, flags)
+    assert torch.equal(a, b) and float((a - plain).abs().max()) > 1e-5  # (a 2-block toy with N(0, 0.02) weights: small, but far above rounding)
+    soft = ((1 - mask.float()) * -10000.0 + torch.randn(2, 7, generator=g))[:, None, :]
+    c = PixArtOracle(cfg, w).forward(x, enc, soft, t, 0, flags)
+    assert float((c - plain).abs().max()) > 1e-6
+
+
 def test_pos_embed_table():
     tab = sincos_pos_embed_2d(1152, 16, base_size=16)
     assert tab.shape == (256, 1152)

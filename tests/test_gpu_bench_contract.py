@@ -81,3 +81,41 @@ def test_rccl_process_group_at_world_one():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env={**env, "ECAD_FORCE_DIST": "1", "PYTHONPATH": str(ROOT)})
     assert out.returncode == 0 and "RCCL-WORLD-1-OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_rccl_at_world_two_when_the_box_has_two_gpus():
+    """The multi-GPU path on real RCCL: `bench.py --gpus 2` (two ranks, one per GPU, barrier + MAX over ranks, rank 0's line counts both ranks' images) and the
+    NSGA-II collectives of ecad_amd/distributed.py at world size 2 (fitness all-gather of a population sharded 5 + 4, bit-matrix broadcast, error flag).
+    Skips on a one-GPU box (torch.cuda.device_count() does not initialise the GPU in this process); the gloo counterparts run in the CPU suite."""
+    import os
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d = _bench("--gpus", "2", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-decode-tail")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "nccl" in d["config"]["process_group"] and d["value"] > 0
+    assert abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2 / 1000.0)) / d["value"] < 1e-6  # both ranks' images over the slowest rank's time
+    code = (
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "from ecad_amd import distributed as D\n"
+        "rank, world, local = D.init()\n"
+        "assert dist.get_backend() == 'nccl' and world == 2 and D._comm_device().type == 'cuda'\n"
+        "X = np.random.default_rng(0).random((9, 1680)) < 0.5\n"
+        "idx = np.array(list(D.shard_range(9, world, rank)), dtype=np.float64)\n"
+        "F = np.stack([idx, -idx], 1)\n"
+        "G = D.gather_fitness(F, 9)\n"
+        "assert np.array_equal(G[:, 0], np.arange(9.0)) and np.array_equal(G[:, 1], -np.arange(9.0))\n"
+        "Y = D.broadcast_population(X if rank == 0 else None, X.shape)\n"
+        "assert np.array_equal(Y, X)\n"
+        "assert D.broadcast_ints([3, 1, 4] if rank == 0 else None, 3) == [3, 1, 4]\n"
+        "assert D.max_over_ranks(float(rank)) == 1.0 and D.any_rank_failed(rank == 1) is True and D.any_rank_failed(False) is False\n"
+        "D.barrier(); dist.destroy_process_group(); print('RCCL-WORLD-2-OK', rank)\n"
+    )
+    script = ROOT / "gpurun_out" / "_rccl_world2.py"
+    script.parent.mkdir(exist_ok=True)
+    script.write_text(code)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env={**env, "PYTHONPATH": str(ROOT), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out.returncode == 0 and out.stdout.count("RCCL-WORLD-2-OK") == 2, out.stderr[-2000:]

@@ -270,7 +270,7 @@ def test_baseline_batch16_properties():
     idx = 5
     sel = torch.tensor([idx, 16 + idx])
     one = eng.run_schedule(enc[sel].cuda(), mask[sel].cuda(), inp["latents"][idx : idx + 1].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
-    assert rel_l2(one, a[idx : idx + 1]) < 1e-6 or torch.equal(one, a[idx : idx + 1])
+    assert torch.equal(one, a[idx : idx + 1])  # bit for bit: a row's arithmetic does not depend on its neighbours in the batch
 
 
 @pytest.mark.parametrize("dtype,side", [(torch.float16, 32), (torch.bfloat16, 32), (torch.float16, 64)])

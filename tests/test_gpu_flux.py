@@ -473,3 +473,53 @@ def test_fp8_engine_tracks_the_bf16_engine_and_the_oracle(dtype):
         torch.cuda.synchronize()
         outs.append(xx.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+
+
+def test_fp16_block_outputs_saturate_like_the_reference():
+    """`if hidden_states.dtype == torch.float16: hidden_states = hidden_states.clip(-65504, 65504)` at the end of both FLUX blocks
+    (cached_flux_transformer_block.py:127-128: the single block's output; :288-289: the joint block's encoder_hidden_states).  Weights that push a few channels
+    past the fp16 range (two blocks that each add 40 000 with gate 1): the fp16 engine must return the oracle's finite values -- executed AND replayed from the
+    cache -- where the unclipped arithmetic gives inf / NaN."""
+    cfg = tiny_cfg(2, 2)
+    dtype = torch.float16
+    w = flux_ref.make_weights(cfg, seed=4)
+    D = cfg.dim
+    hot = [3, 77, 200]
+    for i in range(2):
+        p = f"single_transformer_blocks.{i}"
+        w[p + ".norm.linear.weight"][2 * D:3 * D] = 0  # AdaLayerNormZeroSingle rows (shift, scale, gate): gate = bias = 1
+        w[p + ".norm.linear.bias"][2 * D:3 * D] = 1.0
+        w[p + ".proj_out.weight"][hot] = 0
+        w[p + ".proj_out.bias"][hot] = 40000.0
+        q = f"transformer_blocks.{i}"
+        w[q + ".norm1_context.linear.weight"][5 * D:6 * D] = 0  # c_gate_mlp
+        w[q + ".norm1_context.linear.bias"][5 * D:6 * D] = 1.0
+        w[q + ".ff_context.net.2.weight"][hot] = 0
+        w[q + ".ff_context.net.2.bias"][hot] = 40000.0
+    B, T, gh, gw, steps = 2, 32, 8, 8, 2
+    eng = make_engine(cfg, dtype, max_batch=B)
+    eng.load_state_dict(w)
+    bf = np.ones((steps, 2, 3), dtype=bool)
+    bs = np.ones((steps, 2, 3), dtype=bool)
+    bf[1, :, 2] = False  # step 1 replays ff_context of both joint blocks ...
+    bs[1, :, 2] = False  # ... and proj_out of both single blocks: the clip sits on the replay path too
+    eng.set_schedule(bf, bs)
+    ref = flux_ref.FluxOracle(cfg, w, round_dtype=dtype)  # activations rounded to fp16 as the reference holds them: that is where the overflow happens
+    raw = flux_ref.FluxOracle(cfg, w, round_dtype=dtype)
+    raw.clip_fp16 = False
+    lat, enc, pooled, ids = flux_ref.synthetic_inputs(cfg, B, gh, gw, T)
+    enc_d, pooled_d = enc.to(dtype), pooled.to(dtype)
+    eng.begin_image_batch(enc_d.cuda(), pooled_d.cuda(), gh, gw)
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    for s in range(steps):
+        x = torch.randn(B, gh * gw, 64, generator=g).to(dtype)
+        t, gd = 900.0 - 130 * s, 4992.0
+        got = eng.step(s, x.cuda(), t, gd)
+        args = (x.float(), enc_d.float(), pooled_d.float(), torch.full((B,), t), torch.full((B,), gd), ids, s, bf[s], bs[s])
+        want, unclipped = ref.forward(*args), raw.forward(*args)
+        assert not torch.isfinite(unclipped).all()  # the input really overflows fp16
+        assert torch.isfinite(got).all() and torch.isfinite(want).all()
+        worst = max(worst, rel_l2(got.float(), want))
+    assert within(worst, 3e-3)
+    eng.close()

@@ -409,6 +409,15 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
           if (m < p.M) *reinterpret_cast<u32x2*>(crow + 16 * (FN - 1) + 4 * g) = o.u;
         }
       }
+#ifdef G_STAMP
+      if (p.gate_mod && wave == 0 && lane == 0) {  // diagnostic build: slot 6 = GELU + store ISSUE (the direct epilogue has no LDS phases), slot 2 = until the stores have drained
+        const unsigned long long st_ci = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_c3 = __builtin_amdgcn_s_memtime(), st_r3 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<T*>(p.gate_mod)) + 8 * vb;
+        dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0; dbg[6] = st_ci - st_c2; dbg[7] = 0;
+      }
+#endif
       continue;
     }
   }
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   if (EPI != EPI_BIAS_CACHE_RESID && p.gate_mod && wave == 0 && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st_c3 = __builtin_amdgcn_s_memtime(), st_r3 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<T*>(p.gate_mod)) + 8 * blockIdx.x;
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<T*>(p.gate_mod)) + 8 * vb;  // one record per TILE (a walking workgroup leaves several)
     dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0; dbg[6] = st_ca - st_c2; dbg[7] = st_cb - st_ca;
   }
 #endif

@@ -37,5 +37,12 @@ for kernel, site, epi, M, N, K in CASES:
     span = ((v[:, 4] + v[:, 3]).max() - t0) / 100.0
     clock = med[5] / (med[3] / 100.0) / 1e3
     steps = K // 64
+    if kernel == "wide288" and len(v) > 256:  # a walking workgroup leaves one record per tile: rounds of 256 tiles, timeline in us from the first workgroup's start
+        ends = (v[:, 4] + v[:, 3] - t0) / 100.0
+        order = torch.argsort(v[:, 4])
+        for r in range(len(v) // 256):
+            sel = order[r * 256:(r + 1) * 256]
+            print(f"   round {r}: tile starts {start[sel].min():.1f} / {start[sel].median():.1f} / {start[sel].max():.1f} us (min / median / max), ends {ends[sel].min():.1f} / {ends[sel].median():.1f} / {ends[sel].max():.1f} us;"
+                  f" per tile: fill {v[sel, 0].median():.0f}  loop {v[sel, 1].median():.0f}  epilogue {v[sel, 2].median():.0f} cycles, wall {v[sel, 3].median() / 100:.2f} us")
     print(f"{kernel}/{site} M={M} N={N} K={K} epi={epi}: WGs {len(v)}  prologue {med[0]:.0f}  loop {med[1]:.0f} ({med[1] / steps:.0f}/step)  epilogue {med[2]:.0f} cycles (skew + bias {med[6]:.0f}, acc -> LDS {med[7]:.0f}, LDS -> global {med[2] - med[6] - med[7]:.0f});"
           f"  WG wall {med[3] / 100:.2f} us, clock {clock:.3f} GHz, kernel span {span:.1f} us, starts: median {start.median():.1f} us max {start.max():.1f} us")

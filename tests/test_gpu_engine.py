@@ -8,6 +8,8 @@ Floating-point tolerances (stated, per SURVEY 8c "restated, not verified against
   * paths that must be the same arithmetic (graph vs eager, forced-recompute rule, replay of the same
     batch): bit-exact.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -672,6 +674,74 @@ def test_execution_contexts_share_weights_and_keep_results_bit_identical():
     with pytest.raises(RuntimeError, match="not finalized"):
         taker._chk(taker.lib.ecad_share_weights(taker._h, cold._h))
     pool.close()
+
+
+def test_contexts_follow_new_weights_of_the_donor_and_outlive_it():
+    """A context that borrows its weights (ecad_share_weights) derives plans, a hipGraph and the LayerNorm-fold copies W' / c1 / c2 from them.  After the donor
+    loads NEW weights the context must not keep any of that (stale folded GEMMs beside fresh unfolded ones = silently wrong images): its next run equals a fresh
+    engine with the new weights, bit for bit.  While the donor is mid-load the context refuses to run; and the arena is owned jointly, so a context survives the
+    donor's ecad_destroy."""
+    from ecad_amd.engine import EcadEngine
+
+    layers, steps, B = 3, 4, 2
+    bits = rand_bits(steps, layers, 0.6, seed=4)
+    bits[0] = True
+    eng, w, cfg = make_pair(layers, bits, max_batch=2 * B)
+    inp, enc, mask = cfg_inputs(B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    ctx = eng.new_context()
+    a0, c0 = eng.run_schedule(*args), ctx.run_schedule(*args)
+    assert torch.equal(a0, c0) and ctx.stats()["ln_folded"] > 0  # the context runs the folded plan: it holds copies derived from the weights
+    w2 = make_weights(cfg, seed=77)
+    first = next(iter(w2))
+    shape = (C.c_int64 * w2[first].dim())(*w2[first].shape)
+    t0 = w2[first].contiguous()
+    eng._chk(eng.lib.ecad_load_weights(eng._h, first.encode(), t0.data_ptr(), 2 if t0.dtype == torch.float32 else 0, shape, t0.dim()))  # one tensor in, not finalized yet
+    with pytest.raises(RuntimeError, match="loading new ones"):
+        ctx.run_schedule(*args)
+    eng.load_state_dict(w2)
+    fresh, _, _ = make_pair(layers, bits, max_batch=2 * B, seed=77)
+    want = fresh.run_schedule(*args)
+    got_donor, got_ctx = eng.run_schedule(*args), ctx.run_schedule(*args)
+    assert torch.equal(got_donor, want) and torch.equal(got_ctx, want) and not torch.equal(want, a0)
+    torch.cuda.synchronize()
+    eng.close()  # the donor goes first
+    again = ctx.run_schedule(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(again, want)
+    ctx.close()
+
+
+def test_layernorm_fold_respects_its_memory_budget(monkeypatch):
+    """The pre-scaled weight copies of the LayerNorm fold cost 8-10.6 MB per folded (step, block, component) at D = 1152 (3.3 GB for `ours_fast`, ~10 GB for an
+    all-executed 20-step schedule), per plan set and per execution context.  ECAD_LN_FOLD_BUDGET_MB bounds what an engine holds; a plan set that does not fit is
+    lowered WITHOUT the fold -- same results within the fold's own tolerance -- instead of failing, and the stats say so."""
+    from ecad_amd.engine import EcadEngine
+
+    layers, steps, B = 3, 4, 2
+    bits = rand_bits(steps, layers, 0.7, seed=5)
+    bits[0] = True
+    cfg = PixArtConfig(num_layers=layers)
+    w = make_weights(cfg, seed=1)
+    inp, enc, mask = cfg_inputs(B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    outs, stats = {}, {}
+    for budget in ("100000", "16"):
+        monkeypatch.setenv("ECAD_LN_FOLD_BUDGET_MB", budget)
+        eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
+        eng.load_state_dict(w)
+        eng.set_schedule(bits)
+        outs[budget], stats[budget] = eng.run_schedule(*args).clone(), eng.stats()
+        eng.close()
+    big, small = stats["100000"], stats["16"]
+    assert big["ln_folded"] > 0 and big["fold_refused"] == 0 and big["fold_arena_bytes"] >= big["fold_bytes"] > 16 << 20
+    assert small["ln_folded"] == 0 and small["fold_refused"] == 1 and small["fold_arena_bytes"] == 0
+    assert small["launches_per_batch"] == big["launches_per_batch"] + big["ln_folded"]
+    assert within(rel_l2(outs["16"], outs["100000"]), 3e-3)
 
 
 def test_fp8_mode_tracks_the_oracle_and_is_reproducible():

@@ -46,6 +46,9 @@ enum KClass {
   KC_GEMM_QKV = 0, KC_GEMM_OUT1, KC_GEMM_Q2, KC_GEMM_OUT2, KC_GEMM_FF1, KC_GEMM_FF2, KC_GEMM_TEXTKV, KC_GEMM_CAPTION,
   KC_GEMM_SMALL, KC_GEMM_KV1, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_QUANT, KC_CACHE_HIT_STEP, KC_COUNT
 };
+// Summation order over K of a GEMM call site (gemm3s.h): the wide call sites run their big launches on gemm2w.h (one accumulator per output, K in order), so
+// their 256 x 144 / latency-tile fallbacks sum the same way; every other site sums the even and the odd 32-deep K blocks separately (split-K wave layout).
+constexpr bool eo_site(int tag) { return !(tag == KC_GEMM_FF1 || tag == KC_GEMM_TEXTKV || tag == KC_GEMM_SMALL || tag == KC_GEMM_KV1); }
 static const char* kclass_names[KC_COUNT] = {
     "gemm_qkv", "gemm_attn1_out", "gemm_attn2_q", "gemm_attn2_out", "gemm_ff1_gelu", "gemm_ff2", "gemm_text_kv", "gemm_caption",
     "gemm_small", "gemm_attn1_kv_wide", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc", "fp8_quant_rows", "cache_hit_step"};
@@ -169,7 +172,6 @@ template <typename T> class EngineT : public EngineBase {
   float* sa8 = nullptr;
   const void* a8_src = nullptr;  // plan construction: which tensor a8 currently holds (Q and K/V launches share one pass)
   bool f8_attr = false;
-  bool fp8_wide = true;  // env ECAD_FP8_WIDE=0: 256 x 144 tiles everywhere (A/B)
   // ---- workspaces
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -194,7 +196,6 @@ template <typename T> class EngineT : public EngineBase {
   size_t fold_prep_begin = 0;
   int ln_folded = 0, fold_preps = 0, fold_refused = 0;
   std::vector<float> fold_ts;         // the timesteps the arena was prepared for
-  bool use_comb = true;  // env ECAD_LN_COMB=0: LN reads table + modulation separately (fp32 sum), as the per-step plans do
   float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
   uint8_t* mask_buf;
   // additive attention biases handed over as such (forward(attention_mask=..., encoder_attention_mask=<3-D bias>), pixart_transformer_2d_edited.py:255-291):
@@ -318,40 +319,15 @@ template <typename T> class EngineT : public EngineBase {
     // too (in-run: 19.77 -> 18.80 ms per batch = 1008 TFLOP/s) and on the caption / small GEMMs (pgemm.h, which nothing has launched since, was retired in round 3: scripts/retired_pgemm.h)
     gemm_impl_cls[KC_GEMM_FF2] = gemm_impl_cls[KC_GEMM_CAPTION] = gemm_impl_cls[KC_GEMM_SMALL] = 0;
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
-    if (const char* sq = getenv("ECAD_SPLIT_QKV")) split_qkv = atoi(sq) != 0;  // 256x288 tiles (gemm2w.h): -17 % time on FF1, -13 % on text K/V
-    if (const char* l = getenv("ECAD_LN16")) ln16 = atoi(l);
-    if (const char* l = getenv("ECAD_GEMM_SCHED")) gemm_variant = atoi(l);
     if (const char* l = getenv("ECAD_FUSE_ATTN")) fuse_attn = atoi(l) != 0;
-    if (const char* l = getenv("ECAD_FUSE_FINAL")) fuse_final = atoi(l) != 0;
     if (const char* l = getenv("ECAD_PLAN_CACHE")) plan_lru_cap = (size_t)(atoi(l) > 0 ? atoi(l) : 0);
     custom_mask.assign((size_t)cfg.num_layers * 3, 0);
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
-    if (const char* l = getenv("ECAD_LN_COMB")) use_comb = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LN_FOLD")) ln_fold = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LN_FOLD_BUDGET_MB")) fold_budget = (size_t)(atoll(l) > 0 ? atoll(l) : 0) << 20;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
-    if (const char* l = getenv("ECAD_FP8_WIDE")) fp8_wide = atoi(l) != 0;
-    if (const char* at = getenv("ECAD_ATTN")) { attn_shared = strcmp(at, "generic") != 0; attn_dma = strcmp(at, "dma") == 0 ? 1 : strcmp(at, "dma4") == 0 ? 2 : 0; }
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
-    if (const char* l = getenv("ECAD_EPI_DIRECT")) epi_direct = atoi(l);
-    if (const char* l = getenv("ECAD_GEMM2W_WALK")) gemm2w_walk = atoi(l) != 0;
     if (const char* l = getenv("ECAD_TAIL_SPLIT")) tail_split = atoi(l) != 0;
-    if (const char* l = getenv("ECAD_WIDE_FILL")) wide_fill_rule = atoi(l) != 0;
-    if (const char* l = getenv("ECAD_LATENCY_ATTN")) latency_attn = atoi(l) != 0;
-    if (const char* l = getenv("ECAD_LATENCY_FILL")) latency_fill = atoi(l) > 0 ? atoi(l) : latency_fill;
-    if (const char* l = getenv("ECAD_ATTN_WIDE")) attn_wide = atoi(l) != 0;
-    if (const char* gh = getenv("ECAD_GEMM_HALF")) {  // A/B switch: 1 = the two attention out-projections, 2 = + FF2, 3 = + cross-attention Q when it runs unfused
-      const int lv = atoi(gh);
-      if (lv >= 1) gemm_impl_cls[KC_GEMM_OUT1] = gemm_impl_cls[KC_GEMM_OUT2] = 4;
-      if (lv >= 2) gemm_impl_cls[KC_GEMM_FF2] = 4;
-      if (lv >= 3) gemm_impl_cls[KC_GEMM_Q2] = gemm_impl_cls[KC_GEMM_QKV] = 4;
-    }
-    if (const char* gi = getenv("ECAD_GEMM")) {
-      if (strcmp(gi, "classic") == 0) { for (int c = 0; c < KC_COUNT; ++c) gemm_impl_cls[c] = 0; split_qkv = false; }
-      if (strcmp(gi, "tile128") == 0) tile128_mode = 2;
-      if (strcmp(gi, "wide") == 0) gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_SMALL] = 2;
-      if (strcmp(gi, "classic") && strcmp(gi, "tile128") && strcmp(gi, "wide")) return fail(ECAD_E_INVALID, "ECAD_GEMM=%s: unknown (classic | tile128 | wide; 'persistent' was retired in round 3)", gi);
-    }
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
     // ---- weight arena
@@ -773,7 +749,7 @@ template <typename T> class EngineT : public EngineBase {
   std::string make_key() const {
     std::string k((const char*)bits.data(), bits.size());
     k.append((const char*)custom_mask.data(), custom_mask.size());
-    const int geo[13] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, use_comb ? 1 : 0, split_qkv ? 1 : 0, fuse_attn ? 1 : 0, fuse_final ? 1 : 0, ln_fold ? 1 : 0, in_flight,
+    const int geo[10] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, fuse_attn ? 1 : 0, ln_fold ? 1 : 0, in_flight,
                          (self_bias_on ? 1 : 0) | (enc_bias_on ? 2 : 0)};
     k.append((const char*)geo, sizeof geo);
     return k;
@@ -855,7 +831,7 @@ template <typename T> class EngineT : public EngineBase {
     o.kind = Op<T>::GEMM; o.cls = cls; o.epi = epi;
     o.g.A = A; o.g.W = W; o.g.bias = bias; o.g.C = C; o.g.resid = nullptr; o.g.gate_table = nullptr; o.g.gate_mod = nullptr;
     o.g.gate_mod_stride = 0; o.g.rows_per_batch = N > 0 ? N : 1; o.g.M = M; o.g.N = Nn; o.g.K = K; o.g.lda = lda; o.g.ldw = K; o.g.ldc = ldc; o.g.ldr = ldc;
-    o.g.variant = gemm_variant; o.g.epi_direct = epi_direct;
+    o.g.variant = 1; o.g.epi_direct = 1;
     o.flops = 2.0 * M * (double)Nn * K;
     o.bytes = ((double)M * K + (double)Nn * K + (double)M * Nn) * sizeof(T);
     return o;
@@ -884,7 +860,7 @@ template <typename T> class EngineT : public EngineBase {
       o.desc_off = (int)desc_host.size();
       for (auto& p : pend) desc_host.push_back(SrcDesc{p.cache, p.gate_table, p.gate_mod});
     }
-    if (feeds_fp8 && fp8 && ln16 && D == 1152) {  // the consumers are fp8 GEMMs: the kernel writes e4m3 + row scales straight into a8 / sa8
+    if (feeds_fp8 && fp8 && D == 1152) {  // the consumers are fp8 GEMMs: the kernel writes e4m3 + row scales straight into a8 / sa8
       o.f.y8 = a8; o.f.y8_scale = sa8;
       a8_src = xn;
     } else {
@@ -961,9 +937,9 @@ template <typename T> class EngineT : public EngineBase {
         // (sample, two heads) and runs their attention on the spot -- no attention launch, no Q round trip through HBM
         // Long sequences (N >= 1024, e.g. Sigma-1024's 4096 tokens): the attention kernel with FOUR query fragments per wave (attention_dma.h R = 4: K / V staged
         // once per 512 query rows, every fragment read feeds four MFMAs) beats the fused tail, whose 256-row tile fixes two fragments per wave: Sigma-1024 shape 750
-        // against 850 us stand-alone, and the Q round trip it reintroduces is 2 % of that launch.  env ECAD_ATTN_WIDE=0: fused tail at every length.
-        const bool wide_items = attn_wide && !fp8 && DH == 72 && N >= 1024 && N % 512 == 0 && split_qkv && (2 * D) % G2_BN == 0 && attn_shared && !self_bias_on;
-        const bool fuse1 = fuse_attn && !wide_items && !fp8 && DH == 72 && split_qkv && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0 && !self_bias_on;
+        // against 850 us stand-alone, and the Q round trip it reintroduces is 2 % of that launch.
+        const bool wide_items = !fp8 && DH == 72 && N >= 1024 && N % 512 == 0 && (2 * D) % G2_BN == 0 && !self_bias_on;
+        const bool fuse1 = fuse_attn && !wide_items && !fp8 && DH == 72 && (2 * D) % G2_BN == 0 && N % G3_BM == 0 && N % G3A_KC == 0 && !self_bias_on;
         const bool fold1 = fold_plan && (fuse1 || wide_items) && cb && pend.empty() && stats_ok;
         const T* a_in = xn;
         const T* w_in = B.w_qkv;
@@ -995,7 +971,7 @@ template <typename T> class EngineT : public EngineBase {
           ops.push_back(q);
           a8_src = nullptr;
         } else {
-        if (split_qkv && (2 * D) % G2_BN == 0) {
+        if ((2 * D) % G2_BN == 0) {
           // Q columns on 256x144 tiles (256 tiles) + K,V columns on 256x288 tiles (256 tiles): the wide tiles move 32 % fewer
           // L2->LDS bytes per flop, and both launches fill the chip exactly once
           Op<T> q = mk_gemm(KC_GEMM_QKV, EPI_BIAS, a_in, w_in, b_in, qkv, M, D, D, D, 3 * D);
@@ -1082,7 +1058,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t n_before = ops.size();
     const size_t n_pend = pend.size();
     emit_ln(ops, pend, M, sst_out, sst_out + D, emb_s, emb_s, estride, mstride);
-    if (fuse_final && D == 1152 && P * P * COUT == 32 && ops.size() > n_before && ops.back().kind == Op<T>::LN && !ops.back().f.y8) {
+    if (D == 1152 && P * P * COUT == 32 && ops.size() > n_before && ops.back().kind == Op<T>::LN && !ops.back().f.y8) {
       // one launch for replays + norm_out + modulate + proj_out + unpatchify (final_layer.h); the hidden states are not written back
       Op<T>& o = ops.back();
       o.kind = Op<T>::FINAL; o.cls = KC_GEMM_SMALL; o.p2 = noise; o.call_out = bind_call;
@@ -1150,13 +1126,13 @@ template <typename T> class EngineT : public EngineBase {
     fold_release_current();
     fold_prep_begin = plan_run.size();
     emit_temb(plan_run, ts_dev, steps, 0, false);
-    comb_live = use_comb && ln16 && D == 1152 && (L < 2 || blk[1].sst - blk[0].sst == (blk[L - 1].sst - blk[0].sst) / (L - 1));
+    comb_live = D == 1152 && (L < 2 || blk[1].sst - blk[0].sst == (blk[L - 1].sst - blk[0].sst) / (L - 1));
     if (comb_live) { Op<T> c; c.kind = Op<T>::COMB; c.cls = KC_MISC; plan_run.push_back(c); }
     fold_prep_ops = plan_run.size() - fold_prep_begin;
     // LayerNorm folded into the consumer GEMMs: needs the per-(step, block) comb vectors, fp16 / bf16 GEMMs, 144-column tiles for the statistics,
     // and a timestep embedding that depends on the timestep only (the 1024-MS micro-conditioning adds per-batch terms)
     fold_plan_on = ln_fold && comb_live && !fp8 && !cfg.use_additional_conditions && D == LN_PARTS * G3_BN && gemm_impl_cls[KC_GEMM_OUT1] == 0 &&
-                   gemm_impl_cls[KC_GEMM_OUT2] == 0 && gemm_impl_cls[KC_GEMM_FF2] == 0 && gemm_impl_cls[KC_GEMM_KV1] == 2 && gemm_impl_cls[KC_GEMM_QKV] == 0 && !tile128_mode;
+                   gemm_impl_cls[KC_GEMM_OUT2] == 0 && gemm_impl_cls[KC_GEMM_FF2] == 0 && gemm_impl_cls[KC_GEMM_KV1] == 2 && gemm_impl_cls[KC_GEMM_QKV] == 0;
     if (fold_plan_on) {
       size_t n1 = 0, n2 = 0;
       for (int s_ = 0; s_ < steps; ++s_)
@@ -1242,46 +1218,36 @@ template <typename T> class EngineT : public EngineBase {
   }
   int num_cus = 256;
   bool g3_attr[4][KC_COUNT] = {};
-  bool g3h_attr[4][KC_COUNT] = {};
-  // per call-site class: 0 = one 256 x 144 tile per workgroup (gemm3s.h), 4 = its 128-row half tile, 5 = its 64-row latency tile;
-  // 2 = wide 256x288 tiles (gemm2w.h, N % 288 == 0).  Defaults from interleaved in-process A/B runs with cold caches
-  // (scripts/bench_gemm.py --cold): wide tiles wherever the tile count still fills the chip (FF1, text K/V, attn1 K,V);
-  // kernel for long K with a plain tile count (FF2); 8 mixed waves for the N = 1152 RMW epilogues and QKV.
-  // env ECAD_GEMM=classic forces gemm3s everywhere.
+  // per call-site class: 0 = one 256 x 144 tile per workgroup (gemm3s.h), 5 = its 64-row latency tile; 2 = wide 256x288 tiles (gemm2w.h, N % 288 == 0).
+  // Defaults from interleaved in-process A/B runs with cold caches (scripts/bench_gemm.py --cold): wide tiles wherever the tile count still fills the chip
+  // (FF1, text K/V, attn1 K,V); 256 x 144 tiles for the N = 1152 shapes and FF2.  ecad_op_gemm_ex overrides the choice for one launch (parity tests).
   int gemm_impl_cls[KC_COUNT];
-  int tile128_mode = 0;  // 2: every GEMM with N % 128 == 0 on the 128 x 128 kernel (ECAD_GEMM=tile128)
-  bool fuse_final = true;  // replays + norm_out + modulate + proj_out + unpatchify as one launch (final_layer.h; env ECAD_FUSE_FINAL=0: separate launches)
-  bool fuse_attn = true;  // attention in the tail of the query projection when the geometry allows (env ECAD_FUSE_ATTN=0: separate launches)
-  int gemm_variant = 1;  // K-loop schedule (GemmArgs::variant); env ECAD_GEMM_SCHED=0: the round-1 schedule
+  bool fuse_attn = true;  // attention in the tail of the query projection when the geometry allows (env ECAD_FUSE_ATTN=0: separate launches; bit-identical)
   bool g2_attr[4][KC_COUNT] = {};
-  bool split_qkv = true;  // env ECAD_SPLIT_QKV=0 keeps the single 3D-wide launch
   // Few rows (batch 1-4): a launch whose 256-row tiles cover less than half the chip is a latency chain (18-72 K-steps of ~0.8 us whatever the tile count);
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
   bool latency_tiles = true;
-  bool gemm2w_walk = true;  // gemm2w.h with the direct epilogue: grid = CUs, every workgroup walks its tiles (env ECAD_GEMM2W_WALK=0: one workgroup per tile)
-  int epi_direct = 1;  // gemm2w.h epilogues straight from the registers: 0 none, 1 the GELU epilogue (FF1), 2 the plain ones too (env ECAD_EPI_DIRECT)
-  bool wide_fill_rule = true;  // env ECAD_WIDE_FILL=0: wide call sites keep their 256x288 tiles however few
-  bool latency_attn = true;  // the attention-fused query projections take the latency tile too (env ECAD_LATENCY_ATTN=0: they keep the 256-row tile)
   int in_flight = 1;  // image batches the caller keeps in flight on this GPU (ecad_set_batches_in_flight)
-  int latency_fill = 50;  // "few" = the 256-row tiles of the launch cover at most this percentage of the CUs (env ECAD_LATENCY_FILL)
+  static constexpr int latency_fill = 50;  // "few" = the 256-row tiles of the launch (times the batches in flight) cover at most this percentage of the CUs (100 / 200 / 400 measured slower)
   bool g3q_attr[4][KC_COUNT] = {};
   static int rows_of(const GemmArgs<T>& g) { return (g.m_end ? g.m_end : g.M) - g.m_begin; }  // rows this launch covers (tail split below)
-  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && !tile128_mode && g.N % G3_BN == 0 && ((rows_of(g) + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * in_flight * 100 <= num_cus * latency_fill; }
+  bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && g.N % G3_BN == 0 && ((rows_of(g) + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * in_flight * 100 <= num_cus * latency_fill; }
   template <int EPI, int TAG> int launch_quarter(const GemmArgs<T>& g, hipStream_t s) {
     if (!g3q_attr[EPI][TAG]) {
-      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
       g3q_attr[EPI][TAG] = true;
     }
     const int tq = ((rows_of(g) + G3Q_BM - 1) / G3Q_BM) * (g.N / G3_BN);
-    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3(tq), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>), dim3(tq), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
     return ECAD_OK;
   }
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
-    if (gemm_impl_cls[TAG] == 5 || (few_rows(g) && gemm_impl_cls[TAG] != 4)) return launch_quarter<EPI, TAG>(g, s);
+    // (the split-K wave layout of the even / odd call sites is written for an even count >= 4 of 64-deep K-steps -- every K of the model; other K take the latency tile: same order)
+    if (gemm_impl_cls[TAG] == 5 || few_rows(g) || (eo_site(TAG) && (g.K % 128 != 0 || g.K < 256))) return launch_quarter<EPI, TAG>(g, s);
     if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
       // wide 256x288 tiles -- unless they would leave half the chip idle (FF1 at batch 4-7 alone on the GPU: 128-224 tiles): then the 256x144 tiles below, twice as many
-      const bool wide_underfills = g.N % G3_BN == 0 && ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN) * in_flight * 2 <= num_cus && !tile128_mode && wide_fill_rule;
+      const bool wide_underfills = g.N % G3_BN == 0 && ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN) * in_flight * 2 <= num_cus;
       if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0 && !wide_underfills) {
         if (!g2_attr[EPI][TAG]) {
           HIPCHK(hipFuncSetAttribute((const void*)gemm2w_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
@@ -1289,27 +1255,18 @@ template <typename T> class EngineT : public EngineBase {
         }
         const int tiles2 = ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN);
         // direct epilogue (LDS-free): one workgroup per CU walks its tiles and fetches the next tile's first K-step under the epilogue (gemm2w.h)
-        const bool walk = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && g.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1) && gemm2w_walk && tiles2 > num_cus && tiles2 % num_cus == 0;
+        const bool walk = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && g.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1) && tiles2 > num_cus && tiles2 % num_cus == 0;
         hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(walk ? num_cus : tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);
         return ECAD_OK;
       }
     }
-    if (gemm_impl_cls[TAG] == 4) {  // 128 x 144 tiles, four waves, two workgroups per CU (gemm3s.h half-tile variant; ECAD_GEMM_HALF / kernel id 4)
-      if (!g3h_attr[EPI][TAG]) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3H_BM, G3H_NW, G3H_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3H_LDS_BYTES));
-        g3h_attr[EPI][TAG] = true;
-      }
-      const int tilesh = ((rows_of(g) + G3H_BM - 1) / G3H_BM) * (g.N / G3_BN);
-      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3H_BM, G3H_NW, G3H_STAGES>), dim3(tilesh), dim3(G3H_NW * 64), G3H_LDS_BYTES, s, g);
-      return ECAD_OK;
-    }
     if (gemm_impl_cls[TAG] == 0 || (gemm_impl_cls[TAG] == 2 && g.N % G3_BN == 0)) {  // (2: a wide call site whose wide tiles would underfill the chip)
       if (!g3_attr[EPI][TAG]) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
         g3_attr[EPI][TAG] = true;
       }
       const int tiles3 = ((rows_of(g) + G3_BM - 1) / G3_BM) * (g.N / G3_BN);
-      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
       return ECAD_OK;
     }
     return fail(ECAD_E_INVALID, "no GEMM kernel selected for call site %d (implementation id %d)", TAG, gemm_impl_cls[TAG]);
@@ -1320,28 +1277,22 @@ template <typename T> class EngineT : public EngineBase {
     if (g.N % G3_BN || g.rows_per_batch % G3_BM || g.M % G3_BM || DH != 72 || !g.att_k || !g.att_v || !g.att_out || g.att_nk < 1 || g.att_ldo % 4 || g.att_ldk % 8)
       return fail(ECAD_E_UNSUPPORTED, "fused attention needs 256-row tiles inside one sample and head_dim 72");
     if (EPI == EPI_BIAS_ATTN && g.att_nk % G3A_KC) return fail(ECAD_E_UNSUPPORTED, "fused self-attention needs a key count that is a multiple of 128");
-    if (gemm_impl_cls[TAG] == 5 || (latency_attn && few_rows(g))) {  // few rows: 64 query rows x two heads per workgroup, four times the workgroups (the same arithmetic per row)
+    if (gemm_impl_cls[TAG] == 5 || few_rows(g) || g.K % 128 != 0 || g.K < 256) {  // few rows: 64 query rows x two heads per workgroup, four times the workgroups (the same arithmetic per row)
       if (!g3qa_attr[EPI - EPI_BIAS_ATTN]) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
         g3qa_attr[EPI - EPI_BIAS_ATTN] = true;
       }
-      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3((rows_of(g) / G3Q_BM) * (g.N / G3_BN)), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>), dim3((rows_of(g) / G3Q_BM) * (g.N / G3_BN)), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
       return ECAD_OK;
     }
     if (!g3a_attr[EPI - EPI_BIAS_ATTN]) {
-      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
       g3a_attr[EPI - EPI_BIAS_ATTN] = true;
     }
     const int tiles3 = (rows_of(g) / G3_BM) * (g.N / G3_BN);
-    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
     return ECAD_OK;
   }
-  // Few rows (batch 1-2: M = 512-1024) leave most CUs without a 256-row tile: 2 x 8 tiles for an N = 1152 GEMM at batch 1.  The 128 x 128 kernel of
-  // gemm.h covers the same problem with 2.25-4.5 x as many workgroups: opt-in (env ECAD_GEMM=tile128), measured +8 % at batch 1 and 2, nothing at
-  // batch 4 -- a batch of 1, 2 or 4 images takes the same 56-58 ms, the chain of 2 149 dependent launches at ~26 us each (18-72 K-steps of ~0.8 us
-  // whatever the tile count), not the tile count, is what small batches wait for.  Off by default so that the small-batch engine tests keep
-  // exercising the kernels the headline configuration runs.
-  bool use_tile128(const GemmArgs<T>& g) const { return tile128_mode == 2 && g.N % 128 == 0; }
   // Tail split (round 3): a launch of w whole rounds of 256-row tiles plus a last round that would leave at least half the CUs idle (batch 100:
   // 1600 tiles of the N = 1152 GEMMs = 6.25 rounds) goes out as two launches over row ranges -- the w whole rounds as they are, and the remaining rows as a
   // problem of their own, which the few-rows / wide-underfill rules then put on 64-row latency tiles or 256 x 144 tiles.  Only with one batch in flight (with
@@ -1349,11 +1300,11 @@ template <typename T> class EngineT : public EngineBase {
   bool tail_split = true;
   int launch_gemm(int epi, int cls, const GemmArgs<T>& g, hipStream_t s) {
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
-    if (tail_split && in_flight == 1 && !g.m_begin && !g.m_end && g.N % G3_BN == 0 && !use_tile128(g) && g.M % G3_BM == 0) {
+    if (tail_split && in_flight == 1 && !g.m_begin && !g.m_end && g.N % G3_BN == 0 && g.M % G3_BM == 0) {
       const bool wide_site = cls == KC_GEMM_FF1 || cls == KC_GEMM_TEXTKV || cls == KC_GEMM_SMALL || cls == KC_GEMM_KV1;
       const int tn_sel = wide_site && gemm_impl_cls[cls] == 2 && g.N % G2_BN == 0 ? g.N / G2_BN : g.N / G3_BN;
       const int total = (g.M / G3_BM) * tn_sel, whole = total / num_cus, rem = total % num_cus;
-      if (whole >= 1 && rem > 0 && rem * 2 <= num_cus && (whole * num_cus) % tn_sel == 0 && gemm_impl_cls[cls] != 4 && gemm_impl_cls[cls] != 5) {
+      if (whole >= 1 && rem > 0 && rem * 2 <= num_cus && (whole * num_cus) % tn_sel == 0 && gemm_impl_cls[cls] != 5) {
         GemmArgs<T> part = g;
         part.m_end = (whole * num_cus / tn_sel) * G3_BM;
         int rc = launch_gemm(epi, cls, part, s);
@@ -1366,7 +1317,7 @@ template <typename T> class EngineT : public EngineBase {
     if (epi == EPI_BIAS_ATTN && cls == KC_GEMM_QKV) return launch_g3_attn<EPI_BIAS_ATTN, KC_GEMM_QKV>(g, s);
     if (epi == EPI_BIAS_ATTN_TAIL && cls == KC_GEMM_Q2) return launch_g3_attn<EPI_BIAS_ATTN_TAIL, KC_GEMM_Q2>(g, s);
     if (epi == EPI_BIAS_ATTN || epi == EPI_BIAS_ATTN_TAIL) return fail(ECAD_E_INVALID, "fused attention epilogue on call site %d", cls);
-    if (g.N % G3_BN == 0 && !use_tile128(g)) {
+    if (g.N % G3_BN == 0) {
 #define G144(E, C) if (epi == E && cls == C) return launch_pg<E, C>(g, s)
       G144(EPI_BIAS, KC_GEMM_QKV); G144(EPI_BIAS, KC_GEMM_KV1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT1); G144(EPI_BIAS, KC_GEMM_Q2); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_OUT2);
       G144(EPI_BIAS_GELU, KC_GEMM_FF1); G144(EPI_BIAS_CACHE_RESID, KC_GEMM_FF2); G144(EPI_BIAS, KC_GEMM_TEXTKV);
@@ -1397,29 +1348,17 @@ template <typename T> class EngineT : public EngineBase {
     hipLaunchKernelGGL((attn_kernel<T, KC, MASKED>), dim3(items < cap ? items : cap), dim3(512), lds, s, a);
     return ECAD_OK;
   }
-  int attn_shared = 1;  // attention128.h structure (both query fragments of a wave share each K / V fragment read); env ECAD_ATTN=generic: attention.h
+  int attn_shared = 1;  // attention128.h (d_h 72: both query fragments of a wave share each K / V fragment read); 0 (ecad_op_attention_ex only): the generic attention.h, which serves every other head size
   bool attn_shared_attr[2] = {};
-  bool attn_wide = true;  // self-attention over >= 1024 tokens: stand-alone launch with four query fragments per wave instead of the fused tail (env ECAD_ATTN_WIDE=0)
-  int attn_dma = 0;  // env ECAD_ATTN=dma: attention_dma.h for unmasked attention over whole 128-key chunks (A/B)
-  bool attn_dma_attr[2] = {};
+  bool attn_dma_attr = false;
   int launch_attn(const AttnArgs& a, bool masked, hipStream_t s, bool wide = false) {
-    if ((attn_dma == 2 || wide) && a.dh == 72 && !masked && a.Nk % 128 == 0 && a.seg_t == 0 && a.Nq % 512 == 0) {  // four query fragments per wave: 512 query rows per work item
-      if (!attn_dma_attr[1]) {
+    if (wide && a.dh == 72 && !masked && a.Nk % 128 == 0 && a.seg_t == 0 && a.Nq % 512 == 0) {  // four query fragments per wave: 512 query rows per work item (attention_dma.h)
+      if (!attn_dma_attr) {
         HIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 72, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<72>()));
-        attn_dma_attr[1] = true;
+        attn_dma_attr = true;
       }
       const int items4 = a.B * a.H * (a.Nq / 512);
       hipLaunchKernelGGL((attn_dma_kernel<T, 72, 4>), dim3(items4 < num_cus ? items4 : num_cus), dim3(512), attn_dma_lds_bytes<72>(), s, a);
-      return ECAD_OK;
-    }
-    if (attn_dma && a.dh == 72 && !masked && a.Nk % 128 == 0 && a.seg_t == 0) {
-      if (!attn_dma_attr[0]) {
-        HIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 72>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<72>()));
-        attn_dma_attr[0] = true;
-      }
-      const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
-      const int grid = items < num_cus ? items : num_cus;
-      hipLaunchKernelGGL((attn_dma_kernel<T, 72>), dim3(grid), dim3(512), attn_dma_lds_bytes<72>(), s, a);
       return ECAD_OK;
     }
     if (attn_shared && a.dh == 72) {
@@ -1439,7 +1378,7 @@ template <typename T> class EngineT : public EngineBase {
     if (masked || a.Nk % 128) return launch_attn_t<128, true>(a, 0, 1, s);
     return launch_attn_t<128, false>(a, 1, 1, s);
   }
-  int ln16 = 1;  // 16 lanes per row (D = 1152: 9 chunks per lane), ln16 rows per lane group: 16.2 -> 15.3 us per launch at 1 row, 18.3 at 2, 25.7 at 4
+  static constexpr int ln16 = 1;  // 16 lanes per row (D = 1152: 9 chunks per lane), ln16 rows per lane group: 16.2 -> 15.3 us per launch at 1 row, 18.3 at 2, 25.7 at 4
                  // (the pass is bound by the number of loads in flight, not by bandwidth); env ECAD_LN16=0: one wave per row
   int launch_ln(const FlushArgs& f, hipStream_t s) {
 #ifdef ECAD_ABL_NOLN  // timing ablation only (wrong results): what the LayerNorm launches without pending replays cost end to end
@@ -1448,7 +1387,7 @@ template <typename T> class EngineT : public EngineBase {
     const int cpr = f.D / 8;
     const int grid = (f.M + 3) / 4;
     if (f.D % 8) return fail(ECAD_E_INVALID, "D %% 8 != 0");
-    if (ln16 && f.D == 1152) {  // 16 lanes per row, 9 chunks per lane
+    if (f.D == 1152) {  // 16 lanes per row, 9 chunks per lane
       const dim3 g16(((f.M + 15) / 16 + ln16 - 1) / ln16);  // ln16 rows per 16-lane group
       if (f.comb_shift) hipLaunchKernelGGL((ln_modulate16_kernel<T, 9, true>), g16, dim3(256), 0, s, f);
       else hipLaunchKernelGGL((ln_modulate16_kernel<T, 9, false>), g16, dim3(256), 0, s, f);
@@ -1461,11 +1400,10 @@ template <typename T> class EngineT : public EngineBase {
   }
   // Rows kernel (4 rows per thread, gate fetched once per 4 chunks, non-temporal cache reads) whenever the shapes allow: in-run A/B on the
   // 84-source cache-hit step at Bt 32: 389 -> 258 us (4.17 -> 6.29 TB/s), mid-step replays 162 -> 105 us; 2 rows 340 us, 8 rows 276 us;
-  // capping the grid at 6 or 8 resident blocks per CU, or 8 sources in flight in the flat kernel: slower or equal.  ECAD_REPLAY=flat
-  // restores the one-chunk-per-thread kernel.
+  // capping the grid at 6 or 8 resident blocks per CU, or 8 sources in flight in the flat kernel: slower or equal.  The
+  // one-chunk-per-thread kernel takes the ragged shapes.
   void launch_replay(const FlushArgs& f, hipStream_t s, bool hit_step = false) {
-    static const bool flat = getenv("ECAD_REPLAY") && strcmp(getenv("ECAD_REPLAY"), "flat") == 0;
-    if (!flat && f.M % 4 == 0 && f.rows_per_batch % 4 == 0) {
+    if (f.M % 4 == 0 && f.rows_per_batch % 4 == 0) {
       const size_t nb = ((size_t)(f.M / 4) * (f.D / 8) + 255) / 256;
       if (hit_step) hipLaunchKernelGGL((cache_accumulate_rows_kernel<T, 1, 4>), dim3((unsigned)nb), dim3(256), 0, s, f);
       else hipLaunchKernelGGL((cache_accumulate_rows_kernel<T, 0, 4>), dim3((unsigned)nb), dim3(256), 0, s, f);
@@ -1489,7 +1427,7 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::GEMM8: {
         Gemm8Args<T> q{};
         q.A8 = a8; q.W8 = o.w8; q.sa = sa8; q.sw = o.sw8; q.lda8 = o.g.K; q.e = o.g;
-        if (fp8_wide && o.epi != EPI_BIAS_CACHE_RESID && o.g.N % G2_BN == 0 && ((o.g.M + G2_BM - 1) / G2_BM) * (o.g.N / G2_BN) >= num_cus) {  // 256 x 288 tiles, 4 x 2 waves
+        if (o.epi != EPI_BIAS_CACHE_RESID && o.g.N % G2_BN == 0 && ((o.g.M + G2_BM - 1) / G2_BM) * (o.g.N / G2_BN) >= num_cus) {  // 256 x 288 tiles, 4 x 2 waves
           const int tiles2 = ((o.g.M + G2_BM - 1) / G2_BM) * (o.g.N / G2_BN);
           if (o.epi == EPI_BIAS) hipLaunchKernelGGL((gemm2w8_kernel<T, EPI_BIAS>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, q);
           else hipLaunchKernelGGL((gemm2w8_kernel<T, EPI_BIAS_GELU>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, q);
@@ -1506,9 +1444,7 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::REPLAY: launch_replay(o.f, s, o.cls == KC_CACHE_HIT_STEP); break;
       case Op<T>::PATCH: {
         const T* src = o.call_latents ? (const T*)call_latents : (const T*)o.p0;
-        static const bool rows = getenv("ECAD_PATCH") && strcmp(getenv("ECAD_PATCH"), "rows") == 0;  // the earlier row-of-patches kernel
-        if (rows) hipLaunchKernelGGL((patch_embed_kernel<T, 4, 2>), dim3(Hl / P, Bt), dim3(128), CIN * P * Wl * sizeof(float), s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
-        else hipLaunchKernelGGL((patch_embed_cols_kernel<T, 256>), dim3(D / 128, Bt * ((N + 255) / 256)), dim3(256), 0, s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
+        hipLaunchKernelGGL((patch_embed_cols_kernel<T, 256>), dim3(D / 128, Bt * ((N + 255) / 256)), dim3(256), 0, s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
         break;
       }
       case Op<T>::SINUS: {
@@ -1819,7 +1755,7 @@ template <typename T> class EngineT : public EngineBase {
     GemmArgs<T> g{};
     g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
     g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K; g.lda = K; g.ldw = K; g.ldc = Nn; g.ldr = Nn;
-    g.variant = gemm_variant; g.epi_direct = epi_direct;
+    g.variant = 1; g.epi_direct = 1;
     if (epi == EPI_BIAS_CACHE_RESID && !resid) return fail(ECAD_E_INVALID, "epilogue 3 needs resid");
     int rc = launch_gemm(epi, KC_GEMM_SMALL, g, s);
     if (rc) return rc;
@@ -1840,7 +1776,7 @@ template <typename T> class EngineT : public EngineBase {
       return fail(ECAD_E_INVALID, "fused query projection + attention: x / wq / k / v / out must be 16-byte aligned and ld_kv (%lld) a multiple of 8 >= %d", (long long)ld_kv, D);
     GemmArgs<T> g{};
     g.A = (const T*)x; g.W = (const T*)wq; g.bias = bq; g.C = nullptr; g.M = Bt_ * n_tokens; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldc = D; g.ldr = D;
-    g.rows_per_batch = n_tokens; g.variant = gemm_variant; g.epi_direct = epi_direct;
+    g.rows_per_batch = n_tokens; g.variant = 1; g.epi_direct = 1;
     g.att_k = (const T*)k; g.att_v = (const T*)v; g.att_out = (T*)out; g.att_bias = tail ? key_bias : nullptr; g.att_ldk = (int)ld_kv; g.att_ldo = D; g.att_nk = n_keys;
     g.att_scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
     const int rc = launch_gemm(tail ? EPI_BIAS_ATTN_TAIL : EPI_BIAS_ATTN, site, g, s);
@@ -1857,8 +1793,8 @@ template <typename T> class EngineT : public EngineBase {
     g.A = (const T*)A; g.W = (const T*)W; g.bias = bias; g.C = (T*)out; g.resid = (T*)resid; g.gate_table = gate_table; g.gate_mod = (const T*)gate_mod;
     g.gate_mod_stride = gate_mod_stride; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.M = M; g.N = Nn; g.K = K;
     g.lda = lda > 0 ? (int)lda : K; g.ldw = K; g.ldc = ldc > 0 ? (int)ldc : Nn; g.ldr = Nn;
-    g.variant = (kernel >> 8) ? ((kernel >> 8) - 1) & 3 : gemm_variant;  // bits 8+ of `kernel`: 1 + schedule variant to force (A/B in one process); 0 = the engine's
-    g.epi_direct = (kernel >> 8) && (((kernel >> 8) - 1) & 12) ? ((((kernel >> 8) - 1) & 4) ? 2 : 0) : epi_direct;  // + 4: direct epilogue forced on, + 8: forced off
+    g.variant = (kernel >> 8) ? ((kernel >> 8) - 1) & 3 : 1;  // bits 8+ of `kernel`: 1 + schedule variant to force (A/B in one process); 0 = the engine's
+    g.epi_direct = (kernel >> 8) && (((kernel >> 8) - 1) & 12) ? ((((kernel >> 8) - 1) & 4) ? 2 : 0) : 1;  // + 4: direct epilogue forced on, + 8: forced off
     kernel &= 0xff;
     if (g.K % GEMM_BK || g.M < 1) return fail(ECAD_E_INVALID, "gemm shape M=%d N=%d K=%d unsupported (K%%64)", g.M, g.N, g.K);
     if (kernel == 3) {
@@ -1873,9 +1809,10 @@ template <typename T> class EngineT : public EngineBase {
       HIPCHK(hipGetLastError());
       return ECAD_OK;
     }
-    if ((kernel == 4 || kernel == 5) && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the half / latency tiles have no attention tail");
+    if (kernel == 4) return fail(ECAD_E_UNSUPPORTED, "the 128 x 144 half-tile variant was measured slower at every call site (DESIGN 5c) and removed in round 4");
+    if (kernel == 5 && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the latency tiles have no attention tail through this entry");
     if (kernel == 1) return fail(ECAD_E_UNSUPPORTED, "the persistent producer / consumer kernel (pgemm.h) was retired in round 3: no call site used it");
-    if ((kernel < 0 || kernel > 2) && kernel != 4 && kernel != 5) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
+    if ((kernel < 0 || kernel > 2) && kernel != 5) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
     if (Nn % G3_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
     if (kernel == 2) {
       if (Nn % G2_BN) return fail(ECAD_E_UNSUPPORTED, "gemm2w tiles need N %% 288 == 0, got %d", Nn);
@@ -1895,8 +1832,19 @@ template <typename T> class EngineT : public EngineBase {
   }
   int op_attention_ex(int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk,
                       int dh, const float* bias, hipStream_t s) override {
-    if (kernel < 0 || kernel > 2) return fail(ECAD_E_INVALID, "attention kernel %d unknown", kernel);
-    if (kernel == 2 && dh != 72) return fail(ECAD_E_UNSUPPORTED, "attention128.h is instantiated for head_dim 72 on this path, got %d", dh);
+    if (kernel < 0 || kernel > 3) return fail(ECAD_E_INVALID, "attention kernel %d unknown", kernel);
+    if (kernel >= 2 && dh != 72) return fail(ECAD_E_UNSUPPORTED, "attention128.h / attention_dma.h are instantiated for head_dim 72 on this path, got %d", dh);
+    if (kernel == 3) {  // attention_dma.h with four query fragments per wave: what the plans launch for self-attention over >= 1024 tokens
+      if (bias || Nk % 128 || Nq % 512) return fail(ECAD_E_UNSUPPORTED, "the four-fragment kernel needs Nq %% 512 == 0, Nk %% 128 == 0 and no key bias");
+      HIPCHK(hipSetDevice(dev));
+      AttnArgs a{};
+      a.q = q; a.k = k; a.v = v; a.out = out; a.bias = nullptr; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh;
+      a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)dh));
+      const int rc = launch_attn(a, false, s, true);
+      if (rc) return rc;
+      HIPCHK(hipGetLastError());
+      return ECAD_OK;
+    }
     const int keep = attn_shared;
     if (kernel) attn_shared = kernel == 2;
     const int rc = op_attention(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Nq, Nk, dh, bias, s);

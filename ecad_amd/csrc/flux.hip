@@ -186,8 +186,7 @@ template <typename T> class FluxT : public FluxBase {
   double prof_ms[FC_COUNT], prof_flops[FC_COUNT], prof_bytes[FC_COUNT];
   int64_t prof_launch[FC_COUNT];
   int num_cus = 256;
-  int bn_force = 0;  // env ECAD_FLUX_BN=128|256 forces one tile width wherever it divides N (A/B)
-  int lanes = 2;              // env ECAD_FLUX_LANES=1: everything on one stream (A/B)
+  static constexpr int lanes = 2;  // the text and the image stream of a joint block run on two HIP streams inside the captured graph
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint8_t* a8_side = nullptr;  // the side lane's own quantisation scratch ([B*T][4D])
@@ -201,11 +200,11 @@ template <typename T> class FluxT : public FluxBase {
   uint8_t* xn8 = nullptr;     // [R][D] LN output in e4m3 (row layout of xn) when its only consumers are fp8 GEMMs
   float* sxn8 = nullptr;      // [R]
   bool f8_engine_attr = false;
-  bool fuse_rope = true;      // env ECAD_FLUX_FUSE=0: separate qk_norm_rope pass and separate single-block QKV / proj_mlp GEMMs (A/B)
-  int epi_direct = 1;  // GELU tiles of the block GEMMs stored straight from the registers (fgemm.h; env ECAD_FLUX_EPI_DIRECT=0: through the C tile)
-  bool attn_generic = false;  // env ECAD_FLUX_ATTN=generic: the d_h-templated kernel of attention.h (A/B)
-  int attn_dma = 2;           // attention_dma.h (K / V chunks by LDS-DMA into a double-buffered image) with the partial last round of work items run as 128-row
-                              // items in a second launch; env ECAD_FLUX_ATTN=dma: one launch, =shared: attention128.h, =generic: attention.h
+  static constexpr bool fuse_rope = true;  // RMSNorm + RoPE in the QKV epilogue, single-block QKV + proj_mlp as one GEMM (the separate pass remains as ecad_flux_op_qk_norm_rope)
+  static constexpr int epi_direct = 1;  // GELU tiles of the block GEMMs stored straight from the registers (fgemm.h)
+  static constexpr bool attn_generic = false;
+  static constexpr int attn_dma = 2;  // attention_dma.h (K / V chunks by LDS-DMA into a double-buffered image) with the partial last round of work items run as 128-row
+                                      // items in a second launch; attention128.h takes the shapes it does not cover
   bool attn_dma_attr[1] = {};
   const void* call_in = nullptr;
   void* call_out = nullptr;
@@ -338,16 +337,11 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipSetDevice(dev));
     FHIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     { hipDeviceProp_t pr; FHIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    if (const char* e = getenv("ECAD_FLUX_BN")) bn_force = atoi(e) == 128 ? 128 : atoi(e) == 256 ? 256 : 0;
-    if (const char* e = getenv("ECAD_FLUX_FUSE")) fuse_rope = atoi(e) != 0;
     if (const char* e = getenv("ECAD_FLUX_FP8")) fp8 = atoi(e) != 0;
-    if (const char* e = getenv("ECAD_FLUX_LANES")) lanes = atoi(e) == 1 ? 1 : 2;
     FHIPCHK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
     FHIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     FHIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     if (fp8 && D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
-    if (const char* e = getenv("ECAD_FLUX_EPI_DIRECT")) epi_direct = atoi(e);
-    if (const char* e = getenv("ECAD_FLUX_ATTN")) { attn_generic = strcmp(e, "generic") == 0; attn_dma = strcmp(e, "dma") == 0 ? 1 : strcmp(e, "dma-split") == 0 ? 2 : (strcmp(e, "shared") == 0 || strcmp(e, "generic") == 0) ? 0 : attn_dma; }
     MODW = ((size_t)NL * 12 + (size_t)NS * 3 + 2) * D;
 
     // ---- weights: a dry layout pass sizes the arena
@@ -553,7 +547,6 @@ template <typename T> class FluxT : public FluxBase {
   // can cost more than it saves (joint ff2 on 8192 image rows: 384 tiles = 1.5 rounds vs 768 = 3.0 rounds: 106 ms vs 88 ms).
   int pick_bn(int M, int Nn) const {
     if (Nn % 256) return 128;
-    if (bn_force) return bn_force;
     const int tm = (M + 255) / 256;
     const int r256 = (tm * (Nn / 256) + num_cus - 1) / num_cus, r128 = (tm * (Nn / 128) + num_cus - 1) / num_cus;
     return 1.6 * r256 <= 1.0 * r128 ? 256 : 128;
@@ -1004,7 +997,7 @@ template <typename T> class FluxT : public FluxBase {
     return ECAD_OK;
   }
   void launch_replay(const FluxRowArgs& f, hipStream_t s) {
-    static const bool flat = getenv("ECAD_REPLAY") && strcmp(getenv("ECAD_REPLAY"), "flat") == 0;
+    constexpr bool flat = false;
     const int rpb1 = f.rows_per_batch1 > 0 ? f.rows_per_batch1 : 4;
     if (!flat && f.M % 4 == 0 && f.seg0 % 4 == 0 && (f.seg0 == 0 || f.rows_per_batch0 % 4 == 0) && rpb1 % 4 == 0) {  // 4 rows per thread (flux_kernels.h)
       const size_t nb = ((size_t)(f.M / 4) * (f.D / 8) + 255) / 256;

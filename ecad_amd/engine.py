@@ -322,14 +322,14 @@ class EcadEngine:
         )
         return out
 
-    GEMM_KERNELS = {"tile144": 0, "persistent": 1, "wide288": 2, "tile128": 3, "half144": 4, "latency64": 5}
+    GEMM_KERNELS = {"tile144": 0, "wide288": 2, "tile128": 3, "latency64": 5}
     GEMM_SITES = {"qkv": 0, "attn1_out": 1, "attn2_q": 2, "attn2_out": 3, "ff1": 4, "ff2": 5, "text_kv": 6, "caption": 7, "small": 8, "attn1_kv": 9}
 
     def op_gemm_ex(self, kernel: str, site: str, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None,
                    sched: int | None = None):
         """``op_gemm`` on a named kernel / call-site instantiation (``ecad_op_gemm_ex``); ``a`` and ``out`` may be column slices (row stride > width).
-        ``sched``: force K-loop schedule variant 0 / 1 (default: the engine's own, env ECAD_GEMM_SCHED); + 4: gemm2w's direct (register) epilogue for every
-        epilogue kind, + 8: its staged epilogue (default: direct for the GELU epilogue, env ECAD_EPI_DIRECT)."""
+        ``sched``: force K-loop schedule variant 0 / 1 of the sequential-order kernels (default 1: staggered LDS-DMA issue); + 4: gemm2w's direct (register)
+        epilogue for every epilogue kind, + 8: its staged epilogue (default: direct for the GELU epilogue)."""
         M, K = a.shape
         N = w.shape[0]
         if out is None and epi != 3:
@@ -366,10 +366,10 @@ class EcadEngine:
         return out
 
     def op_attention(self, q, k, v, B, H, Nq, Nk, dh, bias=None, kernel: str = "auto"):
-        """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer).  kernel: auto | generic (attention.h) | shared (attention128.h)."""
+        """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer).  kernel: auto | generic (attention.h) | shared (attention128.h) | wide4 (attention_dma.h, four query fragments per wave)."""
         out = torch.empty((B * Nq, H * dh), device=self.device, dtype=self.dtype)
         if kernel != "auto":
-            self._chk(self.lib.ecad_op_attention_ex(self._h, {"generic": 1, "shared": 2}[kernel], q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+            self._chk(self.lib.ecad_op_attention_ex(self._h, {"generic": 1, "shared": 2, "wide4": 3}[kernel], q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                                     out.data_ptr(), out.stride(0), B, H, Nq, Nk, dh, _ptr(bias), _stream_ptr()))
             return out
         self._chk(self.lib.ecad_op_attention(self._h, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0),

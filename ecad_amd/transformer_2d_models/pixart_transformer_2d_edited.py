@@ -307,7 +307,10 @@ class PixArtTransformer2DEdited:
         # What the step-invariant work of a batch (caption projection, text K/V: hoisted to its first forward) was computed from.  The tensors are held, so
         # their storage cannot be recycled under the key, and an in-place update bumps `_version`.
         def ident(t):
-            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+            if t is None:
+                return None
+            version = 0 if t.is_inference() else t._version  # (inference tensors carry no version counter)
+            return (t.data_ptr(), version, tuple(t.shape), t.dtype)
         key = (ident(encoder_hidden_states), ident(encoder_attention_mask), ident(attention_mask), tuple(hidden_states.shape))
         if self._begun_key != key:
             # A new batch: the engine recomputes the hoisted work and starts from empty caches.  (The reference drops its caches only in the callback after the

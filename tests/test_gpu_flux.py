@@ -60,27 +60,6 @@ def test_fgemm_bias_and_activations(op_engine, dtype, tol, bn, M, N, K):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("bn", [128, 256])
-def test_fgemm_gelu_tiles_stored_from_the_registers_are_the_staged_bytes(monkeypatch, dtype, tol, bn):
-    """fgemm.h (round 3): the GELU tiles leave straight from the accumulator registers (v_permlane16_swap between neighbouring fragments -> 16-byte stores of 64
-    contiguous bytes per row) instead of through the C tile in LDS; ECAD_FLUX_EPI_DIRECT=0 keeps the staged path.  Same bytes, ragged last row tile included."""
-    M, N, K = 1000, 768, 512
-    g = torch.Generator().manual_seed(77 + bn)
-    A = (torch.randn(M, K, generator=g) * 0.5).to(dtype).cuda()
-    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).cuda()
-    bias = torch.randn(N, generator=g).cuda()
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("ECAD_FLUX_EPI_DIRECT", mode)
-        eng = make_engine(tiny_cfg(1, 1), dtype)
-        outs[mode] = eng.op_gemm(1, bn, A, W, bias).clone()
-        torch.cuda.synchronize()
-        del eng
-    assert torch.equal(outs["0"], outs["1"])
-    assert rel_l2(outs["1"].float(), torch.nn.functional.gelu(A.float() @ W.float().T + bias, approximate="tanh")) <= tol
-
-
-@pytest.mark.parametrize("dtype,tol", DTYPES)
-@pytest.mark.parametrize("bn", [128, 256])
 def test_fgemm_split_a_gated_residual_two_segments(op_engine, dtype, tol, bn):
     """proj_out of the single-stream block: A = [attn | gelu(mlp)] from two buffers; resid += gate[b] * out with the
     [text | image] row layout (text rows of all samples first)."""
@@ -160,31 +139,29 @@ def test_joint_attention_matches_sdpa(op_engine, dtype, tol, T, N):
     assert within(rel_l2(out.float(), want), tol)
 
 
-def test_joint_attention_kernels_are_the_same_arithmetic(monkeypatch):
-    """The FLUX engine's default joint attention (attention_dma.h: K / V chunks by LDS-DMA into a double-buffered image; when the work items do not fill whole rounds
-    of workgroups, the rest of every (sample, head) runs as 128-row items in a second launch), its one-launch form (ECAD_FLUX_ATTN=dma) and attention128.h
-    (=shared) on the joint [text | image] layout with whole 128-key chunks on both sides of the boundary: bit-identical outputs.  B 2 x 24 heads x (128 + 2944) rows =
-    576 items on 256 CUs = 2.25 rounds, so the default really splits (512 items + 2 x 48 x 2 half items)."""
+def test_joint_attention_with_a_partial_last_round_of_work_items():
+    """The FLUX engine's joint attention (attention_dma.h: K / V chunks by LDS-DMA into a double-buffered image) when the work items do not fill whole rounds of
+    workgroups: the rest of every (sample, head) runs as 128-row items in a second launch.  B 2 x 24 heads x (128 + 2944) rows = 576 items on 256 CUs = 2.25 rounds,
+    so this really splits (512 items + 2 x 48 x 2 half items); every row against an fp32 reference of its sample."""
     dtype = torch.bfloat16
     B, T, N, H = 2, 128, 2944, 24
     D = H * 128
     qkv = (torch.randn(B * (T + N), 3 * D, generator=torch.Generator().manual_seed(11)) * 0.5).to(dtype).cuda()
-    outs = {}
-    for mode in ("shared", "dma", "dma-split"):
-        monkeypatch.setenv("ECAD_FLUX_ATTN", mode)
-        from ecad_amd.flux_engine import EcadFluxEngine
+    from ecad_amd.flux_engine import EcadFluxEngine
 
-        eng = EcadFluxEngine(num_layers=0, num_single_layers=0, num_heads=H, max_batch=B, max_image_tokens=N, max_text_tokens=T, dtype=dtype)
-        outs[mode] = eng.op_attention(qkv, B, T, N)
-        torch.cuda.synchronize()
-        eng.close()
-    assert torch.equal(outs["dma"], outs["shared"]) and torch.equal(outs["dma-split"], outs["shared"])
+    eng = EcadFluxEngine(num_layers=0, num_single_layers=0, num_heads=H, max_batch=B, max_image_tokens=N, max_text_tokens=T, dtype=dtype)
+    got = eng.op_attention(qkv, B, T, N)
+    torch.cuda.synchronize()
+    eng.close()
     S = T + N
-    rows = torch.cat([torch.arange(0, T), torch.arange(B * T, B * T + N)])  # sample 0
-    x = qkv[rows].float()
-    q, k, v = [x[:, i * D : (i + 1) * D].view(S, H, 128).transpose(0, 1) for i in range(3)]
-    want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(128), -1) @ v).transpose(0, 1).reshape(S, D)
-    assert within(rel_l2(outs["dma-split"][rows].float(), want), 5e-3)
+    worst = 0.0
+    for b in range(B):
+        rows = torch.cat([torch.arange(b * T, (b + 1) * T), torch.arange(B * T + b * N, B * T + (b + 1) * N)])
+        x = qkv[rows].float()
+        q, k, v = [x[:, i * D : (i + 1) * D].view(S, H, 128).transpose(0, 1) for i in range(3)]
+        want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(128), -1) @ v).transpose(0, 1).reshape(S, D)
+        worst = max(worst, rel_l2(got[rows].float(), want))
+    assert within(worst, 5e-3)
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)

@@ -65,11 +65,7 @@ KERNEL_CASES = [
     ("tile144", "caption", 1, 3840, 1152, 4096),
     ("tile144", "small", 2, 40, 1152, 256),
     ("tile128", "small", 1, 1000, 1024, 512),
-    # gemm3s.h half-tile variant: 128 x 144 tiles, four waves, 2-stage ring, two workgroups per CU (ECAD_GEMM_HALF)
-    ("half144", "attn2_q", 0, 8192, 1152, 1152),
-    ("half144", "attn2_q", 0, 700, 1152, 1152),
-    ("half144", "small", 2, 40, 1152, 256),
-    ("half144", "small", 1, 1000, 576, 64),
+    ("tile144", "attn2_q", 0, 600, 1152, 192),  # an odd count of 64-deep K-steps: the split-K wave layout hands over to the latency tile (same summation order)
     # gemm3s.h latency variant: 64 x 144 tiles, four waves of 16 x 144 -- what the engine launches when a GEMM has few rows (batch 1-4)
     ("latency64", "attn2_q", 0, 512, 1152, 1152),
     ("latency64", "ff1", 1, 512, 4608, 1152),
@@ -141,7 +137,6 @@ def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("kernel,site,K,B,Ntok", [("tile144", "attn1_out", 1152, 32, 256), ("tile144", "attn2_out", 1152, 3, 192), ("tile144", "ff2", 4608, 32, 256),
                                                  ("tile128", "small", 1152, 3, 192),
-                                                 ("half144", "attn1_out", 1152, 32, 256), ("half144", "attn2_out", 1152, 3, 192), ("half144", "ff2", 4608, 32, 256),
                                                  ("latency64", "attn1_out", 1152, 2, 256), ("latency64", "attn2_out", 1152, 3, 192), ("latency64", "ff2", 4608, 4, 256)])
 def test_gemm_cache_gate_residual_every_kernel(dtype_name, kernel, site, K, B, Ntok):
     """cache <- out; hidden += gate * out with gates of O(1) (cached_transformer_block.py:243-246,317-320,355-360) on every kernel that carries that epilogue, at
@@ -174,10 +169,39 @@ def test_gemm_ex_refuses_instead_of_substituting():
         eng.op_gemm_ex("wide288", "attn1_out", 0, a, w, None)
     with pytest.raises(ValueError, match="144"):
         eng.op_gemm_ex("tile144", "qkv", 0, a, w[:1024], None)
-    with pytest.raises(ValueError, match="retired"):  # pgemm.h left the library in round 3 (scripts/retired_pgemm.h): its id is refused, not mapped to another kernel
-        eng.op_gemm_ex("persistent", "ff2", 0, a, w, None)
+    with pytest.raises(ValueError, match="retired"):  # pgemm.h left the library in round 3: its id is refused, not mapped to another kernel
+        eng.GEMM_KERNELS["persistent"] = 1
+        try:
+            eng.op_gemm_ex("persistent", "ff2", 0, a, w, None)
+        finally:
+            del eng.GEMM_KERNELS["persistent"]
     with pytest.raises(ValueError, match="attention tail"):
         eng.op_gemm_ex("latency64", "qkv", 4, a, w, None)
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("site,epi,M,K", [("attn2_q", 0, 1024, 1152), ("attn1_out", 3, 512, 1152), ("ff2", 3, 768, 4608), ("caption", 1, 480, 4096)])
+def test_every_tile_shape_of_a_call_site_sums_k_in_the_same_order(dtype_name, site, epi, M, K):
+    """The N = 1152 call sites and FF2 add the even and the odd 32-deep K blocks separately (gemm3s.h: on the 256-row tile that is the split-K wave layout -- two waves
+    per 64 rows, one per K half, exchanging accumulators at the end; on the 64-row latency tile two accumulator sets per wave).  Both tile shapes must give the SAME
+    bits, so that a row's value does not depend on how many rows travel with it (few-rows rule, tail split, batch 1 vs batch 16)."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    D = 1152
+    a, w = _r((M, K), dt, 1.0, 61), _r((D, K), dt, 0.04, 62)
+    bias = _r((D,), torch.float32, 0.3, 63)
+    outs = {}
+    for kernel in ("tile144", "latency64"):
+        if epi == 3:
+            h = _r((M, D), dt, 1.0, 64)
+            table = _r((D,), torch.float32, 1.0, 65)
+            cache = torch.zeros((M, D), dtype=dt, device="cuda")
+            eng.op_gemm_ex(kernel, site, 3, a, w, bias, resid=h, gate_table=table, rows_per_batch=256, out=cache)
+            outs[kernel] = (cache.clone(), h.clone())
+        else:
+            outs[kernel] = (eng.op_gemm_ex(kernel, site, epi, a, w, bias).clone(),)
+    for x, y in zip(outs["tile144"], outs["latency64"]):
+        assert torch.equal(x, y)
 
 
 def test_gemm_asymmetric_identity():
@@ -378,27 +402,22 @@ def test_cross_attention_masked(T):
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
-@pytest.mark.parametrize("N,mode", [(256, "dma"), (1024, "dma"), (1024, "dma4"), (2048, "dma4")])
-def test_self_attention_lds_dma_kernel_is_the_same_arithmetic(monkeypatch, dtype_name, N, mode):
-    """attention_dma.h (opt-in, ECAD_ATTN=dma): K / V chunks by LDS-DMA into a double-buffered image whose pads -- zeros and the ones column -- are written once
-    and never touched again because pad lanes are switched off.  Same fragment layouts and operation order as attention128.h: bit-identical outputs, N = 1024
-    runs eight chunks through both images with a late dominant key tile (running-maximum rescale).  "dma4" = four query fragments per wave (512 query rows per work
-    item): what the engine launches for self-attention over >= 1024 tokens (Sigma-1024, alpha-512) instead of the fused tail."""
-    from ecad_amd.engine import EcadEngine
-
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_self_attention_four_fragment_kernel_is_the_same_arithmetic(dtype_name, N):
+    """attention_dma.h with four query fragments per wave (512 query rows per work item; K / V chunks by LDS-DMA into a double-buffered image whose pads -- zeros
+    and the ones column -- are written once and never touched again): what the plans launch for self-attention over >= 1024 tokens (Sigma-1024, alpha-512)
+    instead of the fused tail.  Same fragment layouts and operation order as attention128.h: bit-identical outputs, with a late dominant key tile (running-
+    maximum rescale), and both within the attention tolerance of an fp32 reference."""
     dt = getattr(torch, dtype_name)
     B, H, dh = 3, 16, 72
     D = H * dh
     qkv = _r((B * N, 3 * D), dt, 1.0, 5)
     qkv[N - 40 : N - 32, D : 2 * D] *= 5.0
-    ref_eng = small_engine(dtype_name)
-    want = ref_eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh)
-    monkeypatch.setenv("ECAD_ATTN", mode)
-    eng = EcadEngine(num_layers=1, max_batch=2, dtype=dt)
-    got = eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh)
+    eng = small_engine(dtype_name)
+    want = eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh, kernel="shared")
+    got = eng.op_attention(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh, kernel="wide4")
     assert torch.equal(got, want)
     assert within(rel_l2(got, _attn_ref(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh, None)), ATT_TOL[dtype_name])
-    eng.close()
 
 
 def test_attention_large_scores_online_softmax():

@@ -108,11 +108,7 @@ ECAD_DEV Pack8 gload16(const void* p) {
 }
 ECAD_DEV void gstore16(void* p, const Pack8& v) { *reinterpret_cast<u32x4*>(p) = v.u; }
 // cache-slot writes: read again one or more denoising steps later, never soon -- keep them out of the way of h / xn in L2 and the Infinity Cache
-#ifdef ECAD_NO_NT_STORE
-ECAD_DEV void gstore16_nt(void* p, const Pack8& v) { *reinterpret_cast<u32x4*>(p) = v.u; }
-#else
 ECAD_DEV void gstore16_nt(void* p, const Pack8& v) { __builtin_nontemporal_store(v.u, reinterpret_cast<u32x4*>(p)); }
-#endif
 
 // 4 rows x 16 cols transposed LDS read (gfx950 ds_read_b64_tr_b16): lane 4q+p of a 16-lane group supplies
 // the address of row q, cols 4p..4p+3; lane i receives column i of the 4 rows.  EXEC must be all ones.

@@ -46,9 +46,6 @@ enum KClass {
   KC_GEMM_QKV = 0, KC_GEMM_OUT1, KC_GEMM_Q2, KC_GEMM_OUT2, KC_GEMM_FF1, KC_GEMM_FF2, KC_GEMM_TEXTKV, KC_GEMM_CAPTION,
   KC_GEMM_SMALL, KC_GEMM_KV1, KC_ATTN_SELF, KC_ATTN_CROSS, KC_LN, KC_CACHE_REPLAY, KC_PATCH, KC_MISC, KC_QUANT, KC_CACHE_HIT_STEP, KC_COUNT
 };
-// Summation order over K of a GEMM call site (gemm3s.h): the wide call sites run their big launches on gemm2w.h (one accumulator per output, K in order), so
-// their 256 x 144 / latency-tile fallbacks sum the same way; every other site sums the even and the odd 32-deep K blocks separately (split-K wave layout).
-constexpr bool eo_site(int tag) { return !(tag == KC_GEMM_FF1 || tag == KC_GEMM_TEXTKV || tag == KC_GEMM_SMALL || tag == KC_GEMM_KV1); }
 static const char* kclass_names[KC_COUNT] = {
     "gemm_qkv", "gemm_attn1_out", "gemm_attn2_q", "gemm_attn2_out", "gemm_ff1_gelu", "gemm_ff2", "gemm_text_kv", "gemm_caption",
     "gemm_small", "gemm_attn1_kv_wide", "attn_self", "attn_cross", "ln_modulate", "cache_replay", "patch_embed", "misc", "fp8_quant_rows", "cache_hit_step"};
@@ -1235,16 +1232,15 @@ template <typename T> class EngineT : public EngineBase {
   bool few_rows(const GemmArgs<T>& g) const { return latency_tiles && g.N % G3_BN == 0 && ((rows_of(g) + G3_BM - 1) / G3_BM) * (g.N / G3_BN) * in_flight * 100 <= num_cus * latency_fill; }
   template <int EPI, int TAG> int launch_quarter(const GemmArgs<T>& g, hipStream_t s) {
     if (!g3q_attr[EPI][TAG]) {
-      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
       g3q_attr[EPI][TAG] = true;
     }
     const int tq = ((rows_of(g) + G3Q_BM - 1) / G3Q_BM) * (g.N / G3_BN);
-    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>), dim3(tq), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3(tq), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
     return ECAD_OK;
   }
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
-    // (the split-K wave layout of the even / odd call sites is written for an even count >= 4 of 64-deep K-steps -- every K of the model; other K take the latency tile: same order)
-    if (gemm_impl_cls[TAG] == 5 || few_rows(g) || (eo_site(TAG) && (g.K % 128 != 0 || g.K < 256))) return launch_quarter<EPI, TAG>(g, s);
+    if (gemm_impl_cls[TAG] == 5 || few_rows(g)) return launch_quarter<EPI, TAG>(g, s);
     if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
       // wide 256x288 tiles -- unless they would leave half the chip idle (FF1 at batch 4-7 alone on the GPU: 128-224 tiles): then the 256x144 tiles below, twice as many
       const bool wide_underfills = g.N % G3_BN == 0 && ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN) * in_flight * 2 <= num_cus;
@@ -1262,11 +1258,11 @@ template <typename T> class EngineT : public EngineBase {
     }
     if (gemm_impl_cls[TAG] == 0 || (gemm_impl_cls[TAG] == 2 && g.N % G3_BN == 0)) {  // (2: a wide call site whose wide tiles would underfill the chip)
       if (!g3_attr[EPI][TAG]) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
         g3_attr[EPI][TAG] = true;
       }
       const int tiles3 = ((rows_of(g) + G3_BM - 1) / G3_BM) * (g.N / G3_BN);
-      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
       return ECAD_OK;
     }
     return fail(ECAD_E_INVALID, "no GEMM kernel selected for call site %d (implementation id %d)", TAG, gemm_impl_cls[TAG]);
@@ -1277,20 +1273,20 @@ template <typename T> class EngineT : public EngineBase {
     if (g.N % G3_BN || g.rows_per_batch % G3_BM || g.M % G3_BM || DH != 72 || !g.att_k || !g.att_v || !g.att_out || g.att_nk < 1 || g.att_ldo % 4 || g.att_ldk % 8)
       return fail(ECAD_E_UNSUPPORTED, "fused attention needs 256-row tiles inside one sample and head_dim 72");
     if (EPI == EPI_BIAS_ATTN && g.att_nk % G3A_KC) return fail(ECAD_E_UNSUPPORTED, "fused self-attention needs a key count that is a multiple of 128");
-    if (gemm_impl_cls[TAG] == 5 || few_rows(g) || g.K % 128 != 0 || g.K < 256) {  // few rows: 64 query rows x two heads per workgroup, four times the workgroups (the same arithmetic per row)
+    if (gemm_impl_cls[TAG] == 5 || few_rows(g)) {  // few rows: 64 query rows x two heads per workgroup, four times the workgroups (the same arithmetic per row)
       if (!g3qa_attr[EPI - EPI_BIAS_ATTN]) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
         g3qa_attr[EPI - EPI_BIAS_ATTN] = true;
       }
-      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES, eo_site(TAG)>), dim3((rows_of(g) / G3Q_BM) * (g.N / G3_BN)), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
+      hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3((rows_of(g) / G3Q_BM) * (g.N / G3_BN)), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
       return ECAD_OK;
     }
     if (!g3a_attr[EPI - EPI_BIAS_ATTN]) {
-      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
       g3a_attr[EPI - EPI_BIAS_ATTN] = true;
     }
     const int tiles3 = (rows_of(g) / G3_BM) * (g.N / G3_BN);
-    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3_BM, G3_NW, G3_STAGES, eo_site(TAG)>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG>), dim3(tiles3), dim3(G3_NW * 64), G3_LDS_BYTES, s, g);
     return ECAD_OK;
   }
   // Tail split (round 3): a launch of w whole rounds of 256-row tiles plus a last round that would leave at least half the CUs idle (batch 100:

@@ -47,21 +47,9 @@ constexpr int G3Q_BM = 64, G3Q_NW = 4, G3Q_STAGES = 3;
 constexpr int G3Q_LDS_BYTES = G3Q_STAGES * (G3Q_BM + G3_BN) * 128;  // 79 872
 static_assert(2 * G3Q_LDS_BYTES <= 160 * 1024, "two latency-tile workgroups per CU");
 
-// Two summation orders over K, chosen per call site by EO_ (engine.hip: eo_site) -- every kernel a call site can be routed to (256-row tile, 64-row latency tile,
-// tail split) uses the same one, so a row's value never depends on the batch it arrives in:
-//   EO_ = false: one accumulator per output, K in order (the wide call sites, whose big launches run on gemm2w.h).
-//   EO_ = true:  out = (sum over the EVEN 32-deep K blocks) + (sum over the ODD ones), each in order.  On the 256-row tile that is a split-K WAVE LAYOUT (round 4):
-//                8 waves = 4 (M) x 2 (K halves of every 64-deep stage), a wave owns 64 rows x 144 columns x its 32-deep half: 13 fragment reads per 36 MFMAs
-//                instead of the 22 of the 32 x 144 wave tile (the K loop of that layout sat at 58-65 % of the MFMA rate, LDS reads and DMA writes filling ~100 %
-//                of the LDS cycles at the ideal rate; stamped 1774-2001 cycles per K-step against 1152).  After the loop the waves of a pair (r, r ^ 1) exchange
-//                the halves of their 64 rows through LDS, and wave r continues with rows [32 r, 32 r + 32) -- exactly the old wave tile, so every epilogue below
-//                (plain, read-modify-write + LayerNorm statistics, attention tail) is unchanged.  On the 64-row latency tile: two accumulator sets per wave.
-template <typename T, int EPI, int TAG, int BM_ = G3_BM, int NW_ = G3_NW, int STAGES_ = G3_STAGES, bool EO_ = false>
+template <typename T, int EPI, int TAG, int BM_ = G3_BM, int NW_ = G3_NW, int STAGES_ = G3_STAGES>
 __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p) {  // two waves per SIMD either way: 8 of one workgroup, or 4 + 4 of two
   constexpr int BM = BM_, BN = G3_BN, NWAVES = NW_, NSTG = STAGES_;
-  constexpr bool KS = EO_ && BM_ == 256 && NW_ == 8;  // split-K wave layout
-  constexpr bool EO2 = EO_ && !KS;                     // even / odd accumulator sets inside one wave
-  static_assert(!KS || STAGES_ == 3, "the split-K layout runs on the 3-stage ring");
   constexpr int WTM = BM / NWAVES;
   constexpr int FM = WTM / 16, FN = BN / 16;
   static_assert((FM == 1 || FM == 2) && FN == 9 && (NSTG == 2 || NSTG == 3), "wave tile 32 x 144 or 16 x 144");
@@ -200,8 +188,8 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       if (p.gate_mod) gmod = gload16(p.gate_mod + (size_t)(m0 / p.rows_per_batch) * p.gate_mod_stride + n);
     }
   };
-  const bool resid_in_loop = !KS && nk >= 3;
-  if (!resid_in_loop && !KS) prefetch_resid();
+  const bool resid_in_tail = nk >= 3;
+  if (!resid_in_tail) prefetch_resid();
   // All FN bias vectors of this lane in ONE batch of loads: hipcc otherwise emits load -> s_waitcnt vmcnt(0) -> use per column group, nine
   // serialized L2 / HBM latencies at the tail of the tile (stamped: 7.4k cycles of epilogue with the global stores ablated, 5.0k batched).
   // Plain epilogues (registers to spare) fetch them two K-steps before the end, so not even one latency is left; the residual epilogue
@@ -214,14 +202,13 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * g);
     }
   };
-  const bool bias_in_loop = !KS && EPI != EPI_BIAS_CACHE_RESID && nk >= 2;
+  const bool bias_in_loop = EPI != EPI_BIAS_CACHE_RESID && nk >= 2;
   int stage = 0;
   // top of K-step kt: stage kt has landed when at most the newest stage's DMA (A_INST + 2 = 6 per wave) is outstanding; in the step after the
   // residual prefetch went out behind that DMA its NCH loads are newer still, so they may be outstanding as well
   auto step_top = [&](int kt) {
     // 2-stage ring: the stage of this step is the newest thing in flight (it was issued during the previous step): everything must have landed
     if (NSTG == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (EPI == EPI_BIAS_CACHE_RESID && resid_in_loop && kt == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW + NCH) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -230,153 +217,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #endif
   };
   constexpr int NPIECE = A_INST + B_INST_MAX;  // LDS-DMA slots of a wave per stage: 7 (the last one only on the waves that own an 18th W piece)
-  if constexpr (KS) {
-    // ---------------------------------------------------------------------------------------------------------------------------------------------
-    // split-K wave layout: wave r = (row block r >> 1, K half r & 1) owns 64 rows x 144 columns of the 32-deep half (r & 1) of every stage.
-    // Per K-step and wave: 13 fragment reads, 36 MFMAs.  The MFMAs of the last PN weight columns are issued behind the NEXT barrier (work for the matrix pipe
-    // while the barrier resolves and the new fragments travel); the fragments ping-pong between two register sets (no copies), so the loop body exists
-    // twice.  LDS-DMA pieces: one per group of 2 MFMAs, waves 0-3 in the first half of the step, waves 4-7 (their SIMD partners) in the second.
-    constexpr int KM = 4, PN = 2;
-    const int wmk = wave >> 1, wkk = wave & 1;
-    f32x4 acck[KM][FN];
-#pragma unroll
-    for (int i = 0; i < KM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acck[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // fragment index i = 0, 1: the 32 rows this wave KEEPS in the epilogue (rows 64 wmk + 32 wkk + 16 i = [32 wave, 32 wave + 32)); i = 2, 3: the 32 rows it hands to
-    // its partner (wave ^ 1) -- so the exchange below moves acck[2 .. 3] and adds into acck[0 .. 1] for every wave, no branch, no register shuffle
-    const unsigned kcol = (unsigned)(((wkk * 4 + g) ^ swz) * 16);
-    const unsigned ka_keep = (unsigned)(size_t)0 + (unsigned)((wmk * 64 + wkk * 32 + l15) * 128) + kcol;
-    const unsigned ka_send = (unsigned)((wmk * 64 + (1 - wkk) * 32 + l15) * 128) + kcol;
-    const unsigned kb_off = (unsigned)(A_BYTES + l15 * 128) + kcol;
-    const unsigned smem_base = (unsigned)(size_t)smem;  // LDS byte address of the dynamic segment (0 for a kernel without static LDS; kept general)
-    u32x4 fa[2][KM], fw[2][FN];
-    // Fragment reads as inline asm: hipcc waits lgkmcnt(0) at the first use of ANY of the 13 results (the uniform branches around the LDS-DMA issues end its counting),
-    // i.e. the 28 MFMAs of a step's own columns would wait for the last read.  Here column j waits for exactly the reads it needs (A x 4, W 0 .. j): the counted waits sit
-    // in ks_step, each followed by a scheduling barrier (the compiler otherwise moves register-only MFMAs across an asm wait).
-#define KS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-    auto ks_read = [&](u32x4 (&A)[KM], u32x4 (&W)[FN], int stg) {  // (the arrays as parameters: an asm operand alone does not make a generic lambda capture them)
-      const unsigned sb = smem_base + (unsigned)(stg * STAGE_BYTES);
-      const unsigned a0 = sb + ka_keep, a1 = sb + ka_send, b0 = sb + kb_off;
-      static_assert(FN == 9 && KM == 4, "four row fragments, nine weight fragments");
-      KS_READ(A[0], a0, 0); KS_READ(A[1], a0, 2048); KS_READ(A[2], a1, 0); KS_READ(A[3], a1, 2048);
-      KS_READ(W[0], b0, 0); KS_READ(W[1], b0, 2048); KS_READ(W[2], b0, 4096); KS_READ(W[3], b0, 6144); KS_READ(W[4], b0, 8192);
-      KS_READ(W[5], b0, 10240); KS_READ(W[6], b0, 12288); KS_READ(W[7], b0, 14336); KS_READ(W[8], b0, 16384);
-    };
-#undef KS_READ
-    auto ks_pack = [](const u32x4& v) { Pack8 r; r.u = v; return r; };
-    // MFMA number q (0 .. 35) of a step in phase PH: the carried columns of the OTHER register set first, then this step's columns 0 .. FN - PN - 1
-    auto ks_mfma = [&](auto phc, auto qc) {
-      constexpr int PH = decltype(phc)::value, q = decltype(qc)::value;
-      if constexpr (q < KM * PN) {
-        constexpr int j = FN - PN + q / KM, i = q % KM;
-        acck[i][j] = mfma16<T>(ks_pack(fw[PH ^ 1][j]), ks_pack(fa[PH ^ 1][i]), acck[i][j]);
-      } else {
-        constexpr int j = (q - KM * PN) / KM, i = q % KM;
-        acck[i][j] = mfma16<T>(ks_pack(fw[PH][j]), ks_pack(fa[PH][i]), acck[i][j]);
-      }
-    };
-    // before MFMA q: the reads its operands came from have landed.  Of the 13 reads of the step (A 0 .. 3, W 0 .. 8, in that order) column j needs the first 5 + j.
-    auto ks_wait = [&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      if constexpr (q >= KM * PN && (q - KM * PN) % KM == 0) {
-        constexpr int j = (q - KM * PN) / KM;
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FN - 1 - j) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    // MODE 0: the first step (nothing carried in; its pieces go out in one block while the fragments travel); 1: staggered (a stage is still to be fetched);
-    // 2: one of the last two steps (nothing left to fetch)
-    auto ks_step = [&](auto phc, auto modec, int kt) {
-      constexpr int MODE = decltype(modec)::value;
-      step_top(kt);  // (its lgkmcnt(0) retires the two reads of the previous step that no MFMA of that step waited for: the carried columns)
-      ks_read(fa[decltype(phc)::value], fw[decltype(phc)::value], stage);
-      __builtin_amdgcn_sched_barrier(0);
-      int ns = stage + NSTG - 1;
-      ns = ns >= NSTG ? ns - NSTG : ns;
-      if constexpr (MODE == 0) {
-        if (kt + NSTG - 1 < nk) issue(ns);
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<KM*(FN - PN)>([&](auto qc) {
-          constexpr int q = KM * PN + decltype(qc)::value;
-          ks_wait(std::integral_constant<int, q>{});
-          ks_mfma(phc, std::integral_constant<int, q>{});
-        });
-      } else if constexpr (MODE == 2) {
-        static_for<KM * FN>([&](auto qc) { ks_wait(qc); ks_mfma(phc, qc); });
-      } else {
-        const bool early = wave < NWAVES / 2;
-        constexpr int GROUPS = KM * FN / 2;  // 18 groups of 2 MFMAs
-        static_for<GROUPS>([&](auto gc) {
-          constexpr int gi = decltype(gc)::value;
-          if constexpr (gi < NPIECE) { if (early) issue_one(ns, gc); }
-          if constexpr (gi >= GROUPS / 2 && gi - GROUPS / 2 < NPIECE) { if (!early) issue_one(ns, std::integral_constant<int, gi - GROUPS / 2>{}); }
-          ks_wait(std::integral_constant<int, 2 * gi>{});
-          ks_mfma(phc, std::integral_constant<int, 2 * gi>{});
-          ks_mfma(phc, std::integral_constant<int, 2 * gi + 1>{});
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        advance_src();
-      }
-      stage = stage + 1 >= NSTG ? 0 : stage + 1;
-    };
-    constexpr std::integral_constant<int, 0> P0{};
-    constexpr std::integral_constant<int, 1> P1{};
-    constexpr std::integral_constant<int, 2> M2{};
-    // step kt runs in phase kt & 1.  The step count is even and >= 4 here (launch_pg sends other K to the latency-tile kernel, which sums in the same order):
-    // step 0, the staggered steps 1 .. nk - 3 (in pairs + one), the two last steps, the carried columns of the last one -- straight-line code around one loop.
-    ks_step(P0, P0, 0);
-    int kt = 1;
-    for (; kt + 1 <= nk - 3; kt += 2) {
-      ks_step(P1, P1, kt);
-      ks_step(P0, P1, kt + 1);
-    }
-    ks_step(P1, P1, kt);
-    ks_step(P0, M2, kt + 1);
-    ks_step(P1, M2, kt + 2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<KM * PN>([&](auto qc) { ks_mfma(P0, qc); });  // the columns carried out of the last step (phase 1): issued as the "carried in" of a phase-0 step
-#ifdef G_STAMP
-    st_c2 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- exchange: this wave keeps acck[0 .. 1] (its epilogue rows [32 wave, +32)) and receives the other K half of them from wave ^ 1, to which it hands
-    // acck[2 .. 3]; out = even half + odd half (the sum is the same on both sides: a + b == b + a).  72 accumulator registers per lane each way, as 16-byte pieces
-    // [piece][lane]: 18 432 bytes per wave, 147 456 in all, inside the operand ring.
-    __builtin_amdgcn_s_barrier();  // every wave has read its last fragments: the ring is free
-    {
-      f32x4* mine = reinterpret_cast<f32x4*>(smem + wave * (2 * FN * 64 * 16)) + lane;
-      const f32x4* theirs = reinterpret_cast<const f32x4*>(smem + (wave ^ 1) * (2 * FN * 64 * 16)) + lane;
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) mine[(ii * FN + j) * 64] = acck[2 + ii][j];
-      __builtin_amdgcn_sched_barrier(0);
-      // residual / gate / bias loads of this wave's epilogue rows now (72 registers have just been freed): in flight during the rest of the exchange
-      prefetch_resid();
-      load_bias();
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[ii][j] = acck[ii][j] + theirs[(ii * FN + j) * 64];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // the exchange buffers have been read: the epilogues below may write their C tile / Q tile over them
-    }
-  } else {
   // second fragment set of a step consumed after the NEXT step's barrier: the matrix pipe has a full group to chew on while the barrier
   // resolves and the new stage's first fragments travel from LDS (11 more live fragment registers: fits this kernel's 72 accumulators;
   // 244 VGPRs, no spills).  In-run A/B: Q -2.7 %, attn1-out -3.7 %, attn2-out -3.2 %, cross-Q -3.0 %.
-  // EO2 (latency tile of an even / odd call site): the first set of every step accumulates into acc, the second into acc_odd; summed behind the loop.
-  f32x4 acc_odd[EO2 ? FM : 1][EO2 ? FN : 1];
-  if constexpr (EO2) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc_odd[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
   Pack8 afp[FM], wfp[FN];
   auto read_set = [&](Pack8 (&af)[FM], Pack8 (&wf)[FN], int stg, int half) {
     const char* abase = smem + stg * STAGE_BYTES;
@@ -387,19 +230,12 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #pragma unroll
     for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 16 * 128 + coff);
   };
-  // `second`: the operands are a step's second (odd) 32-deep block
-  auto mfma_one = [&](const Pack8& w, const Pack8& a, auto ic, auto jc, bool second) {
-    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-    if constexpr (EO2) {
-      if (second) acc_odd[i][j] = mfma16<T>(w, a, acc_odd[i][j]);
-      else acc[i][j] = mfma16<T>(w, a, acc[i][j]);
-    } else {
-      acc[i][j] = mfma16<T>(w, a, acc[i][j]);
-    }
-  };
-  auto mfma_all = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM], bool second) {
+  auto mfma_all = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM]) {
     static_for<FN>([&](auto jc) {
-      static_for<FM>([&](auto ic) { mfma_one(wf[decltype(jc)::value], af[decltype(ic)::value], ic, jc, second); });
+      static_for<FM>([&](auto ic) {
+        constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
+        acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
+      });
     });
   };
   // Block schedule (round 1; also the first and the last two K-steps of the staggered schedule): every wave issues its pieces in one block
@@ -413,13 +249,13 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       ns = ns >= NSTG ? ns - NSTG : ns;
       issue(ns);
     }
-    if (resid_in_loop && kt == 1) prefetch_resid();
+    if (resid_in_tail && kt == nk - 2) prefetch_resid();
     if (bias_in_loop && kt == nk - 2) load_bias();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt > 0) mfma_all(wfp, afp, true);
+    if (kt > 0) mfma_all(wfp, afp);
     __builtin_amdgcn_sched_barrier(0);
     read_set(afp, wfp, stage, 1);
-    mfma_all(wf0, af0, false);
+    mfma_all(wf0, af0);
     stage = stage + 1 >= NSTG ? 0 : stage + 1;
   };
   // Staggered schedule (K-steps 1 .. nk-3: a carried fragment set exists and a stage is still to be fetched, so the body has no conditions).
@@ -433,7 +269,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   static_assert(NMF % GROUPS == 0 && NPIECE <= GROUPS + 1, "piece / MFMA interleave");
   // both halves run the same MFMA stream (one code path: a wave-group branch around the MFMAs makes hipcc shuffle and spill the accumulators);
   // only the small DMA-issue blocks in between are conditional on the half the wave belongs to
-  auto mfma_dma = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM], int ns, bool mine, bool second) {
+  auto mfma_dma = [&](const Pack8 (&wf)[FN], const Pack8 (&af)[FM], int ns, bool mine) {
     static_for<GROUPS>([&](auto gc) {
       constexpr int gi = decltype(gc)::value;
       if constexpr (gi < NPIECE) {
@@ -445,7 +281,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       static_for<PER>([&](auto tc) {
         constexpr int idx = gi * PER + decltype(tc)::value;
         constexpr int j = idx / FM, i = idx - j * FM;
-        mfma_one(wf[j], af[i], std::integral_constant<int, i>{}, std::integral_constant<int, j>{}, second);
+        acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
       });
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -458,12 +294,11 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
     int ns = stage + NSTG - 1;
     ns = ns >= NSTG ? ns - NSTG : ns;
     const bool early = wave < NWAVES / 2;
-    mfma_dma(wfp, afp, ns, early, true);
+    mfma_dma(wfp, afp, ns, early);
     read_set(afp, wfp, stage, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_dma(wf0, af0, ns, !early, false);
+    mfma_dma(wf0, af0, ns, !early);
     advance_src();
-    if (resid_in_loop && kt == 1) prefetch_resid();
     stage = stage + 1 >= NSTG ? 0 : stage + 1;
   };
   // Measured NEGATIVE and removed (round 2): a ping-pong schedule -- every K-step as phase A (both fragment sets -> registers, DMA issue, wait) and
@@ -477,18 +312,11 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       for (; kt + 2 < nk; ++kt) step_stagger(kt);  // (a stage is still to be fetched in each of these steps for either ring depth)
     for (; kt < nk; ++kt) step_block(kt);
   }
-  mfma_all(wfp, afp, true);
-  if constexpr (EO2) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = acc[i][j] + acc_odd[i][j];  // even + odd
-  }
+  mfma_all(wfp, afp);
 #ifdef G_STAMP
   st_c2 = __builtin_amdgcn_s_memtime();
 #endif
-  }
-  if (!bias_in_loop && !KS) load_bias();
+  if (!bias_in_loop) load_bias();
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (EPI == EPI_BIAS_ATTN || EPI == EPI_BIAS_ATTN_TAIL) {  // the tile is a query projection: its attention runs here (gemm3s_attn.h)
     {
@@ -526,7 +354,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       }
     }
   }
-  const bool private_epi = KS || (NSTG == 3 && nk >= 2 && (nk - 1) % NSTG == 2 && (BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float)) <= 2 * STAGE_BYTES);  // (split-K layout: the exchange ended with a barrier)
+  const bool private_epi = NSTG == 3 && nk >= 2 && (nk - 1) % NSTG == 2 && (BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float)) <= 2 * STAGE_BYTES;
   static_assert(BM * CS * (int)sizeof(T) + NWAVES * BN * (int)sizeof(float) <= NSTG * STAGE_BYTES, "C tile + gate copies inside the ring");
   if (!private_epi) __syncthreads();
 #ifdef G_STAMP

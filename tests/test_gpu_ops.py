@@ -65,7 +65,7 @@ KERNEL_CASES = [
     ("tile144", "caption", 1, 3840, 1152, 4096),
     ("tile144", "small", 2, 40, 1152, 256),
     ("tile128", "small", 1, 1000, 1024, 512),
-    ("tile144", "attn2_q", 0, 600, 1152, 192),  # an odd count of 64-deep K-steps: the split-K wave layout hands over to the latency tile (same summation order)
+    ("tile144", "attn2_q", 0, 600, 1152, 192),  # three K-steps only: first / last-two steps of the staggered schedule with nothing in between
     # gemm3s.h latency variant: 64 x 144 tiles, four waves of 16 x 144 -- what the engine launches when a GEMM has few rows (batch 1-4)
     ("latency64", "attn2_q", 0, 512, 1152, 1152),
     ("latency64", "ff1", 1, 512, 4608, 1152),
@@ -182,9 +182,8 @@ def test_gemm_ex_refuses_instead_of_substituting():
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("site,epi,M,K", [("attn2_q", 0, 1024, 1152), ("attn1_out", 3, 512, 1152), ("ff2", 3, 768, 4608), ("caption", 1, 480, 4096)])
 def test_every_tile_shape_of_a_call_site_sums_k_in_the_same_order(dtype_name, site, epi, M, K):
-    """The N = 1152 call sites and FF2 add the even and the odd 32-deep K blocks separately (gemm3s.h: on the 256-row tile that is the split-K wave layout -- two waves
-    per 64 rows, one per K half, exchanging accumulators at the end; on the 64-row latency tile two accumulator sets per wave).  Both tile shapes must give the SAME
-    bits, so that a row's value does not depend on how many rows travel with it (few-rows rule, tail split, batch 1 vs batch 16)."""
+    """The 256-row tile and the 64-row latency tile of a call site must give the SAME bits (one accumulator per output, K in order, the same epilogue arithmetic), so
+    that a row's value does not depend on how many rows travel with it (few-rows rule, tail split, batch 1 vs batch 16)."""
     eng = small_engine(dtype_name)
     dt = getattr(torch, dtype_name)
     D = 1152

@@ -616,6 +616,24 @@ def main():
                 png_ready_in_flight(nb)
                 torch.cuda.synchronize()
                 res["png_ready_batches_in_flight_images_per_s"] = nb * batch / (time.perf_counter() - t1)
+            # the decode alone on the device (HIP events on the stream it is launched on, no host copy): its convolution GEMMs against the MFMA peak
+            lat_fixed = latents_only()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2):
+                vae.decode_to_uint8(lat_fixed)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(5):
+                vae.decode_to_uint8(lat_fixed)
+            ev1.record()
+            torch.cuda.synchronize()
+            dec_ms = ev0.elapsed_time(ev1) / 5
+            vs = vae.decode_stats()
+            res["decode_tail"] = {
+                "device_ms_per_batch": dec_ms, "conv_launches": vs["conv_launches"], "conv3s_launches": vs["conv3s_launches"], "conv_flops_per_batch": vs["conv_flops"],
+                "roofline": {"bound": "mfma", "kernel": "conv3s_kernel + conv_gemm_kernel (implicit-GEMM convolutions of the AutoencoderKL decoder; GroupNorm / SiLU / upsample time included in the denominator)",
+                             "achieved": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
+            }
             res["config"]["decode_tail_ms_per_batch"] = 1000.0 * (dt - dt_lat)  # against one batch at a time on the same context
             res["config"]["decode_tail"] = "HIP AutoencoderKL decoder (ecad_vae_decode, random-init SD-VAE geometry) -> uint8 NHWC -> host -> PIL; the reference's 84.09 ms/image (A6000) includes this tail"
             log(f"png-ready: {batch / dt:.1f} img/s")

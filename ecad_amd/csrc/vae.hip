@@ -59,6 +59,9 @@ struct VaeBase {
   virtual int load(const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim) = 0;
   virtual int finalize() = 0;
   virtual int decode(const float* lat, int B, int h, int w, float scaling, float shift, uint8_t* out, hipStream_t s) = 0;
+  // roofline accounting of the last decode: flops of its convolution GEMMs (2 M Cout taps Cin each) and how many of them ran on the 256 x 128 / 3-stage kernel
+  double conv_flops = 0;
+  int conv_launches = 0, conv3s_launches = 0;
 };
 
 template <typename T> struct VaeT : VaeBase {
@@ -212,9 +215,12 @@ template <typename T> struct VaeT : VaeBase {
     a.in = in; a.w = w_override ? w_override : W_<T>(name + ".weight"); a.bias = no_bias ? nullptr : (b_override ? b_override : W_<float>(name + ".bias"));
     a.resid = resid; a.out = out; a.zero_page = zero_page; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = taps; a.up = up;
     const int M = B * H * W;
+    conv_flops += 2.0 * M * (double)cout * taps * cin;
+    ++conv_launches;
     // 256 x 128 tiles with the 3-stage K loop (conv3s_kernel) once they fill the chip; the 128 x 128 kernel for the small launches (mid-block attention, 8 x 8 latents)
     if (!conv_tile128 && ((M + C3_BM - 1) / C3_BM) * (cout / C3_BN) >= num_cus && (taps * cin) / 64 >= 4) {
       hipLaunchKernelGGL((conv3s_kernel<T>), dim3(((M + C3_BM - 1) / C3_BM) * (cout / C3_BN)), dim3(C3_NW * 64), C3_LDS_BYTES, s, a);
+      ++conv3s_launches;
       return ECAD_OK;
     }
     const int tiles = ((M + 127) / 128) * (cout / 128);
@@ -256,6 +262,7 @@ template <typename T> struct VaeT : VaeBase {
     if (B < 1 || h < 4 || w < 4 || (h * w) % 128 || (w & 1)) return fail(ECAD_E_INVALID, "latent %dx%dx%d unsupported (h*w must be a multiple of 128, w even)", B, h, w);
     int rc = ensure_acts(B, h, w);
     if (rc) return rc;
+    conv_flops = 0; conv_launches = conv3s_launches = 0;
     T *x = bufA, *y = bufB, *t = bufC;
     int H = h, Wd = w;
     {
@@ -353,6 +360,13 @@ int ecad_vae_finalize_weights(EcadVae* v) { return v ? v->impl->finalize() : ECA
 int ecad_vae_decode(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, uint8_t* out_u8_dev, void* stream) {
   if (!v || !latents_dev || !out_u8_dev) return ECAD_E_INVALID;
   return v->impl->decode(latents_dev, B, h, w, scaling_factor, 0.f, out_u8_dev, (hipStream_t)stream);
+}
+int ecad_vae_decode_stats(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches) {
+  if (!v) return ECAD_E_INVALID;
+  if (conv_flops) *conv_flops = v->impl->conv_flops;
+  if (conv_launches) *conv_launches = v->impl->conv_launches;
+  if (conv3s_launches) *conv3s_launches = v->impl->conv3s_launches;
+  return ECAD_OK;
 }
 int ecad_vae_decode_ex(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, float shift_factor, uint8_t* out_u8_dev, void* stream) {
   if (!v || !latents_dev || !out_u8_dev) return ECAD_E_INVALID;

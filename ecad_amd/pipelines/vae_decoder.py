@@ -118,6 +118,13 @@ class HipVaeDecoder:
         c = module.config
         return cls(c.scaling_factor, dtype, device, c.latent_channels, getattr(c, "use_post_quant_conv", True), getattr(c, "shift_factor", 0.0) or 0.0).load_state_dict(module.state_dict())
 
+    def decode_stats(self) -> dict:
+        """Roofline accounting of the last decode: flops of its convolution GEMMs, their launch count, how many ran on the 256 x 128 / 3-stage kernel."""
+        C = self._C
+        fl, n, n3 = C.c_double(0), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.ecad_vae_decode_stats(self._h, C.byref(fl), C.byref(n), C.byref(n3)))
+        return {"conv_flops": fl.value, "conv_launches": n.value, "conv3s_launches": n3.value}
+
     def decode_to_uint8(self, latents: torch.Tensor, stream=None) -> torch.Tensor:
         """latents: [B, latent_channels, h, w] (un-scaled pipeline latents) -> uint8 [B, 8h, 8w, 3] on the device."""
         lat = latents.to(device=torch.device("cuda", self.device_index), dtype=torch.float32).contiguous()

@@ -256,6 +256,9 @@ int ecad_vae_decode(EcadVae* v, const float* latents_dev, int B, int h, int w, f
  * from ecad/image_generators/flux_image_generator.py:330-360): latent_channels 4 or 16. */
 int ecad_vae_create_ex(int device, int dtype, int latent_channels, int use_post_quant_conv, EcadVae** out);
 int ecad_vae_decode_ex(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, float shift_factor, uint8_t* out_u8_dev, void* stream);
+/* Roofline accounting of the last ecad_vae_decode*: flops of its convolution GEMMs (2 M Cout taps Cin per launch: the implicit-GEMM view of the 3x3 / 1x1
+ * convolutions behind vae.decode, pass_through.py:382-396), their launch count, and how many ran on the 256 x 128 / 3-stage kernel (any pointer may be NULL). */
+int ecad_vae_decode_stats(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // build (one binary per set of experiment macros):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DG_STAMP [-D...] scripts/probe_gemm3s.hip -o build_tmp/probe_gemm3s[_x]
 // run on the GPU box: build_tmp/probe_gemm3s [reps]
+// (Round 4: streams created with hipExtStreamCreateWithCUMask -- each owning a share of every XCD's CUs -- HUNG the first launch on this pool; not pursued.)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

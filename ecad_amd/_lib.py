@@ -129,6 +129,7 @@ SIGNATURES = {
     "ecad_set_attention_bias": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ecad_set_schedule": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),
     "ecad_begin_image_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
+    "ecad_rebind_batch_inputs": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ecad_step": (_I, [_P, _I, _P, _P, _P, _P]),
     "ecad_run_schedule": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, _I, _P]),
     "ecad_reset_cache": (_I, [_P]),

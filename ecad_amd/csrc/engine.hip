@@ -74,7 +74,7 @@ struct EngineBase {
   virtual int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt) = 0;
   virtual int set_attention_bias(const float* self_bias, const float* enc_bias, int Bt, int N, int T, hipStream_t st) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
-  virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st) = 0;
+  virtual int begin_batch(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, hipStream_t st, bool keep_caches = false) = 0;
   virtual int step(int step_idx, const void* latents, const float* timestep, void* out, hipStream_t st) = 0;
   virtual int run_schedule(int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, float* latents, const float* ts, const float* coef,
                            float guidance, int use_graph, hipStream_t st) = 0;
@@ -237,8 +237,8 @@ template <typename T> class EngineT : public EngineBase {
   size_t plan_lru_cap = 4;
   std::string cur_key;
   int plan_builds = 0, graph_captures = 0;
-  // ---- ecad_step: which cache slots hold a usable value RIGHT NOW (reset by begin_image_batch / reset_cache; a slot whose write the static plan
-  // skipped as dead counts as unusable).  A step whose "flag or no usable cache" set differs from the static resolution runs an ad-hoc plan.
+  // ---- ecad_step: which cache slots hold a usable value RIGHT NOW (reset by begin_image_batch / reset_cache; the step plans keep every cache write --
+  // dead-write elimination is the whole-loop plan's alone).  A step whose "flag or no usable cache" set differs from the static resolution runs an ad-hoc plan.
   std::vector<uint8_t> valid_rt;
   SrcDesc* desc_dyn_dev = nullptr;
   size_t desc_dyn_cap = 0, desc_dyn_pos = 0;
@@ -887,7 +887,9 @@ template <typename T> class EngineT : public EngineBase {
   // `ex_rt` (ecad_step only): the components that execute in THIS call, overriding the static resolution (all cache writes are then kept)
   void emit_transformer(std::vector<Op<T>>& ops, int s, const T* mod_s, int64_t mstride, const T* emb_s, int64_t estride, bool bind_call, const uint8_t* ex_rt = nullptr) {
     const int M = Bt * N, Mt = Bt * Tt;
-    auto live = [&](int b, int c) { return ex_rt ? true : cache_write_live(s, b, c); };
+    // dead-write elimination belongs to the whole-loop plan, whose steps run in order by construction; ecad_step keeps every write: its caller may step out of
+    // order or repeat a step, and the reference's caches are then as warm as the last forward left them (cached_transformer_block.py:355-360)
+    auto live = [&](int b, int c) { return (ex_rt || bind_call) ? true : cache_write_live(s, b, c); };
     // a component routed to the user's compute plug-in (step plans only): its input lands in io_in, the callback fills io_out with the
     // sub-layer output, which then joins the pending gated sums exactly like a cached tensor would (gate applied by the engine, :243-246)
     auto custom = [&](int b, int c) { return bind_call && any_custom && custom_mask[(size_t)b * 3 + c]; };
@@ -1529,9 +1531,11 @@ template <typename T> class EngineT : public EngineBase {
     return ECAD_OK;
   }
 
-  int begin_batch(int Bt_, int H_, int W_, const void* enc, const uint8_t* mask, int T_, hipStream_t s) override {
+  int begin_batch(int Bt_, int H_, int W_, const void* enc, const uint8_t* mask, int T_, hipStream_t s, bool keep_caches) override {
     HIPCHK(hipSetDevice(dev));
     if (!enc) return fail(ECAD_E_INVALID, "enc_dev is NULL");
+    if (keep_caches && (!batch_begun || !plan_valid || Bt_ != Bt || H_ != Hl || W_ != Wl || T_ != Tt))
+      return fail(ECAD_E_NOT_READY, "ecad_rebind_batch_inputs: no batch of that geometry has begun");
     int rc = ensure_shapes(Bt_, H_, W_, T_);
     if (rc) return rc;
     if (cfg.use_additional_conditions && cond_bt != Bt_)
@@ -1541,7 +1545,7 @@ template <typename T> class EngineT : public EngineBase {
     rc = run_ops(plan_begin, s, 0.f, true);
     if (rc) return rc;
     batch_begun = true;
-    std::fill(valid_rt.begin(), valid_rt.end(), 0);  // caches dropped: reset_cache (:155-158)
+    if (!keep_caches) std::fill(valid_rt.begin(), valid_rt.end(), 0);  // caches dropped: reset_cache (:155-158)
     return ECAD_OK;
   }
 
@@ -1565,7 +1569,7 @@ template <typename T> class EngineT : public EngineBase {
       int rc = run_ops(plan_step[step_idx], s, 0.f, true);
       if (rc) return rc;
       for (int i = 0; i < L * 3; ++i)
-        if (ex[i]) valid_rt[i] = cache_write_live(step_idx, i / 3, i % 3);  // a write skipped as dead leaves nothing usable behind
+        if (ex[i]) valid_rt[i] = 1;
       return ECAD_OK;
     }
     // the caller reset the caches mid-run (or stepped out of order): lower this one step from the live cache state
@@ -1937,6 +1941,7 @@ int ecad_set_added_cond(EcadEngine* e, const float* resolution, const float* asp
 int ecad_set_attention_bias(EcadEngine* e, const float* self_bias_dev, const float* enc_bias_dev, int Bt, int N, int T, void* stream) { ENG(e); return E->set_attention_bias(self_bias_dev, enc_bias_dev, Bt, N, T, (hipStream_t)stream); }
 int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks) { ENG(e); if (!bits) return E->fail(ECAD_E_INVALID, "NULL bits"); return E->set_schedule(bits, steps, blocks); }
 int ecad_begin_image_batch(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, void* stream) { ENG(e); return E->begin_batch(Bt, H, W, enc, mask, T, (hipStream_t)stream); }
+int ecad_rebind_batch_inputs(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, void* stream) { ENG(e); return E->begin_batch(Bt, H, W, enc, mask, T, (hipStream_t)stream, true); }
 int ecad_step(EcadEngine* e, int step_idx, const void* lat, const float* ts, void* out, void* stream) { ENG(e); return E->step(step_idx, lat, ts, out, (hipStream_t)stream); }
 int ecad_run_schedule(EcadEngine* e, int Bt, int H, int W, const void* enc, const uint8_t* mask, int T, float* latents, const float* ts, const float* coef, float guidance, int use_graph, void* stream) {
   ENG(e); return E->run_schedule(Bt, H, W, enc, mask, T, latents, ts, coef, guidance, use_graph, (hipStream_t)stream);

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     // step have half a step to land before the vmcnt(0) at the next barrier -- wide K,V 44.6 -> 49.2 us, FF1 92.6 -> 100.8 us.  The block
     // schedule stays the default here; the staggered one is what gemm3s.h (3 stages) runs (-DG2_STAGGER_AB compiles it in here).
 #ifdef G2_STAGGER_AB
-    if (p.variant == 2)
+    if (p.variant == 2 || G2_STAGGER_AB == 2)
       for (; kt + 1 < nk; ++kt) step_stagger(kt);
 #endif
     for (; kt < nk; ++kt) step_block(kt);

@@ -193,6 +193,13 @@ class EcadEngine:
         self._keep = (enc, mask)
         self._chk(self.lib.ecad_begin_image_batch(self._h, Bt, height, width, enc.data_ptr(), _ptr(mask), T, _stream_ptr(stream)))
 
+    def rebind_batch_inputs(self, enc: torch.Tensor, mask: torch.Tensor | None, height: int, width: int, stream=None) -> None:
+        """``begin_image_batch`` for new input tensors of the batch that has begun, leaving the block caches as they are (``ecad_rebind_batch_inputs``)."""
+        enc, mask = self._prep_enc(enc, mask)
+        Bt, T, _ = enc.shape
+        self._keep = (enc, mask)
+        self._chk(self.lib.ecad_rebind_batch_inputs(self._h, Bt, height, width, enc.data_ptr(), _ptr(mask), T, _stream_ptr(stream)))
+
     def step(self, step_idx: int, latents: torch.Tensor, timestep: torch.Tensor, stream=None) -> torch.Tensor:
         latents = latents.to(device=self.device, dtype=self.dtype).contiguous()
         Bt = latents.shape[0]

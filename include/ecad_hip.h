@@ -148,6 +148,10 @@ int ecad_set_schedule(EcadEngine* e, const uint8_t* bits, int steps, int blocks)
  * cross-attention K/V of the text.  enc_dev: [Bt, T, caption_channels] engine dtype;
  * mask_dev: [Bt, T] uint8 (1 keep / 0 discard), NULL = all keep.  H, W: latent height/width. */
 int ecad_begin_image_batch(EcadEngine* e, int Bt, int H, int W, const void* enc_dev, const uint8_t* mask_dev, int T, void* stream);
+/* The same step-invariant work (caption projection, text K/V, mask bias) recomputed from new input tensors WITHOUT touching the block caches: the reference's
+ * forward takes encoder_hidden_states / encoder_attention_mask at every step and never looks at the caches when they change (they are dropped only by
+ * reset_cache, image_generator.py:193-202).  For a batch that has begun with the same geometry (ECAD_E_NOT_READY otherwise). */
+int ecad_rebind_batch_inputs(EcadEngine* e, int Bt, int H, int W, const void* enc_dev, const uint8_t* mask_dev, int T, void* stream);
 
 /* One noise prediction == PixArtTransformer2DEdited.forward (:160-253) at schedule row `step_idx`.
  * latents_dev: [Bt, C, H, W] engine dtype; timestep_dev: [Bt] float32; out: [Bt, out_channels, H, W]

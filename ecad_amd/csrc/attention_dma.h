@@ -35,19 +35,22 @@
 
 namespace ecad {
 
-// Timing-only ablations for scripts/probe_attention.hip (never defined in the product build; results are wrong by design): bit 0 no exponential, 1 one K fragment
+// Timing-only ablations for scripts/probe_attention.hip (honoured only under -DECAD_DIAG, which the product library cannot be built with; results are wrong by design): bit 0 no exponential, 1 one K fragment
 // read per K-step instead of four, 2 one V fragment read per 32 keys instead of ND, 3 no DMA after the first chunk, 4 no S MFMAs, 5 no PV MFMAs, 6 no barrier.
-#ifndef ATT_ABL
+#if !defined(ECAD_DIAG) || !defined(ATT_ABL)
+#undef ATT_ABL
 #define ATT_ABL 0
 #endif
 // Probe switch (scripts/probe_attention.hip): ATT_KSWZ -- d_h 128 K image in unpadded 256-byte rows with the 16-byte column XOR-swizzled by the row (conflict-free
 // ds_read_b128; the padded 272-byte rows are 2-way on one slot per lane group): -2 %.  Measured and removed again: the DMA pieces of waves 4-7 issued
 // half a chunk later (+6 %), all K fragments of a unit requested in one batch in front of its S MFMAs (+4 %: the wait moves into the row-maximum phase).
-#ifndef ATT_KSWZ
+#if !defined(ECAD_DIAG) || !defined(ATT_KSWZ)
+#undef ATT_KSWZ
 #define ATT_KSWZ 0
 #endif
 // ATT_STAMP: wave 0 of workgroup 0 sums s_memtime deltas per loop phase into p.bias (reused as a u64[8] debug buffer): wait+barrier, DMA issue, S, softmax, PV, units
-#ifndef ATT_STAMP
+#if !defined(ECAD_DIAG) || !defined(ATT_STAMP)
+#undef ATT_STAMP
 #define ATT_STAMP 0
 #endif
 

@@ -9,6 +9,13 @@
 //   pipelines/pass_through.py:297-380                               CFG / learned-sigma drop / scheduler step
 #include "../../include/ecad_hip.h"
 
+#if (defined(G_STAMP) || defined(G2_BREAK_TILE) || defined(ATT_ABL) || defined(ATT_STAMP)) && !defined(ECAD_DIAG)
+#error "in-kernel stamps and wrong-result ablations exist in diagnostic builds only: make -C ecad_amd/csrc diag (-DECAD_DIAG, output build_tmp/libecad_diag.so)"
+#endif
+#if defined(ECAD_DIAG) && defined(ECAD_PRODUCT_BUILD)
+#error "the product library (ecad_amd/libecad_hip.so) is never built with -DECAD_DIAG"
+#endif
+
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1379,9 +1386,6 @@ template <typename T> class EngineT : public EngineBase {
   static constexpr int ln16 = 1;  // 16 lanes per row (D = 1152: 9 chunks per lane), ln16 rows per lane group: 16.2 -> 15.3 us per launch at 1 row, 18.3 at 2, 25.7 at 4
                  // (the pass is bound by the number of loads in flight, not by bandwidth); env ECAD_LN16=0: one wave per row
   int launch_ln(const FlushArgs& f, hipStream_t s) {
-#ifdef ECAD_ABL_NOLN  // timing ablation only (wrong results): what the LayerNorm launches without pending replays cost end to end
-    if (f.n_src == 0) return ECAD_OK;
-#endif
     const int cpr = f.D / 8;
     const int grid = (f.M + 3) / 4;
     if (f.D % 8) return fail(ECAD_E_INVALID, "D %% 8 != 0");

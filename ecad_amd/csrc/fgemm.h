@@ -141,10 +141,9 @@ ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   issue(0);
   if (STAGES == 3 && nk > 1) issue(1);
   int stage = 0;
-#ifndef FG_NO_XBAR
   // gemm2w.h's scheme: the last PN = 2 columns of a step's second fragment set are consumed after the NEXT barrier (8 MFMAs of pipe work
   // while the barrier resolves).  FLUX-1024 in-run: single-stream QKV+MLP -1 %, proj_out -2.9 %, +0.6 % end to end.  The full set spills
-  // at BN = 256 (-25 %).  -DFG_NO_XBAR: the plain loop below.
+  // at BN = 256 (-25 %).
   constexpr int PN = 2;
   Pack8 afp[FM], wfp[PN];
   for (int kt = 0; kt < nk; ++kt) {
@@ -200,52 +199,6 @@ ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   for (int j = 0; j < PN; ++j)
 #pragma unroll
     for (int i = 0; i < FM; ++i) acc[i][FN - PN + j] = mfma16<T>(wfp[j], afp[i], acc[i][FN - PN + j]);
-  __syncthreads();
-  return;
-#endif
-  for (int kt = 0; kt < nk; ++kt) {
-    if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INST + B_INST) : "memory");  // only the newest stage may still be in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading the stage about to be refilled
-    const char* abase = smem + stage * STAGE_BYTES;
-    const char* bbase = abase + A_BYTES;
-    // The first fragment set is requested BEFORE the next stage's DMA is issued, so its LDS latency hides behind the eight DMA issues instead
-    // of following them (plain GEMM, in-run A/B: 9216 x 9216 x 3072 940 -> 1018 TFLOP/s, 9216 x 3072 x 15360 1014 -> 1089, 8192^3 1200 ->
-    // 1266; issuing the DMA after half of the first MFMA group instead: equal or worse; consuming the second fragment set after the NEXT
-    // step's barrier so that the matrix pipe has work while the barrier resolves: +2..4 % at BN = 128, but 22 spilled VGPRs and -25 % at BN = 256).
-    Pack8 af0[FM], wf0[FN];
-    {
-      const int coff = (g ^ swz) * 16;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + STAGES - 1 < nk) {
-      int ns = stage + STAGES - 1;
-      ns = ns >= STAGES ? ns - STAGES : ns;
-      issue(ns);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
-    {
-      const int coff = ((4 + g) ^ swz) * 16;
-      Pack8 af[FM], wf[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
-    }
-    stage = stage + 1 >= STAGES ? 0 : stage + 1;
-  }
   __syncthreads();
 }
 
@@ -323,7 +276,6 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   constexpr int CPR = BN / 8;
   constexpr int CHUNKS = 32 * CPR;
   if (EPI == FEPI_BIAS_GATE_RESID) {
-#ifndef FG_EPI_SERIAL
     // 64 % CPR == 0: a lane keeps its column chunk for all its rows.  All hidden-state chunks of the wave's 32 rows are requested in
     // one batch (inside a loop each load would wait behind the previous row's store to the same buffer), and the gate of a strip that
     // lies in one sample and segment is fetched once per lane instead of once per chunk.
@@ -375,7 +327,6 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
       gstore16(p.resid + (size_t)m * p.ldr + n, pack8<T>(h));
     }
     return;
-#endif
   }
   for (int id = lane; id < CHUNKS; id += 64) {
     const int rl = id / CPR, cchunk = id - rl * CPR;

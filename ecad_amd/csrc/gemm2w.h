@@ -98,25 +98,6 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     }
   };
 
-  // one 1-KiB piece of this wave's share of a stage, q = 0 .. 8 (4 A pieces, up to 5 W pieces); source pointers advance once per step (advance_src)
-  auto issue_one = [&](int stage, auto qc) {
-    constexpr int q = decltype(qc)::value;
-    char* abase = smem + stage * G2_STAGE_BYTES;
-    if constexpr (q < A_INST) {
-      glds16(a_src[q], abase + (wave * A_INST + q) * 1024);
-    } else {
-      constexpr int i = q - A_INST;
-      const int inst = wave + i * G2_NW;
-      if (inst < B_TOTAL) glds16(b_src[i], abase + G2_A_BYTES + inst * 1024);
-    }
-  };
-  auto advance_src = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_INST; ++i) a_src[i] += GEMM_BK;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) b_src[i] += GEMM_BK;
-  };
-
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -138,10 +119,9 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     issue(0);
   }
   pre_issued = false;
-#ifndef G2_NO_XBAR
   // the last PN columns of a step's second fragment set are consumed after the NEXT barrier (4 * PN MFMAs of pipe work while the barrier
   // resolves and the new stage's first fragments arrive); the full set does not fit next to 144 accumulators (PN = 2: 254 VGPRs, no spills).
-  // In-run A/B: FF1 -1.6 %, wide K,V -1.5 %, +0.8 % end to end; PN = 4 the same.  -DG2_NO_XBAR: the plain loop below.
+  // In-run A/B: FF1 -1.6 %, wide K,V -1.5 %, +0.8 % end to end; PN = 4 the same.
   constexpr int PN = 2;
   Pack8 afp[FM], wfp[PN];
   auto step_top = [&](int kt) {
@@ -199,122 +179,15 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
 #pragma unroll
       for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], afp[i], acc[i][j]);
   };
-  // Staggered schedule (see gemm3s.h; K-steps 1 .. nk-2): one MFMA stream for all waves, the 9 LDS-DMA pieces of the next stage one per group
-  // of 4 MFMAs -- waves 0-3 beside the first 36 MFMAs of the step, waves 4-7 (their SIMD partners) beside the last 28
-  [[maybe_unused]] auto step_stagger = [&](int kt) {
-    const int stage = kt & 1, nst = stage ^ 1;
-#ifdef G2_STAGGER_ALL_EARLY
-    const bool early = true;  // every wave spreads its pieces over the first 36 MFMAs of the step (no offset between SIMD partners)
-#else
-    const bool early = wave < G2_NW / 2;
-#endif
-    step_top(kt);
-    Pack8 af0[FM], wf0[FN];
-    read_set0(af0, wf0, stage);
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<11>([&](auto gc) {  // MFMAs 0..7: the carried columns; 8..43: the first fragment set, column by column
-      constexpr int gi = decltype(gc)::value;
-      if constexpr (gi < 9) { if (early) issue_one(nst, gc); }
-      static_for<4>([&](auto tc) {
-        constexpr int idx = gi * 4 + decltype(tc)::value;
-        if constexpr (idx < 4 * PN) {
-          constexpr int j = idx / FM, i = idx - j * FM;
-          acc[i][FN - PN + j] = mfma16<T>(wfp[j], afp[i], acc[i][FN - PN + j]);
-        } else {
-          constexpr int k2 = idx - 4 * PN;
-          constexpr int j = k2 / FM, i = k2 - j * FM;
-          acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
-        }
-      });
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    Pack8 wf[FN - PN];
-    read_set1(wf, stage);
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<FN - PN>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if (!early) {
-        issue_one(nst, jc);
-        if constexpr (j + (FN - PN) < 9) issue_one(nst, std::integral_constant<int, j + (FN - PN)>{});
-      }
-      static_for<FM>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        acc[i][j] = mfma16<T>(wf[j], afp[i], acc[i][j]);
-      });
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    advance_src();
-  };
-  {
-    int kt = 0;
-    step_block(kt++);
-    // measured NEGATIVE on this kernel (variant 2 selects it for A/B): with a 2-stage ring the pieces the late half issues in the second half of a
-    // step have half a step to land before the vmcnt(0) at the next barrier -- wide K,V 44.6 -> 49.2 us, FF1 92.6 -> 100.8 us.  The block
-    // schedule stays the default here; the staggered one is what gemm3s.h (3 stages) runs (-DG2_STAGGER_AB compiles it in here).
-#ifdef G2_STAGGER_AB
-    if (p.variant == 2 || G2_STAGGER_AB == 2)
-      for (; kt + 1 < nk; ++kt) step_stagger(kt);
-#endif
-    for (; kt < nk; ++kt) step_block(kt);
-  }
+  // (measured NEGATIVE on this kernel: the staggered LDS-DMA issue of gemm3s.h -- with a 2-stage ring the pieces the late half issues in the second half of a step
+  // have half a step to land before the vmcnt(0) at the next barrier: wide K,V 44.6 -> 49.2 us, FF1 92.6 -> 100.8 us; with every wave spreading its pieces over the
+  // first 36 MFMAs of the step instead: 3213 -> 2894 cycles per K-step and the SAME time, the in-kernel clock falling from 1.85 to 1.77 GHz -- the loop is
+  // power-limited, cycles saved are not time saved: DESIGN 5h)
+  for (int kt = 0; kt < nk; ++kt) step_block(kt);
 #pragma unroll
   for (int j = 0; j < PN; ++j)
 #pragma unroll
     for (int i = 0; i < FM; ++i) acc[i][FN - PN + j] = mfma16<T>(wfp[j], afp[i], acc[i][FN - PN + j]);
-#else
-  for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed (nothing else is in flight)
-    __builtin_amdgcn_s_barrier();                      // tile kt complete; everyone is done reading the other stage
-    const char* abase = smem + stage * G2_STAGE_BYTES;
-    const char* bbase = abase + G2_A_BYTES;
-#ifdef G_LATE_READS
-    if (kt + 1 < nk) issue(stage ^ 1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int coff = ((kk * 4 + g) ^ swz) * 16;
-      Pack8 af[FM], wf[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
-    }
-#else
-    // first fragment set requested before the next stage's DMA is issued: its LDS latency hides behind the DMA issues (fgemm.h has the numbers)
-    Pack8 af0[FM], wf0[FN];
-    {
-      const int coff = (g ^ swz) * 16;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af0[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf0[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) issue(stage ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf0[j], af0[i], acc[i][j]);
-    {
-      const int coff = ((4 + g) ^ swz) * 16;
-      Pack8 af[FM], wf[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = lds_read16(abase + a_row_off + i * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf[j] = lds_read16(bbase + b_row_off + j * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<T>(wf[j], af[i], acc[i][j]);
-    }
-#endif
-  }
-#endif
 #ifdef G_STAMP
   st_c2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -328,9 +201,9 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
       pre_issued = true;
     }
   }
-#ifdef G2_BREAK_TILE
-  // deliberately wrong build for checking the parity net (never shipped): tile column 1 loses one 16-column fragment of its second column half
-  if (tn == 1 && wn == 1)
+#if defined(ECAD_DIAG) && defined(G2_BREAK_TILE)
+  // deliberately wrong DIAGNOSTIC build for checking the parity net (make diag only: the product library cannot be built with it): tile column 1 loses one 16-column fragment of its second column half
+  if (n0 == G2_BN && wn == 1)
 #pragma unroll
     for (int i = 0; i < FM; ++i) acc[i][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #endif
@@ -430,7 +303,7 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
   // ---- epilogue: bias / activation / rounding of the wave's 64 x 144 block into the row-major C tile, one barrier (rows are shared by the two
   // column-half waves), then wave w streams rows 32w .. 32w+31 out in 16-byte chunks.  Stamped (cycles per tile, 256 WGs): wait for the slowest
   // wave + bias 2.9k, accumulators -> LDS 3.3k (FF1 with GELU: 11.0k), LDS -> global 7.1k (the CU's store path moves ~25 B per clock).
-  // Measured NEGATIVE (-DG2_EPI_SLABS): the same in three column slabs so that the VALU works on slab s+1 while the stores of slab s drain --
+  // Measured NEGATIVE and removed: the same in three column slabs so that the VALU works on slab s+1 while the stores of slab s drain --
   // a wave that issues stores into a full queue stalls, so nothing overlaps and two more barriers are paid: wide K,V 44.6 -> 54 us, FF1 92.6 -> 101 us.
   T* ctile = reinterpret_cast<T*>(smem);
   auto convert = [&](auto jc) {
@@ -441,20 +314,14 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     for (int i = 0; i < FM; ++i) {
       const int ml = wm * 64 + 16 * i + l15;
       Pack4 o;
-#if !defined(G_ABL_NOGELU) && !defined(G2_SCALAR_GELU)
       if constexpr (EPI == EPI_BIAS_GELU) {
         const f32x2 v01 = gelu_tanh2((f32x2){acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]});
         const f32x2 v23 = gelu_tanh2((f32x2){acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]});
         float_to_elem4<T>(o, 0, v01[0]); float_to_elem4<T>(o, 1, v01[1]); float_to_elem4<T>(o, 2, v23[0]); float_to_elem4<T>(o, 3, v23[1]);
-      } else
-#endif
-      {
+      } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][r] + bv[r];
-#ifndef G_ABL_NOGELU
-          if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
-#endif
           if (EPI == EPI_BIAS_SILU) v = silu(v);
           float_to_elem4<T>(o, r, v);
         }
@@ -492,32 +359,9 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
       }
       gstore16(rp, pack8<T>(h));
     } else {
-#ifdef G_ABL_NOSTORE
-      if (v.u[0] == 0x12345678u)  // ablation build (wrong results): the epilogue without its global stores
-#endif
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }
   };
-#ifdef G2_EPI_SLABS
-  constexpr int SLABS = 3, JS = FN / SLABS;      // 3 fragment columns per slab and column half
-  constexpr int SCH = JS * 2;                    // 16-byte chunks per row, slab and column half: 6
-  static_assert(FN % SLABS == 0 && (32 * 2 * SCH) % 64 == 0, "slab geometry");
-  static_for<SLABS>([&](auto sc) {
-    constexpr int sb = decltype(sc)::value;
-    static_for<JS>([&](auto jj) { convert(std::integral_constant<int, sb * JS + decltype(jj)::value>{}); });
-    __syncthreads();
-#ifdef G_STAMP
-    if (sb == SLABS - 1) st_cb = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-    for (int it = 0; it < 32 * 2 * SCH / 64; ++it) {  // 6 chunks per lane and slab
-      const int id = lane + it * 64;
-      const int rl = id / (2 * SCH), cc = id - rl * (2 * SCH);
-      const int cchunk = (cc < SCH ? 0 : 144 / 8 - SCH) + sb * SCH + cc;  // column half 0: chunks [6s, 6s+6), half 1: 18 + [6s, 6s+6)
-      store_chunk(wave * 32 + rl, cchunk);
-    }
-  });
-#else
   static_for<FN>([&](auto jc) { convert(jc); });
   __syncthreads();  // rows are shared by the two column-half waves
 #ifdef G_STAMP
@@ -530,7 +374,6 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w_kernel(const GemmArgs<T> p)
     const int rl = id / CPR, cchunk = id - rl * CPR;
     store_chunk(wave * 32 + rl, cchunk);
   }
-#endif
 #ifdef G_STAMP
   // diagnostic build only: cycles of prologue / K loop / epilogue and the in-kernel clock, per workgroup, into a buffer riding in the unused gate_mod slot
   if (EPI != EPI_BIAS_CACHE_RESID && p.gate_mod && wave == 0 && lane == 0) {

@@ -1,6 +1,6 @@
 // probe_attention.hip -- stand-alone timing of the attention kernels (attention_dma.h / scripts/retired_attention_pingpong.h) on the FLUX joint shape (B 2, 24 heads x 128,
 // S 4608, bf16) and the Sigma-1024 self-attention shape (Bt 8, 16 heads x 72, N 4096, fp16), with the ablation macros of attention_dma.h.
-// build (one binary per ablation): hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DATT_ABL=<bits> scripts/probe_attention.hip -o build_tmp/probe_attention_<bits>
+// build (one binary per ablation): hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DECAD_DIAG -DATT_ABL=<bits> scripts/probe_attention.hip -o build_tmp/probe_attention_<bits>
 // run on the GPU box: build_tmp/probe_attention_<bits> [reps]; prints microseconds per launch (min of 3 timed loops) for every kernel.
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,7 +1,7 @@
 // probe_gemm3s.hip -- the product GEMM kernels of gemm3s.h / gemm2w.h on the model's shapes without the Python stack: microseconds per launch (HIP events over
 // back-to-back launches on random data) and the in-kernel stamps of a -DG_STAMP build (cycles of pipeline fill / K loop / epilogue per workgroup, in-kernel clock).
 // build (one binary per set of experiment macros):
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DG_STAMP [-D...] scripts/probe_gemm3s.hip -o build_tmp/probe_gemm3s[_x]
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DECAD_DIAG -DG_STAMP scripts/probe_gemm3s.hip -o build_tmp/probe_gemm3s[_x]
 // run on the GPU box: build_tmp/probe_gemm3s [reps]
 // (Round 4: streams created with hipExtStreamCreateWithCUMask -- each owning a share of every XCD's CUs -- HUNG the first launch on this pool; not pursued.)
 #include <hip/hip_runtime.h>

@@ -286,11 +286,11 @@ def test_blocks_run_in_the_order_of_the_references_default_fx_graph(golden_dir):
 
     seen = []
 
-    def spy(block, norm_hidden, **kw):
-        seen.append(block.block_num)
+    @ComputeFFRegistry.register
+    def order_spy(block, norm_hidden, **kw):
+        seen.append(int(block.block_num))
         return block.ff(norm_hidden)
 
-    ComputeFFRegistry.register("order_spy", spy)
     bits = np.ones((steps, layers, 3), dtype=bool)
     custom = {(s, b): {"custom_compute_ff": {"name": "order_spy", "kwargs": {}}} for s in range(steps) for b in range(layers)}
     tr, sched, cfg, w = _model(layers, steps, bits, custom)

@@ -639,7 +639,7 @@ def main():
             log(f"png-ready: {batch / dt:.1f} img/s")
             del vae
         if world == 1 and not args.no_cpu_baseline and headline:
-            res["cpu_baseline"] = cpu_baseline(weights, bits, images=2)
+            res["cpu_baseline"] = cpu_baseline(weights, bits, images=4)
         if world == 1 and headline and not args.no_secondary:
             names = list(SECONDARY) if args.secondary == "all" else [n for n in args.secondary.split(",") if n in SECONDARY]
             if pool is not None:

@@ -284,8 +284,10 @@ def test_forced_recompute_and_all_cached_steps_are_exact_replays():
     assert torch.equal(res[0][0], res[0][1])  # recomputing everything on the same inputs is deterministic too
 
 
-def test_flux_1024_full_size_properties():
-    """BASELINE config 5 at its full size -- FLUX.1-dev geometry, 19 joint + 38 single blocks, 1024 x 1024 (N = 4096 + T = 512), batch 2, bf16, the
+@pytest.mark.parametrize("fp8", [False, True])
+def test_flux_1024_full_size_properties(fp8):
+    """BASELINE config 5 at its full size -- FLUX.1-dev geometry, 19 joint + 38 single blocks, 1024 x 1024 (N = 4096 + T = 512), batch 2, bf16 and the fp8
+    block GEMMs the config names (e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4; final latents within 1.2e-1 of the bf16 engine's, measured 6.1e-2), the
     paper's schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json -- cannot be checked against the fp32 CPU oracle in seconds (the reduced-depth
     full-width test below covers the arithmetic), so the size-independent properties: determinism, hipGraph == eager bit for bit, sample 1 of the
     batch == that sample run alone (rows of a batch never see each other), and the engine's Linear MAC count == the closed form that reproduces the
@@ -303,6 +305,8 @@ def test_flux_1024_full_size_properties():
     sched = FluxCacheSchedule.from_json(path)
     model = FluxTransformer2DEdited(guidance_embeds=True, max_batch=B, max_image_tokens=grid * grid, max_text_tokens=T, torch_dtype=torch.bfloat16, device=0)
     eng = model.engine
+    if fp8:
+        eng._chk(eng.lib.ecad_flux_set_fp8(eng._h, 1))
     model.load_state_dict(synthetic_state_dict(model.config, 0, device="cuda:0", dtype=torch.bfloat16))
     bf, bs = sched.to_device_bits()
     of, os_ = flux_bits_from_schedule_json(path)
@@ -329,6 +333,11 @@ def test_flux_1024_full_size_properties():
     assert 2 * st["linear_macs_reference"] == want == json.loads(path.read_text())["metrics"]["total_macs"]  # the engine's figure is per sample
     one = run(slice(1, 2), False)
     assert torch.equal(one, a[1:2])
+    key = "_flux_1024_bf16_latents"
+    if not fp8:
+        globals()[key] = a.float().cpu()  # the fp8 case (collected right after this one) is held to these
+    elif key in globals():
+        assert within(rel_l2(a.float().cpu(), globals()[key]), 1.2e-1)
 
 
 def test_flux_errors():

@@ -63,7 +63,7 @@ class EcadStats(C.Structure):
         ("fold_bytes", C.c_int64),
         ("fold_arena_bytes", C.c_int64),
         ("fold_refused", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("replays_folded", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

@@ -7,17 +7,9 @@
 #pragma once
 #include "common.h"
 #include "fgemm8.h"
+#include "gemm.h"  // SrcDesc
 
 namespace ecad {
-
-// One cached sub-layer output waiting to be added to the hidden states.
-//   attn1 / ff: gate = scale_shift_table[2|5] + timestep_mod[b][2|5]   (cached_transformer_block.py:243-246,317-320)
-//   attn2:      gate = 1 (gate_table == nullptr)                        (:289)
-struct SrcDesc {
-  const void* cache;
-  const float* gate_table;  // [D] fp32 or null
-  const void* gate_mod;     // T[b * mod_stride + d] or null
-};
 
 struct FlushArgs {
   void* h;               // [M, D] hidden states (updated in place when n_src > 0)

@@ -199,6 +199,8 @@ template <typename T> class EngineT : public EngineBase {
   size_t fold_prep_ops = 0;           // plan_run[n_begin .. n_begin + fold_prep_ops) = timestep MLP + comb vectors: what the prep needs before the first replay
   size_t fold_prep_begin = 0;
   int ln_folded = 0, fold_preps = 0, fold_refused = 0;
+  bool xsrc_fold = true;   // cached components replayed in the epilogue of the read-modify-write GEMM in front of them (env ECAD_REPLAY_FOLD=0: pending list only)
+  int xsrc_folded = 0;
   std::vector<float> fold_ts;         // the timesteps the arena was prepared for
   float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
   uint8_t* mask_buf;
@@ -328,6 +330,7 @@ template <typename T> class EngineT : public EngineBase {
     custom_mask.assign((size_t)cfg.num_layers * 3, 0);
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
     if (const char* l = getenv("ECAD_LN_FOLD")) ln_fold = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_REPLAY_FOLD")) xsrc_fold = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LN_FOLD_BUDGET_MB")) fold_budget = (size_t)(atoll(l) > 0 ? atoll(l) : 0) << 20;
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
@@ -917,10 +920,28 @@ template <typename T> class EngineT : public EngineBase {
     // GEMM that last wrote h are still current (`stats_ok`).
     const bool fold_plan = fold_plan_on && !bind_call && comb_live;
     bool stats_ok = false;
+    // index of the read-modify-write GEMM that wrote h last, while it is still the LAST op of the list (nothing has read h since): a cached component that comes
+    // next is replayed in that GEMM's epilogue (GemmArgs::xsrc, at most G3_XSRC_MAX of them) instead of joining the pending list -- the LayerNorm launch / replay
+    // flush that would have carried it is not emitted, and the row statistics the GEMM publishes already describe the final h, so the LayerNorm fold goes on.
+    int last_rmw = -1;
     auto push_rmw = [&](Op<T> o) {
       if (fold_plan) o.g.stat_out = hstat;
       push_gemm(ops, o);
       stats_ok = fold_plan;
+      last_rmw = (!ops.empty() && ops.back().kind == Op<T>::GEMM && xsrc_fold) ? (int)ops.size() - 1 : -1;
+    };
+    auto pend_push = [&](const Pending& q) {
+      if (last_rmw >= 0 && last_rmw == (int)ops.size() - 1 && pend.empty() && ops[last_rmw].g.n_xsrc < G3_XSRC_MAX) {
+        Op<T>& r = ops[last_rmw];
+        if (r.g.n_xsrc == 0) { r.desc_off = (int)desc_host.size(); r.g.xsrc_mod_stride = mstride; }
+        desc_host.push_back(SrcDesc{q.cache, q.gate_table, q.gate_mod});
+        ++r.g.n_xsrc;
+        r.bytes += (double)M * D * sizeof(T);
+        st.cache_bytes_read += (int64_t)M * D * (int64_t)sizeof(T);
+        ++xsrc_folded;
+        return;
+      }
+      pend.push_back(q);
     };
     auto fold_take = [&](size_t bytes) { char* q = fold_cur.base + fold_used; fold_used += (bytes + 255) & ~(size_t)255; return q; };
     auto set_fold = [&](Op<T>& o, const float* c1) {
@@ -937,7 +958,7 @@ template <typename T> class EngineT : public EngineBase {
       if (custom(b, 0)) {
         emit_ln(ops, pend, M, B.sst + 0 * D, B.sst + 1 * D, mod_s + 0 * D, mod_s + 1 * D, mstride, mstride, false, nullptr, nullptr);
         emit_custom(b, 0, xn);
-        pend.push_back(Pending{io_out, B.sst + 2 * D, mod_s + 2 * D});
+        pend.push_back(Pending{io_out, B.sst + 2 * D, mod_s + 2 * D});  // (a plug-in's output: the host callback sits between the GEMM and this sum)
       } else if (ex[0]) {
         // attention in the tail of the Q projection (gemm3s_attn.h): the K,V columns first (wide tiles), then one launch that projects Q for
         // (sample, two heads) and runs their attention on the spot -- no attention launch, no Q round trip through HBM
@@ -998,7 +1019,7 @@ template <typename T> class EngineT : public EngineBase {
         if (live(b, 0)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 4ll * M * D * D; st.linear_macs_executed += 4ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)N * D;
       } else {
-        pend.push_back(Pending{c0, B.sst + 2 * D, mod_s + 2 * D});
+        pend_push(Pending{c0, B.sst + 2 * D, mod_s + 2 * D});
       }
       // --- attn2 (no norm for ada_norm_single, cached_transformer_block.py:264-267; no gate, :289)
       if (custom(b, 1)) {
@@ -1030,7 +1051,7 @@ template <typename T> class EngineT : public EngineBase {
         if (live(b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
       } else {
-        pend.push_back(Pending{c1, nullptr, nullptr});
+        pend_push(Pending{c1, nullptr, nullptr});
       }
       // --- ff
       if (custom(b, 2)) {
@@ -1057,7 +1078,7 @@ template <typename T> class EngineT : public EngineBase {
         if (live(b, 2)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
         st.linear_macs_reference += 8ll * M * D * D; st.linear_macs_executed += 8ll * M * D * D;
       } else {
-        pend.push_back(Pending{c2, B.sst + 5 * D, mod_s + 5 * D});
+        pend_push(Pending{c2, B.sst + 5 * D, mod_s + 5 * D});
       }
     }
     // --- _create_output: norm_out, modulate with scale_shift_table[2, D] + embedded_timestep, proj_out, unpatchify
@@ -1148,12 +1169,14 @@ template <typename T> class EngineT : public EngineBase {
       if (!fold_acquire(need)) { fold_plan_on = false; ++fold_refused; }
     }
     { Op<T> d; d.kind = Op<T>::DUP; d.cls = KC_MISC; plan_run.push_back(d); }
+    xsrc_folded = 0;
     for (int s = 0; s < steps; ++s) {
       emit_transformer(plan_run, s, mod_all + (size_t)s * 6 * D, 0, temb + (size_t)s * D, 0, false);
       Op<T> o; o.kind = Op<T>::SOLVER; o.cls = KC_MISC; o.i0 = s;
       plan_run.push_back(o);
     }
     st.launches_per_batch = (int)plan_run.size();
+    st.replays_folded = xsrc_folded;
     if (fold_plan_on) {
       if (fold_descs.empty()) { fold_pool.push_back(fold_cur); fold_cur = FoldArena{}; }
       else {  // the descriptors of the preparation kernel live behind the weights they describe
@@ -1179,7 +1202,10 @@ template <typename T> class EngineT : public EngineBase {
       HIPCHK(hipMalloc((void**)&desc_dev, desc_cap * sizeof(SrcDesc)));
     }
     if (!desc_host.empty()) HIPCHK(hipMemcpy(desc_dev, desc_host.data(), desc_host.size() * sizeof(SrcDesc), hipMemcpyHostToDevice));
-    auto patch = [&](std::vector<Op<T>>& ops) { for (auto& o : ops) if (o.desc_off >= 0) o.f.srcs = desc_dev + o.desc_off; };
+    auto patch = [&](std::vector<Op<T>>& ops) {
+      for (auto& o : ops)
+        if (o.desc_off >= 0) { if (o.kind == Op<T>::GEMM) o.g.xsrc = desc_dev + o.desc_off; else o.f.srcs = desc_dev + o.desc_off; }
+    };
     patch(plan_run);
     for (auto& v : plan_step) patch(v);
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -1595,7 +1621,8 @@ template <typename T> class EngineT : public EngineBase {
       SrcDesc* base = desc_dyn_dev + desc_dyn_pos;
       desc_dyn_pos += region;
       HIPCHK(hipMemcpy(base, dyn.data(), dyn.size() * sizeof(SrcDesc), hipMemcpyHostToDevice));
-      for (auto& o : ops) if (o.desc_off >= 0) o.f.srcs = base + o.desc_off;
+      for (auto& o : ops)
+        if (o.desc_off >= 0) { if (o.kind == Op<T>::GEMM) o.g.xsrc = base + o.desc_off; else o.f.srcs = base + o.desc_off; }
     }
     ++dynamic_steps;
     int rc = run_ops(ops, s, 0.f, true);

@@ -22,6 +22,14 @@ namespace ecad {
 enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_BIAS_CACHE_RESID = 3,
                EPI_BIAS_ATTN = 4, EPI_BIAS_ATTN_TAIL = 5 };  // gemm3s.h only: the tile is a query projection, attention runs in its tail (gemm3s_attn.h)
 
+// One cached sub-layer output to add to the hidden states: h += gate . cache (cached_transformer_block.py:243-246,289,317-320 with the cached tensor of :354-355,383-386)
+//   attn1 / ff: gate = scale_shift_table[2|5] + timestep_mod[b][2|5];  attn2: gate = 1 (gate_table == nullptr)
+struct SrcDesc {
+  const void* cache;
+  const float* gate_table;  // [D] fp32 or null
+  const void* gate_mod;     // T[b * mod_stride + d] or null
+};
+
 template <typename T> struct GemmArgs {
   const T* A;
   const T* W;
@@ -52,6 +60,12 @@ template <typename T> struct GemmArgs {
   float ln_eps, ln_inv_d;
   // read-modify-write epilogue (gemm3s.h): also publish (sum x, sum x^2) of the tile's 144 columns of the UPDATED hidden states, [N / 144][M][2] floats
   float* stat_out;
+  // read-modify-write epilogue (gemm3s.h), round 4: cached components that FOLLOW this GEMM in the plan with nothing reading the hidden states in between are
+  // replayed right here -- h <- round(h + sum_i gate_i . cache_i) on top of this GEMM's own update, the arithmetic of the replay kernel (elementwise.h) -- so the
+  // LayerNorm launch / replay flush that would have carried them disappears and the row statistics (stat_out) already describe the final h.  At most G3_XSRC_MAX.
+  const struct SrcDesc* xsrc;
+  int n_xsrc;
+  int64_t xsrc_mod_stride;  // row stride of the sources' gate_mod (0 when one timestep is shared by the whole batch)
   int m_begin, m_end;  // this launch covers rows [m_begin, m_end) of the M-row problem (m_end 0: up to M); both multiples of 256 when set: engine.hip splits a launch whose
                        // last round of tiles would leave most CUs idle into whole rounds + a tail that takes the few-rows kernels
   int epi_direct;  // gemm2w.h plain / GELU / SiLU epilogues: 1 = rows leave straight from the registers (permlane-transposed 16-byte stores), 0 = through a C tile in LDS

@@ -11,6 +11,7 @@
 namespace ecad {
 
 constexpr int G3_BM = 256, G3_BN = 144, G3_STAGES = 3, G3_NW = 8;
+constexpr int G3_XSRC_MAX = 2;  // cached components replayed in a read-modify-write epilogue (GemmArgs::xsrc)
 constexpr int G3_STAGE_BYTES = (G3_BM + G3_BN) * 128;
 constexpr int G3_LDS_BYTES = G3_STAGES * G3_STAGE_BYTES;
 static_assert(G3A_LDS_BYTES <= G3_LDS_BYTES, "the fused attention tail (Q tile + K/V staging + bias strip) must fit the operand ring: launch_g3_attn requests G3_LDS_BYTES only");
@@ -317,6 +318,25 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   st_c2 = __builtin_amdgcn_s_memtime();
 #endif
   if (!bias_in_loop) load_bias();
+  // cached components replayed in this epilogue (GemmArgs::xsrc): their chunks of this lane's rows, requested now so that they travel during the C-tile phase
+  Pack8 xs[EPI == EPI_BIAS_CACHE_RESID ? NCH : 1][EPI == EPI_BIAS_CACHE_RESID ? G3_XSRC_MAX : 1];
+  if constexpr (EPI == EPI_BIAS_CACHE_RESID) {
+    if (p.n_xsrc > 0) {
+#pragma unroll
+      for (int sx = 0; sx < G3_XSRC_MAX; ++sx) {
+        if (sx >= p.n_xsrc) break;
+        const T* cbase = reinterpret_cast<const T*>(p.xsrc[sx].cache);
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+          const int id = lane + it * 64;
+          const int rl = id / CPR, cchunk = id - rl * CPR;
+          const int m = m0 + wave * WTM + rl;
+          xs[it][sx].u = (u32x4){0, 0, 0, 0};
+          if (id < CHUNKS && m < p.M) xs[it][sx].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(cbase + (size_t)m * p.ldr + n0 + cchunk * 8));
+        }
+      }
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (EPI == EPI_BIAS_ATTN || EPI == EPI_BIAS_ATTN_TAIL) {  // the tile is a query projection: its attention runs here (gemm3s_attn.h)
     {
@@ -432,7 +452,31 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] += o[e];
       }
-      const Pack8 hn = pack8<T>(h);
+      Pack8 hn = pack8<T>(h);
+      if (p.n_xsrc > 0) {  // the replay kernel's arithmetic on top of the rounded update: h <- round(h + sum gate_i . cache_i), sources in plan order
+        float h2[8];
+        unpack8<T>(hn, h2);
+#pragma unroll
+        for (int sx = 0; sx < G3_XSRC_MAX; ++sx) {
+          if (sx >= p.n_xsrc) break;
+          const SrcDesc d = p.xsrc[sx];
+          float cf[8], gate[8];
+          unpack8<T>(xs[it][sx], cf);
+          if (d.gate_table) {
+            unpack8<T>(gload16(reinterpret_cast<const T*>(d.gate_mod) + (size_t)(m / p.rows_per_batch) * p.xsrc_mod_stride + n), gate);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(d.gate_table + n);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(d.gate_table + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gate[e] += t0[e]; gate[4 + e] += t1[e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h2[e] += gate[e] * cf[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h2[e] += cf[e];
+          }
+        }
+        hn = pack8<T>(h2);
+      }
       gstore16(rp, hn);
       if (p.stat_out) *reinterpret_cast<u32x4*>(ctile + ml * CS + cchunk * 8) = hn.u;  // the wave's own rows of the C tile now hold the updated hidden states
     } else {

@@ -74,7 +74,7 @@ typedef struct EcadStats {
   int64_t fold_bytes;            /* bytes of pre-scaled weights + c1 / c2 vectors the live plan set uses */
   int64_t fold_arena_bytes;      /* device memory this engine holds for such copies right now: live + parked plan sets + recycling pool (bounded by ECAD_LN_FOLD_BUDGET_MB, default 24576) */
   int32_t fold_refused;          /* plan sets lowered WITHOUT the fold because their copies did not fit that budget / the device */
-  int32_t reserved0;
+  int32_t replays_folded;        /* cached components of the whole-loop plan replayed in the epilogue of the read-modify-write GEMM in front of them (no pending list, no launch) */
 } EcadStats;
 
 typedef struct EcadEngine EcadEngine;

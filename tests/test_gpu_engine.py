@@ -637,6 +637,48 @@ def test_execution_contexts_share_weights_and_keep_results_bit_identical():
     pool.close()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cached_components_replayed_in_the_epilogue_of_the_gemm_in_front_of_them(monkeypatch, dtype):
+    """Round 4: a cached component that follows a read-modify-write GEMM with nothing reading the hidden states in between (attn2 cached behind an executed attn1,
+    ff cached behind an executed attn2, the next block's attn1 behind an executed ff ...) is added in that GEMM's epilogue -- h <- round(h + gate . cache) on top of
+    the GEMM's own rounded update, exactly what the replay kernel / the LayerNorm launch would have done next -- so no pending list, no flush launch, and the row
+    statistics the GEMM publishes stay current for the folded LayerNorm behind it.  Same bits as with ECAD_REPLAY_FOLD=0, fewer launches; graph == eager; a row's
+    value does not depend on its batch."""
+    from ecad_amd.engine import EcadEngine
+
+    layers, steps, B = 4, 6, 2
+    bits = rand_bits(steps, layers, 0.75, seed=31)
+    bits[0] = True
+    cfg = PixArtConfig(num_layers=layers)
+    w = unit_gate_weights(cfg, seed=12)
+    inp, enc, mask = cfg_inputs(B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    outs, stats = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ECAD_REPLAY_FOLD", mode)
+        eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=dtype)
+        eng.load_state_dict(w)
+        eng.set_schedule(bits)
+        a = eng.run_schedule(*args, use_graph=True)
+        c = eng.run_schedule(*args, use_graph=False)
+        assert torch.equal(a, c)
+        if mode == "1":
+            one = eng.run_schedule(enc[[1, B + 1]].cuda(), mask[[1, B + 1]].cuda(), inp["latents"][1:2].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
+            assert torch.equal(one, a[1:2])
+        outs[mode], stats[mode] = a.clone(), eng.stats()
+        eng.close()
+    assert stats["1"]["replays_folded"] > 0 and stats["0"]["replays_folded"] == 0
+    assert stats["1"]["launches_per_batch"] < stats["0"]["launches_per_batch"] and stats["1"]["ln_folded"] >= stats["0"]["ln_folded"]
+    print(f"replays folded into read-modify-write epilogues: {stats['1']['replays_folded']}; launches {stats['0']['launches_per_batch']} -> {stats['1']['launches_per_batch']}, "
+          f"LayerNorm folds {stats['0']['ln_folded']} -> {stats['1']['ln_folded']}")
+    # Not the same bits: the pending list sums ALL waiting sources in fp32 and rounds once (and its LayerNorm normalises the unrounded sum), the epilogue rounds after
+    # its (at most two) sources; and a LayerNorm launch that goes takes the statistics path.  Both within the LayerNorm fold's own tolerance, and both plans are held
+    # to the oracle by the run-parity tests of this file (the default engine folds).
+    assert within(rel_l2(outs["1"], outs["0"]), 3e-3 if dtype == torch.float16 else 2e-2)
+
+
 def test_contexts_follow_new_weights_of_the_donor_and_outlive_it():
     """A context that borrows its weights (ecad_share_weights) derives plans, a hipGraph and the LayerNorm-fold copies W' / c1 / c2 from them.  After the donor
     loads NEW weights the context must not keep any of that (stale folded GEMMs beside fresh unfolded ones = silently wrong images): its next run equals a fresh

@@ -289,7 +289,7 @@ def main_flux(args, world, rank, device, dist):
 
             def traffic_of(cls):
                 e = pmc.get(cls) or (pmc.get("gemm_joint_attn_out+ff2") if cls in ("gemm_joint_attn_out", "gemm_joint_ff2") else None)
-                return e.get("hbm_bytes_per_launch") if e else None
+                return e.get("hbm_bytes_per_op", e.get("hbm_bytes_per_launch")) if e else None  # per engine op: a split launch (joint attention) is the sum of its kernels
 
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS,
                                "traffic": traffic_of(dom), "traffic_source": pmc_file, "kernel_sources_stamp": stamp,

@@ -82,7 +82,7 @@ def classify(name: str) -> str | None:
 
 
 def read_pass(directory: Path, counter: str, flux: bool = False):
-    per = defaultdict(lambda: [0, 0.0, ""])  # class -> [launches, sum of counter values, symbol]
+    per = defaultdict(lambda: [0, 0.0, "", defaultdict(int)])  # class -> [launches, sum of counter values, symbol, launches per symbol]
     files = list(directory.rglob("*counter_collection.csv"))
     if not files:
         raise SystemExit(f"no *counter_collection.csv under {directory}")
@@ -102,6 +102,7 @@ def read_pass(directory: Path, counter: str, flux: bool = False):
                 e[0] += 1
                 e[1] += float(row["Counter_Value"])
                 e[2] = row["Kernel_Name"]
+                e[3][row["Kernel_Name"]] += 1
     return per
 
 
@@ -112,13 +113,19 @@ def main():
     fetch, write = read_pass(fetch_dir, "FETCH_SIZE", flux), read_pass(write_dir, "WRITE_SIZE", flux)
     res = {}
     for cls in sorted(set(fetch) | set(write)):
-        nf, sf, sym = fetch.get(cls, [0, 0.0, ""])
-        nw, sw, sym2 = write.get(cls, [0, 0.0, ""])
+        nf, sf, sym, syms = fetch.get(cls, [0, 0.0, "", {}])
+        nw, sw, sym2, syms2 = write.get(cls, [0, 0.0, "", {}])
         fkb = sf / nf if nf else 0.0
         wkb = sw / nw if nw else 0.0
         res[cls] = {"kernel": sym or sym2, "launches": nf or nw, "fetch_size_kb_raw_per_launch": fkb, "write_size_kb_per_launch": wkb,
                     "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0,
                     "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM); WRITE_SIZE exact; separate --pmc passes, eager (no graph) run"}
+        # an engine op that goes out as several kernel launches (FLUX joint attention: whole rounds + the 128-row remainder, two symbols launched equally often):
+        # the engine's profiler and bench.py count ONE launch per op, so the figure to set beside their algorithmic bytes is the sum over the op's launches
+        counts = sorted((syms or syms2).values())
+        if len(counts) > 1 and counts[0] == counts[-1]:
+            res[cls]["kernel_launches_per_op"] = len(counts)
+            res[cls]["hbm_bytes_per_op"] = res[cls]["hbm_bytes_per_launch"] * len(counts)
     sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
     import bench
 

@@ -172,14 +172,8 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   }
   auto prefetch_resid = [&]() {
     if (EPI != EPI_BIAS_CACHE_RESID) return;
-#pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-      const int id = lane + it * 64;
-      const int rl = id / CPR, cchunk = id - rl * CPR;
-      const int m = m0 + wave * WTM + rl;
-      hpre[it].u = (u32x4){0, 0, 0, 0};
-      if (id < CHUNKS && m < p.M) hpre[it] = gload16(p.resid + (size_t)m * p.ldr + n0 + cchunk * 8);
-    }
+    // the (few, L2-resident) gate loads first, then EXACTLY NCH residual loads, every one issued by every wave (clamped addresses instead of lane conditions): the
+    // last K-step's wait counts on it -- step_top lets the newest NCH loads stay in flight across the final barrier
     if (gate_lds && lane < CPR) {
       const int n = n0 + lane * 8;
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
@@ -187,6 +181,16 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gpre[e] = t0[e]; gpre[4 + e] = t1[e]; }
       if (p.gate_mod) gmod = gload16(p.gate_mod + (size_t)(m0 / p.rows_per_batch) * p.gate_mod_stride + n);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      int id = lane + it * 64;
+      id = id < CHUNKS ? id : CHUNKS - 1;
+      const int rl = id / CPR, cchunk = id - rl * CPR;
+      int m = m0 + wave * WTM + rl;
+      m = m < p.M ? m : p.M - 1;
+      hpre[it] = gload16(p.resid + (size_t)m * p.ldr + n0 + cchunk * 8);  // (rows past M / chunks past the wave's share are never stored: the row pass skips them)
     }
   };
   const bool resid_in_tail = nk >= 3;
@@ -209,7 +213,11 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   // residual prefetch went out behind that DMA its NCH loads are newer still, so they may be outstanding as well
   auto step_top = [&](int kt) {
     // 2-stage ring: the stage of this step is the newest thing in flight (it was issued during the previous step): everything must have landed
-    if (NSTG == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (last step of a read-modify-write tile: the NCH residual loads went out in the step before, behind every LDS-DMA piece; vmcnt retires in order, so "at most
+    // NCH outstanding" means the operands have landed while the residual -- an HBM round trip -- keeps travelling into the epilogue.  Waiting for it here cost
+    // the loop ~230 cycles per K-step against the plain epilogue's, 2001 vs 1774: the whole latency, exposed once per tile.)
+    if (EPI == EPI_BIAS_CACHE_RESID && NSTG == 3 && resid_in_tail && kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
+    else if (NSTG == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

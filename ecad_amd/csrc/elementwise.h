@@ -387,9 +387,24 @@ __global__ __launch_bounds__(128) void patch_embed_kernel(const T* __restrict__ 
 // either, but writes 2 bytes per lane per store from 4 waves per CU (43 us for the 18.9 MB output at Bt 32); this one is 16-byte stores with
 // 128 independent FMAs between them: 43 -> 22 us per launch (64 / 128 / 256 tokens per block: equal).  P = 2, CIN = 4 (K = 16).
 // grid: (D / 128, Bt * ceil(Ntok / TOKB)).
-template <typename T, int TOKB>
+// SOLVE (whole-loop plan, steps 1 ..): the latents this patch embed reads do not exist yet -- they are the CFG + sigma-drop + DPM-Solver++ update of the PREVIOUS step
+// (cfg_solver_kernel below, same operations in the same order), computed here on the fly from that step's noise prediction and the solver state, so the separate
+// solver launch between two transformer forwards disappears (20 -> 1 per batch).  Every block recomputes the few values it gathers (4 channels x 2 x 2 pixels per token:
+// nothing next to the 1152 x 16 MACs per token); the blocks of column block 0 and of the first (unconditional) half of the CFG batch also write the new state, into
+// the OTHER buffer pair (ping-pong per step: every reader of this launch sees the old state).
+struct PatchSolve {
+  const void* noise;      // [2B, Cout, H, W], unconditional half first
+  const float* lat_old;   // [B, 4, H, W] fp32
+  const float* x0_old;
+  float* lat_new;
+  float* x0_new;
+  const float* coef;      // {alpha_s, sigma_s, c_x, c_m0, c_m1}
+  float guidance;
+  int B, Cout;
+};
+template <typename T, int TOKB, bool SOLVE = false>
 __global__ __launch_bounds__(256) void patch_embed_cols_kernel(const T* __restrict__ latents, const T* __restrict__ w, const float* __restrict__ bias,
-                                                               const float* __restrict__ pos, T* __restrict__ out, int Hl, int Wl, int D) {
+                                                               const float* __restrict__ pos, T* __restrict__ out, int Hl, int Wl, int D, const PatchSolve sv = PatchSolve{}) {
   constexpr int KK = 16;
   __shared__ float xs[TOKB][KK];
   const int gw = Wl >> 1, ntok = (Hl >> 1) * gw;
@@ -402,9 +417,32 @@ __global__ __launch_bounds__(256) void patch_embed_cols_kernel(const T* __restri
     float x0 = 0.f, x1 = 0.f;
     if (tok < ntok) {
       const int gi = tok / gw, gj = tok - gi * gw;
+      if constexpr (SOLVE) {
+        const int bb = b < sv.B ? b : b - sv.B, c = cp >> 1, HW = Hl * Wl, hw = (gi * 2 + (cp & 1)) * Wl + gj * 2;
+        const size_t idx = ((size_t)bb * 4 + c) * HW + hw;
+        const T* nu = reinterpret_cast<const T*>(sv.noise) + ((size_t)bb * sv.Cout + c) * HW + hw;
+        const T* nt = reinterpret_cast<const T*>(sv.noise) + ((size_t)(sv.B + bb) * sv.Cout + c) * HW + hw;
+        const float alpha_s = sv.coef[0], sigma_s = sv.coef[1], c_x = sv.coef[2], c0 = sv.coef[3], c1 = sv.coef[4];
+        float nxv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float u = (float)nu[e], t = (float)nt[e];
+          const float eps = round_elem<T>(u + sv.guidance * (t - u));
+          const float x = sv.lat_old[idx + e];
+          const float xz = (x - sigma_s * eps) / alpha_s;
+          float nx = c_x * x + c0 * xz;
+          if (c1 != 0.f) nx += c1 * sv.x0_old[idx + e];
+          nx = round_elem<T>(nx);
+          if (blockIdx.x == 0 && b < sv.B) { sv.x0_new[idx + e] = xz; sv.lat_new[idx + e] = nx; }
+          nxv[e] = nx;
+        }
+        x0 = nxv[0];
+        x1 = nxv[1];
+      } else {
       const T* src = latents + (((size_t)b * 4 + (cp >> 1)) * Hl + gi * 2 + (cp & 1)) * Wl + gj * 2;
       x0 = (float)src[0];
       x1 = (float)src[1];
+      }
     }
     xs[t][cp * 2] = x0;
     xs[t][cp * 2 + 1] = x1;
@@ -587,8 +625,10 @@ template <typename T> __global__ void unpatchify_kernel(const T* __restrict__ pr
 // ---- guidance + learned-sigma drop + DPM-Solver++(2M) update (pass_through.py:341-370; scheduler [ext]).
 // noise: [2B, Cout, H, W] (uncond half first); latents fp32 [B, C, H, W] in place; x0_prev fp32.
 // coef = {alpha_s, sigma_s, c_x, c_m0, c_m1}.  Also refreshes the CFG-doubled transformer input for the next step.
+// (whole-loop plan: only the LAST step's update runs as this launch -- the others ride in the next step's patch embed, PatchSolve above; lat_in / x0_in are then the
+// buffer pair that step left current, and model_in is null: nothing reads it any more)
 template <typename T>
-__global__ void cfg_solver_kernel(const T* __restrict__ noise, float* __restrict__ latents, float* __restrict__ x0_prev, T* __restrict__ model_in,
+__global__ void cfg_solver_kernel(const T* __restrict__ noise, const float* lat_in, const float* x0_in, float* latents, float* x0_prev, T* __restrict__ model_in,
                                   const float* __restrict__ coef, float guidance, int B, int C, int Cout, int HW) {
   const int total = B * C * HW;
   const float alpha_s = coef[0], sigma_s = coef[1], c_x = coef[2], c0 = coef[3], c1 = coef[4];
@@ -597,15 +637,17 @@ __global__ void cfg_solver_kernel(const T* __restrict__ noise, float* __restrict
     const float u = (float)noise[((size_t)b * Cout + c) * HW + hw];
     const float t = (float)noise[((size_t)(B + b) * Cout + c) * HW + hw];
     const float eps = round_elem<T>(u + guidance * (t - u));
-    const float x = latents[idx];
+    const float x = lat_in[idx];
     const float x0 = (x - sigma_s * eps) / alpha_s;
     float nx = c_x * x + c0 * x0;
-    if (c1 != 0.f) nx += c1 * x0_prev[idx];
+    if (c1 != 0.f) nx += c1 * x0_in[idx];
     nx = round_elem<T>(nx);  // the reference keeps latents in half precision between steps
     x0_prev[idx] = x0;
     latents[idx] = nx;
-    model_in[idx] = (T)nx;
-    model_in[(size_t)total + idx] = (T)nx;
+    if (model_in) {
+      model_in[idx] = (T)nx;
+      model_in[(size_t)total + idx] = (T)nx;
+    }
   }
 }
 

@@ -203,6 +203,7 @@ template <typename T> class EngineT : public EngineBase {
   int xsrc_folded = 0;
   std::vector<float> fold_ts;         // the timesteps the arena was prepared for
   float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
+  float *x0_prev2 = nullptr, *lat_buf2 = nullptr;  // second solver-state pair: the update of step s rides in the patch embed of step s + 1 and writes the pair it does not read (elementwise.h PatchSolve)
   uint8_t* mask_buf;
   // additive attention biases handed over as such (forward(attention_mask=..., encoder_attention_mask=<3-D bias>), pixart_transformer_2d_edited.py:255-291):
   // one float per (sample, key), broadcast over heads and queries.  self: [Bt][N] for attn1; enc: [Bt][T] replaces the bias derived from the 0/1 mask.
@@ -445,6 +446,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t o_comb = take(max_steps * (size_t)L * 4 * d * sizeof(T));
     const size_t o_hstat = take((d / 144 + 1) * M * 2 * sizeof(float));
     const size_t o_sbias = take(M * sizeof(float)), o_ebias = take(Mt * sizeof(float));
+    const size_t o_x02 = take(lat * sizeof(float)), o_lat2 = take(lat * sizeof(float));
     ws_bytes = off;
     HIPCHK(hipMalloc((void**)&ws, ws_bytes));
     HIPCHK(hipMemset(ws, 0, ws_bytes));
@@ -458,6 +460,7 @@ template <typename T> class EngineT : public EngineBase {
     comb = (T*)(ws + o_comb);
     hstat = (float*)(ws + o_hstat);
     self_bias_buf = (float*)(ws + o_sbias); enc_bias_user = (float*)(ws + o_ebias);
+    x0_prev2 = (float*)(ws + o_x02); lat_buf2 = (float*)(ws + o_lat2);
     st.workspace_bytes = (int64_t)ws_bytes;
     st.cache_arena_bytes = (int64_t)((size_t)L * 3 * M * d * sizeof(T));
 
@@ -878,6 +881,9 @@ template <typename T> class EngineT : public EngineBase {
     pend.clear();
     ops.push_back(o);
   }
+  // the CFG + sigma-drop + DPM-Solver++ update between two forwards of the whole-loop plan is computed by the next forward's patch embed (P = 2, 4 latent channels:
+  // what patch_embed_cols_kernel is written for) instead of a launch of its own
+  bool solver_in_patch() const { return P == 2 && CIN == 4; }
   void emit_replay(std::vector<Op<T>>& ops, std::vector<Pending>& pend, int M, int64_t mstride) {
     if (pend.empty()) return;
     Op<T> o;
@@ -911,6 +917,7 @@ template <typename T> class EngineT : public EngineBase {
     const size_t slot = (size_t)M * D;
     {
       Op<T> o; o.kind = Op<T>::PATCH; o.cls = KC_PATCH; o.p0 = model_in; o.call_latents = bind_call; o.bytes = (double)M * D * sizeof(T);
+      o.i0 = (!bind_call && s > 0 && solver_in_patch()) ? s : 0;  // whole-loop plan: the solver update of step s - 1 is computed here (elementwise.h PatchSolve)
       ops.push_back(o);
     }
     std::vector<Pending> pend;
@@ -1172,6 +1179,7 @@ template <typename T> class EngineT : public EngineBase {
     xsrc_folded = 0;
     for (int s = 0; s < steps; ++s) {
       emit_transformer(plan_run, s, mod_all + (size_t)s * 6 * D, 0, temb + (size_t)s * D, 0, false);
+      if (s + 1 < steps && solver_in_patch()) continue;  // this step's CFG + solver update rides in the next step's patch embed
       Op<T> o; o.kind = Op<T>::SOLVER; o.cls = KC_MISC; o.i0 = s;
       plan_run.push_back(o);
     }
@@ -1472,7 +1480,15 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::REPLAY: launch_replay(o.f, s, o.cls == KC_CACHE_HIT_STEP); break;
       case Op<T>::PATCH: {
         const T* src = o.call_latents ? (const T*)call_latents : (const T*)o.p0;
-        hipLaunchKernelGGL((patch_embed_cols_kernel<T, 256>), dim3(D / 128, Bt * ((N + 255) / 256)), dim3(256), 0, s, src, w_patch, b_patch, pos, h, Hl, Wl, D);
+        if (o.i0 > 0) {  // solver update of step o.i0 - 1 on the fly: state pair A = (lat_buf, x0_prev) after an even number of updates, B after an odd one
+          const int k = o.i0 - 1;
+          PatchSolve sv{};
+          sv.noise = noise; sv.lat_old = (k & 1) ? lat_buf2 : lat_buf; sv.x0_old = (k & 1) ? x0_prev2 : x0_prev; sv.lat_new = (k & 1) ? lat_buf : lat_buf2;
+          sv.x0_new = (k & 1) ? x0_prev : x0_prev2; sv.coef = coef_dev + k * 8; sv.guidance = guidance; sv.B = Bt / 2; sv.Cout = COUT;
+          hipLaunchKernelGGL((patch_embed_cols_kernel<T, 256, true>), dim3(D / 128, Bt * ((N + 255) / 256)), dim3(256), 0, s, src, w_patch, b_patch, pos, h, Hl, Wl, D, sv);
+          break;
+        }
+        hipLaunchKernelGGL((patch_embed_cols_kernel<T, 256, false>), dim3(D / 128, Bt * ((N + 255) / 256)), dim3(256), 0, s, src, w_patch, b_patch, pos, h, Hl, Wl, D, PatchSolve{});
         break;
       }
       case Op<T>::SINUS: {
@@ -1504,7 +1520,10 @@ template <typename T> class EngineT : public EngineBase {
       }
       case Op<T>::SOLVER: {
         const int B = Bt / 2, total = B * CIN * Hl * Wl;
-        hipLaunchKernelGGL((cfg_solver_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, noise, lat_buf, x0_prev, model_in, coef_dev + o.i0 * 8, guidance, B, CIN, COUT, Hl * Wl);
+        // o.i0 updates ran before this one; with the solver in the patch embed they alternated between the two state pairs, and this launch (the last step's) ends in pair A
+        const bool odd = solver_in_patch() && (o.i0 & 1);
+        hipLaunchKernelGGL((cfg_solver_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, noise, odd ? lat_buf2 : lat_buf, odd ? x0_prev2 : x0_prev, lat_buf, x0_prev,
+                           solver_in_patch() ? (T*)nullptr : model_in, coef_dev + o.i0 * 8, guidance, B, CIN, COUT, Hl * Wl);
         break;
       }
       case Op<T>::CUSTOM: {

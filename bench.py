@@ -147,8 +147,8 @@ def stamped_traffic(workload: str, dtype: str) -> tuple[dict, str | None, str]:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def device_weights(cfg_like, seed: int, device) -> dict:
-    """Random-init weights of the PixArt-XL-2 architecture, generated on the device (fp16)."""
+def device_weights(cfg_like, seed: int, device, dtype=None) -> dict:
+    """Random-init weights of the PixArt-XL-2 architecture, generated on the device (fp16; bf16 for the --bf16 secondary)."""
     from ecad_amd.transformer_2d_models.pixart_transformer_2d_edited import state_dict_shapes
 
     g = torch.Generator(device=device).manual_seed(seed)
@@ -156,17 +156,18 @@ def device_weights(cfg_like, seed: int, device) -> dict:
     out = {}
     for name, shape in state_dict_shapes(cfg_like).items():
         scale = d**-0.5 if name.endswith("scale_shift_table") else 0.02
-        out[name] = (torch.randn(shape, generator=g, device=device) * scale).half()
+        out[name] = (torch.randn(shape, generator=g, device=device) * scale).to(dtype or torch.float16)
     return out
 
 
-def synthetic_batch(batch: int, seed: int, device, T: int = 120, side: int = 32):
+def synthetic_batch(batch: int, seed: int, device, T: int = 120, side: int = 32, dtype=None):
+    dtype = dtype or torch.float16
     g = torch.Generator(device="cpu").manual_seed(seed)
     C = 4096
-    prompt = (torch.randn(batch, T, C, generator=g) * 0.1).half()
+    prompt = (torch.randn(batch, T, C, generator=g) * 0.1).to(dtype)
     lens = torch.randint(8, T + 1, (batch,), generator=g)
     mask = (torch.arange(T)[None, :] < lens[:, None]).to(torch.uint8)
-    neg = (torch.randn(1, T, C, generator=g) * 0.1).half().repeat(batch, 1, 1)
+    neg = (torch.randn(1, T, C, generator=g) * 0.1).to(dtype).repeat(batch, 1, 1)
     neg_mask = torch.zeros(batch, T, dtype=torch.uint8)
     neg_mask[:, :2] = 1
     latents = torch.randn(batch, 4, side, side, generator=g)
@@ -317,6 +318,8 @@ SECONDARY = {
     "alpha256_batch4_x4_contexts": ["--batch", "4", "--streams", "4", "--steps", "24", "--warmup", "2"],  # small-batch serving: four batches of 4 in flight
     "alpha256_batch100_paper_latency_config": ["--batch", "100", "--steps", "3", "--warmup", "1"],
     "alpha256_fp8_block_gemms": ["--fp8", "--steps", "5", "--warmup", "1"],
+    # the same kernels with bf16 storage / MFMAs (north_star names bf16): fewer mantissa bits toggle in the multipliers, and the power-limited K loops run at a higher clock
+    "alpha256_bf16": ["--bf16", "--streams", "3", "--steps", "9", "--warmup", "1"],
     "sigma1024_batch4": ["--workload", "sigma1024", "--steps", "3", "--warmup", "1", "--roofline"],
     "flux1024_batch2_bf16": ["--workload", "flux1024", "--steps", "2", "--warmup", "1", "--roofline"],
     "flux1024_batch2_fp8": ["--workload", "flux1024", "--fp8", "--steps", "2", "--warmup", "1", "--roofline"],  # BASELINE config 5 names fp8 MFMA
@@ -367,6 +370,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary workloads (batch 1 / batch 100 / fp8 / Sigma-1024 / FLUX-1024) reported under `secondary`")
     ap.add_argument("--secondary", default="all", help="comma-separated subset of: " + ", ".join(SECONDARY))
     ap.add_argument("--fp8", action="store_true", help="opt-in OCP e4m3 block GEMMs (north_star / BASELINE config 5 name fp8 MFMA); secondary: dtype then reads fp8, the headline stays f16 / bf16")
+    ap.add_argument("--bf16", action="store_true", help="PixArt workloads in bf16 instead of the reference's fp16 (secondary line; `value` of the default run stays fp16)")
     ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024", "flux1024"],
                     help="alpha256 = BASELINE metric config (default); sigma1024 / flux1024 = BASELINE configs 3 / 5 (secondary, not the headline)")
     ap.add_argument("--streams", type=int, default=None,
@@ -422,14 +426,15 @@ def main():
         scfg = json.loads(schedule.read_text())["config"]  # the geometry comes from the file's config block, as the image generator reads it
         assert scfg["transformer_weights"] == "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" and scfg["height"] == scfg["width"] == 1024
         batch, side, text_tokens, sample_size, interp = args.batch or 4, scfg["height"] // 8, 300, 128, 2
-    headline = args.workload == "alpha256" and batch == BATCH and not args.fp8
+    headline = args.workload == "alpha256" and batch == BATCH and not args.fp8 and not args.bf16
+    tdt = torch.bfloat16 if args.bf16 else torch.float16
     sched = PixArtCacheSchedule.from_json(schedule)
     bits = sched.to_numpy()
     n_ctx = max(1, args.streams if args.streams is not None else (DEFAULT_STREAMS if headline else 1))
     eng = EcadEngine(num_layers=28, max_batch=2 * batch, max_tokens=(side // 2) ** 2, max_text_tokens=text_tokens, sample_size=sample_size,
-                     interpolation_scale=interp, dtype=torch.float16, device=local_rank, fp8=True if args.fp8 else None)
+                     interpolation_scale=interp, dtype=tdt, device=local_rank, fp8=True if args.fp8 else None)
     weights = device_weights(type("C", (), dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2,
-                                                num_layers=28, caption_channels=4096)), seed=0, device=device)
+                                                num_layers=28, caption_channels=4096)), seed=0, device=device, dtype=tdt)
     log('weights generated')
     eng.load_state_dict(weights)
     eng.set_schedule(bits)
@@ -440,7 +445,7 @@ def main():
     solver.set_timesteps(NUM_STEPS)
     ts = solver.timesteps.numpy().astype(np.float32)
     coefs = solver.coefficient_table()
-    enc, mask, latents = synthetic_batch(batch, seed=1000 + rank, device=device, T=text_tokens, side=side)  # disjoint work per rank
+    enc, mask, latents = synthetic_batch(batch, seed=1000 + rank, device=device, T=text_tokens, side=side, dtype=tdt)  # disjoint work per rank
 
     def one_batch(graph=True):
         """One image batch, asynchronously: with several contexts consecutive batches go to the contexts in turn (own streams) and overlap on the device."""
@@ -473,7 +478,8 @@ def main():
         job = whole_job(world, batch, args.steps, elapsed)
         value = job["value"]
         flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"]) / batch
-        dtype_label = "fp8-e4m3 block GEMMs, f16 elsewhere [opt-in, not the headline precision]" if args.fp8 else "f16"
+        el = "bf16" if args.bf16 else "f16"
+        dtype_label = f"fp8-e4m3 block GEMMs, {el} elsewhere [opt-in, not the headline precision]" if args.fp8 else ("bf16 [secondary: the reference computes in fp16, `value` of the default run is fp16]" if args.bf16 else "f16")
         if args.workload == "alpha256":
             metric = "images/sec at fixed schedule (PixArt-alpha 256, 20-step, ours_fast)" + ("" if batch == BATCH else f" [secondary: batch {batch}]")
             workload = f"PixArt-alpha 256x256, 20 steps, schedules_in_paper/pixart_alpha_256/ours_fast.json, batch={batch} (CFG batch {2 * batch}), 1xMI355X per rank"
@@ -524,7 +530,7 @@ def main():
             all_fl = sum(v["flops"] for v in gemms.values())
             # HBM bytes per launch by PMC (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/pmc_traffic.py): quoted only from a
             # committed profile stamped with THIS workload, dtype and kernel-source hash; otherwise null (it is not measured inside this run)
-            pmc, pmc_file, stamp = stamped_traffic(f"{args.workload}_b{batch}", "fp8" if args.fp8 else "f16")
+            pmc, pmc_file, stamp = stamped_traffic(f"{args.workload}_b{batch}", "fp8" if args.fp8 else ("bf16" if args.bf16 else "f16"))
             res["roofline"] = {
                 "bound": "mfma",
                 "kernel": dom,

@@ -315,6 +315,8 @@ def main_flux(args, world, rank, device, dist):
 # secondary workloads reported inside the default line (never in `value`): each is this script run as a CHILD process with its own flags
 SECONDARY = {
     "alpha256_batch1_latency": ["--batch", "1", "--steps", "20", "--warmup", "3", "--streams", "1"],
+    # opt-in split-K of the few-rows FF2 (ECAD_SPLIT_K=1): faster at batch 1-2, but a sample run alone then differs in the last bits from the same sample in a batch
+    "alpha256_batch1_latency_split_k": ["ENV:ECAD_SPLIT_K=1", "--batch", "1", "--steps", "20", "--warmup", "3", "--streams", "1"],
     "alpha256_batch4_x4_contexts": ["--batch", "4", "--streams", "4", "--steps", "24", "--warmup", "2"],  # small-batch serving: four batches of 4 in flight
     "alpha256_batch100_paper_latency_config": ["--batch", "100", "--steps", "3", "--warmup", "1"],
     "alpha256_fp8_block_gemms": ["--fp8", "--steps", "5", "--warmup", "1"],
@@ -330,12 +332,13 @@ def run_secondary(names: list[str]) -> dict:
     out = {}
     for name in names:
         roof = "--roofline" in SECONDARY[name]  # configs 3 and 5 carry their own compact roofline (dominant MFMA class by HIP events in the child)
-        cmd = [sys.executable, str(Path(__file__).resolve())] + [a for a in SECONDARY[name] if a != "--roofline"] + ["--no-cpu-baseline", "--no-decode-tail", "--no-secondary"]
+        cmd = [sys.executable, str(Path(__file__).resolve())] + [a for a in SECONDARY[name] if a != "--roofline" and not a.startswith("ENV:")] + ["--no-cpu-baseline", "--no-decode-tail", "--no-secondary"]
+        extra_env = dict(a[4:].split("=", 1) for a in SECONDARY[name] if a.startswith("ENV:"))
         if not roof:
             cmd.append("--no-roofline")
         t0 = time.time()
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ECAD_FORCE_DIST")})
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**{k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ECAD_FORCE_DIST")}, **extra_env})
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not lines:
                 out[name] = {"error": (p.stderr or p.stdout)[-400:]}

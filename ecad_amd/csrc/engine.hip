@@ -203,6 +203,11 @@ template <typename T> class EngineT : public EngineBase {
   int xsrc_folded = 0;
   std::vector<float> fold_ts;         // the timesteps the arena was prepared for
   float *bias_buf, *x0_prev, *lat_buf, *ts_dev, *coef_dev;
+  float* splitk_ws = nullptr;
+  size_t splitk_rows = 0;
+  static constexpr int SPLITK_SLICES = 4;
+  bool split_k = false;  // env ECAD_SPLIT_K=1: few-rows FF2 as K-slices + splitk_rmw_kernel (batch 1: -14 % per image).  Off by default: the fp32 sum is then taken in
+                         // another order than in the sequential-K kernels, so a sample run alone no longer equals the same sample inside a larger batch bit for bit
   float *x0_prev2 = nullptr, *lat_buf2 = nullptr;  // second solver-state pair: the update of step s rides in the patch embed of step s + 1 and writes the pair it does not read (elementwise.h PatchSolve)
   uint8_t* mask_buf;
   // additive attention biases handed over as such (forward(attention_mask=..., encoder_attention_mask=<3-D bias>), pixart_transformer_2d_edited.py:255-291):
@@ -336,6 +341,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_FP8")) fp8 = atoi(l) != 0;
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
     if (const char* l = getenv("ECAD_TAIL_SPLIT")) tail_split = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_SPLIT_K")) split_k = atoi(l) != 0;
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
     // ---- weight arena
@@ -447,6 +453,8 @@ template <typename T> class EngineT : public EngineBase {
     const size_t o_hstat = take((d / 144 + 1) * M * 2 * sizeof(float));
     const size_t o_sbias = take(M * sizeof(float)), o_ebias = take(Mt * sizeof(float));
     const size_t o_x02 = take(lat * sizeof(float)), o_lat2 = take(lat * sizeof(float));
+    splitk_rows = 4096;  // split-K partial sums of a few-rows FF2 (launch_pg): slices x rows <= 4096 row-slices of D fp32 (18.9 MB)
+    const size_t o_splitk = take(splitk_rows * d * sizeof(float));
     ws_bytes = off;
     HIPCHK(hipMalloc((void**)&ws, ws_bytes));
     HIPCHK(hipMemset(ws, 0, ws_bytes));
@@ -461,6 +469,7 @@ template <typename T> class EngineT : public EngineBase {
     hstat = (float*)(ws + o_hstat);
     self_bias_buf = (float*)(ws + o_sbias); enc_bias_user = (float*)(ws + o_ebias);
     x0_prev2 = (float*)(ws + o_x02); lat_buf2 = (float*)(ws + o_lat2);
+    splitk_ws = (float*)(ws + o_splitk);
     st.workspace_bytes = (int64_t)ws_bytes;
     st.cache_arena_bytes = (int64_t)((size_t)L * 3 * M * d * sizeof(T));
 
@@ -1282,7 +1291,39 @@ template <typename T> class EngineT : public EngineBase {
     hipLaunchKernelGGL((gemm3s_kernel<T, EPI, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3(tq), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, g);
     return ECAD_OK;
   }
+  // Few rows AND a long K (FF2: K = 4608 = 72 K-steps on 8-64 latency tiles, 44 us per launch at batch 1 -- 28 % of that batch): SPLITK_SLICES workgroups per tile, each
+  // multiplying a quarter of K into fp32 partial sums, then splitk_rmw_kernel (gemm3s.h) adds them in slice order and runs the read-modify-write epilogue.  Two launches,
+  // four times the workgroups, an 18-step chain instead of a 72-step one.  Deterministic; not bit-identical to the sequential-K kernels (one rounding of an fp32 sum
+  // taken in another order).  Kernel id 6 of ecad_op_gemm_ex forces it.
+  bool g3sk_attr[KC_COUNT] = {};
+  // K-slices per tile: 4, or 2 when four would not fit the chip in one round of two co-resident workgroups per CU (batch 4: 256 latency tiles); 0 = not applicable
+  // (measured: batch 1 31.4 -> 27.0 ms, batch 2 33.3 -> 30.7 ms per batch; batch 4 with four slices = two rounds: 38.7 -> 40.6, hence the one-round rule)
+  int splitk_slices(const GemmArgs<T>& g) const {
+    if (g.K < 2304 || g.m_begin || g.m_end || g.N != D || !g.resid || g.ldr != g.N) return 0;
+    const int tq = ((g.M + G3Q_BM - 1) / G3Q_BM) * (g.N / G3_BN);
+    for (int sl = SPLITK_SLICES; sl >= 2; sl >>= 1)
+      if (g.K % (sl * GEMM_BK) == 0 && tq * sl * in_flight * (sl == 2 ? 5 : 4) <= 8 * num_cus && (size_t)g.M * sl <= splitk_rows) return sl;  // two slices only up to 80 % of a round (batch 3: -3.6 %; batch 4, a full round: +1.8 %)
+    return 0;
+  }
+  template <int TAG> int launch_splitk(const GemmArgs<T>& g, int slices, hipStream_t s) {
+    if (!g3sk_attr[TAG]) {
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s_kernel<T, EPI_SPLITK, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, G3Q_LDS_BYTES));
+      g3sk_attr[TAG] = true;
+    }
+    GemmArgs<T> a = g;
+    a.part = splitk_ws;
+    const int tq = ((g.M + G3Q_BM - 1) / G3Q_BM) * (g.N / G3_BN);
+    hipLaunchKernelGGL((gemm3s_kernel<T, EPI_SPLITK, TAG, G3Q_BM, G3Q_NW, G3Q_STAGES>), dim3(tq, slices), dim3(G3Q_NW * 64), G3Q_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((splitk_rmw_kernel<T>), dim3((g.M * (g.N / G3_BN) + 3) / 4), dim3(256), 0, s, a, slices);
+    return ECAD_OK;
+  }
   template <int EPI, int TAG> int launch_pg(const GemmArgs<T>& g, hipStream_t s) {
+    if constexpr (EPI == EPI_BIAS_CACHE_RESID && (TAG == KC_GEMM_FF2 || TAG == KC_GEMM_SMALL)) {
+      const int slices = (gemm_impl_cls[TAG] == 6 || (split_k && gemm_impl_cls[TAG] != 5 && few_rows(g))) ? splitk_slices(g) : 0;
+      if (slices) return launch_splitk<TAG>(g, slices, s);
+      if (gemm_impl_cls[TAG] == 6) return fail(ECAD_E_UNSUPPORTED, "split-K needs K >= 2304 in whole K-steps per slice, N = D and one round of at most %d slice-tiles", 2 * num_cus);
+    }
+    if (gemm_impl_cls[TAG] == 6) return fail(ECAD_E_UNSUPPORTED, "split-K is instantiated for the read-modify-write epilogue of the FF2 / small call sites");
     if (gemm_impl_cls[TAG] == 5 || few_rows(g)) return launch_quarter<EPI, TAG>(g, s);
     if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
       // wide 256x288 tiles -- unless they would leave half the chip idle (FF1 at batch 4-7 alone on the GPU: 128-224 tiles): then the 256x144 tiles below, twice as many
@@ -1862,7 +1903,8 @@ template <typename T> class EngineT : public EngineBase {
     if (kernel == 4) return fail(ECAD_E_UNSUPPORTED, "the 128 x 144 half-tile variant was measured slower at every call site (DESIGN 5c) and removed in round 4");
     if (kernel == 5 && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the latency tiles have no attention tail through this entry");
     if (kernel == 1) return fail(ECAD_E_UNSUPPORTED, "the persistent producer / consumer kernel (pgemm.h) was retired in round 3: no call site used it");
-    if ((kernel < 0 || kernel > 2) && kernel != 5) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
+    if (kernel == 6 && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "split-K exists for the read-modify-write epilogue only");
+    if ((kernel < 0 || kernel > 2) && kernel != 5 && kernel != 6) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
     if (Nn % G3_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
     if (kernel == 2) {
       if (Nn % G2_BN) return fail(ECAD_E_UNSUPPORTED, "gemm2w tiles need N %% 288 == 0, got %d", Nn);

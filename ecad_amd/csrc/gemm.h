@@ -20,7 +20,8 @@
 namespace ecad {
 
 enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_BIAS_CACHE_RESID = 3,
-               EPI_BIAS_ATTN = 4, EPI_BIAS_ATTN_TAIL = 5 };  // gemm3s.h only: the tile is a query projection, attention runs in its tail (gemm3s_attn.h)
+               EPI_BIAS_ATTN = 4, EPI_BIAS_ATTN_TAIL = 5,  // gemm3s.h only: the tile is a query projection, attention runs in its tail (gemm3s_attn.h)
+               EPI_SPLITK = 6 };  // gemm3s.h latency tiles only: workgroup (x, y) multiplies K-slice y of tile x and leaves fp32 partial sums in `part` (no bias, no rounding)
 
 // One cached sub-layer output to add to the hidden states: h += gate . cache (cached_transformer_block.py:243-246,289,317-320 with the cached tensor of :354-355,383-386)
 //   attn1 / ff: gate = scale_shift_table[2|5] + timestep_mod[b][2|5];  attn2: gate = 1 (gate_table == nullptr)
@@ -68,6 +69,9 @@ template <typename T> struct GemmArgs {
   int64_t xsrc_mod_stride;  // row stride of the sources' gate_mod (0 when one timestep is shared by the whole batch)
   int m_begin, m_end;  // this launch covers rows [m_begin, m_end) of the M-row problem (m_end 0: up to M); both multiples of 256 when set: engine.hip splits a launch whose
                        // last round of tiles would leave most CUs idle into whole rounds + a tail that takes the few-rows kernels
+  // split-K for long-K GEMMs with few rows (round 4; FF2 at batch 1-4: 72 K-steps on 8-64 tiles were a 44 us latency chain): the launch has gridDim.y K-slices per
+  // tile, slice y writes part[y][M][N] (fp32); splitk_rmw_kernel (gemm3s.h) then adds the slices in slice order, adds the bias and runs the read-modify-write epilogue.
+  float* part;
   int epi_direct;  // gemm2w.h plain / GELU / SiLU epilogues: 1 = rows leave straight from the registers (permlane-transposed 16-byte stores), 0 = through a C tile in LDS
   int variant;  // K-loop schedule of gemm3s.h / gemm2w.h: 0 = every wave issues its LDS-DMA pieces in one block after the barrier (round 1),
                 // 1 = staggered: pieces interleaved one per MFMA group, waves 0-3 in the first half of the step, waves 4-7 in the second

@@ -80,6 +80,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   tile_coords(bid, tiles_m, tiles_n, tm, tn);
   const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
 
+  // EPI_SPLITK: this workgroup multiplies K-slice blockIdx.y of its tile (gemm.h)
+  const int k_len = EPI == EPI_SPLITK ? p.K / (int)gridDim.y : p.K;
+  const int k_first = EPI == EPI_SPLITK ? (int)blockIdx.y * k_len : 0;
   const T* a_src[A_INST];
   const T* b_src[B_INST_MAX];
 #pragma unroll
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int row = m0 + r;
     row = row < p.M ? row : p.M - 1;
-    a_src[i] = p.A + (size_t)row * p.lda + c * 8;
+    a_src[i] = p.A + (size_t)row * p.lda + c * 8 + k_first;
   }
 #pragma unroll
   for (int i = 0; i < B_INST_MAX; ++i) {
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
     inst = inst < B_INST_TOTAL ? inst : B_INST_TOTAL - 1;
     const int r = inst * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    b_src[i] = p.W + (size_t)(n0 + r) * p.ldw + c * 8;
+    b_src[i] = p.W + (size_t)(n0 + r) * p.ldw + c * 8 + k_first;
   }
   auto issue = [&](int stage) {
     char* abase = smem + stage * STAGE_BYTES;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
   const int swz = (l15 >> 1) & 7;
   const int a_row_off = (wave * WTM + l15) * 128;
   const int b_row_off = l15 * 128;
-  const int nk = p.K / GEMM_BK;
+  const int nk = k_len / GEMM_BK;
 #ifdef G_STAMP
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long st_c1 = 0, st_c2 = 0, st_ca = 0, st_cb = 0;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * g);
     }
   };
-  const bool bias_in_loop = EPI != EPI_BIAS_CACHE_RESID && nk >= 2;
+  const bool bias_in_loop = EPI != EPI_BIAS_CACHE_RESID && EPI != EPI_SPLITK && nk >= 2;
   int stage = 0;
   // top of K-step kt: stage kt has landed when at most the newest stage's DMA (A_INST + 2 = 6 per wave) is outstanding; in the step after the
   // residual prefetch went out behind that DMA its NCH loads are newer still, so they may be outstanding as well
@@ -325,6 +328,18 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
 #ifdef G_STAMP
   st_c2 = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (EPI == EPI_SPLITK) {  // fp32 partial sums of this K-slice, straight from the accumulators: lane (l15, g) holds row l15, columns 4g .. 4g + 3 of every fragment
+    float* part = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wave * WTM + 16 * i + l15;
+      if (m < p.M) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(part + (size_t)m * p.N + n0 + 16 * j + 4 * g) = acc[i][j];
+      }
+    }
+    return;
+  }
   if (!bias_in_loop) load_bias();
   // cached components replayed in this epilogue (GemmArgs::xsrc): their chunks of this lane's rows, requested now so that they travel during the C-tile phase
   Pack8 xs[EPI == EPI_BIAS_CACHE_RESID ? NCH : 1][EPI == EPI_BIAS_CACHE_RESID ? G3_XSRC_MAX : 1];
@@ -524,6 +539,98 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
     dbg[0] = st_c1 - st_c0; dbg[1] = st_c2 - st_c1; dbg[2] = st_c3 - st_c2; dbg[3] = st_r3 - st_r0; dbg[4] = st_r0; dbg[5] = st_c3 - st_c0; dbg[6] = st_ca - st_c2; dbg[7] = st_cb - st_ca;
   }
 #endif
+}
+
+// Second half of a split-K read-modify-write GEMM (EPI_SPLITK above): out = round(sum over the K-slices, in slice order, + bias), then the epilogue of gemm3s_kernel
+// for EPI_BIAS_CACHE_RESID on that value -- cache slot, h += gate . out, the replayed cached components (xsrc), and the per-tile row statistics of the updated h.
+// One wave per (row, 144-column tile): lanes 0 .. 17 own one 16-byte chunk each, the statistics meet through a fixed butterfly (deterministic: graph == eager,
+// run == re-run).  The K-slices are summed in fp32 before the one rounding, so the result differs from the sequential-K kernels in the last bits (tests hold it to
+// the oracle and to the unsplit kernel within a tolerance, not bit for bit).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_rmw_kernel(const GemmArgs<T> p, int slices) {
+  constexpr int CPR = G3_BN / 8;
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tiles_n = p.N / G3_BN;
+  const int m = w / tiles_n, tn = w - m * tiles_n;
+  if (m >= p.M) return;  // wave-uniform
+  const bool act = lane < CPR;
+  const int n = tn * G3_BN + (act ? lane : 0) * 8;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < slices; ++sl) {
+    const float* q = p.part + ((size_t)sl * p.M + m) * p.N + n;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(q), q1 = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] += q0[e]; a[4 + e] += q1[e]; }
+  }
+  if (p.bias) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] += b0[e]; a[4 + e] += b1[e]; }
+  }
+  const Pack8 v = pack8<T>(a);
+  float sx = 0.f, sxx = 0.f;
+  if (act) {
+    if (p.C) gstore16_nt(p.C + (size_t)m * p.ldc + n, v);
+    T* rp = p.resid + (size_t)m * p.ldr + n;
+    float o[8], h[8];
+    unpack8<T>(v, o);
+    unpack8<T>(gload16(rp), h);
+    const int b = m / p.rows_per_batch;
+    if (p.gate_table) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n), t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
+      float gt[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+      if (p.gate_mod) {
+        float gm[8];
+        unpack8<T>(gload16(p.gate_mod + (size_t)b * p.gate_mod_stride + n), gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gt[e] += gm[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] += gt[e] * o[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] += o[e];
+    }
+    Pack8 hn = pack8<T>(h);
+    if (p.n_xsrc > 0) {
+      float h2[8];
+      unpack8<T>(hn, h2);
+      for (int sxi = 0; sxi < p.n_xsrc; ++sxi) {
+        const SrcDesc d = p.xsrc[sxi];
+        float cf[8], gate[8];
+        Pack8 cv;
+        cv.u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(d.cache) + (size_t)m * p.ldr + n));
+        unpack8<T>(cv, cf);
+        if (d.gate_table) {
+          unpack8<T>(gload16(reinterpret_cast<const T*>(d.gate_mod) + (size_t)b * p.xsrc_mod_stride + n), gate);
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(d.gate_table + n), t1 = *reinterpret_cast<const f32x4*>(d.gate_table + n + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gate[e] += t0[e]; gate[4 + e] += t1[e]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h2[e] += gate[e] * cf[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h2[e] += cf[e];
+        }
+      }
+      hn = pack8<T>(h2);
+    }
+    gstore16(rp, hn);
+    float x[8];
+    unpack8<T>(hn, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sx += x[e]; sxx = __builtin_fmaf(x[e], x[e], sxx); }
+  }
+  if (p.stat_out) {  // (sum x, sum x^2) of this tile's 144 columns of the updated row: lanes 18 .. 63 contribute zeros, fixed butterfly over the first 32 lanes
+#pragma unroll
+    for (int o2 = 16; o2 > 0; o2 >>= 1) { sx += __shfl_xor(sx, o2); sxx += __shfl_xor(sxx, o2); }
+    if (lane == 0) {
+      float* dst = p.stat_out + ((size_t)tn * p.M + m) * 2;
+      dst[0] = sx;
+      dst[1] = sxx;
+    }
+  }
 }
 
 }  // namespace ecad

@@ -329,7 +329,7 @@ class EcadEngine:
         )
         return out
 
-    GEMM_KERNELS = {"tile144": 0, "wide288": 2, "tile128": 3, "latency64": 5}
+    GEMM_KERNELS = {"tile144": 0, "wide288": 2, "tile128": 3, "latency64": 5, "latency64_splitk": 6}
     GEMM_SITES = {"qkv": 0, "attn1_out": 1, "attn2_q": 2, "attn2_out": 3, "ff1": 4, "ff2": 5, "text_kv": 6, "caption": 7, "small": 8, "attn1_kv": 9}
 
     def op_gemm_ex(self, kernel: str, site: str, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None,

@@ -203,6 +203,35 @@ def test_every_tile_shape_of_a_call_site_sums_k_in_the_same_order(dtype_name, si
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("M,gated", [(512, True), (192, False), (1024, True), (1536, False)])
+def test_split_k_latency_tiles_against_fp32_and_the_sequential_kernel(dtype_name, M, gated):
+    """Kernel id `latency64_splitk` (what the engine launches for FF2 with few rows): four K-slices per 64 x 144 tile into fp32 partial sums, then splitk_rmw_kernel.
+    Cache slot and updated hidden states per output tile against fp32, and against the sequential-K latency tile within one output rounding."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    D, K = 1152, 4608
+    a, w = _r((M, K), dt, 1.0, 71), _r((D, K), dt, 0.03, 72)
+    bias = _r((D,), torch.float32, 0.3, 73)
+    h0 = _r((M, D), dt, 1.0, 74)
+    table = _r((D,), torch.float32, 1.0, 75) if gated else None
+    outs = {}
+    for kernel in ("latency64_splitk", "latency64"):
+        h = h0.clone()
+        cache = torch.zeros((M, D), dtype=dt, device="cuda")
+        eng.op_gemm_ex(kernel, "ff2", 3, a, w, bias, resid=h, gate_table=table, rows_per_batch=64, out=cache)
+        outs[kernel] = (cache.clone(), h.clone())
+    out_ref = a.float() @ w.float().t() + bias
+    h_ref = h0.float() + (table if gated else 1.0) * out_ref.to(dt).float()
+    c, h = outs["latency64_splitk"]
+    assert within(tile_rel_l2(c, out_ref), TOL[dtype_name])
+    assert within(tile_rel_l2(h, h_ref), TOL[dtype_name])
+    assert not torch.equal(c, outs["latency64"][0])  # another summation order: this really is the split kernel
+    assert within(tile_rel_l2(c, outs["latency64"][0].float()), TOL[dtype_name])
+    with pytest.raises(ValueError, match="read-modify-write"):
+        eng.op_gemm_ex("latency64_splitk", "ff2", 0, a, w, bias)
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric W catches a transposed C write (guide 3, 'A=I check')."""
     eng = small_engine("float16")

@@ -1325,10 +1325,14 @@ template <typename T> class EngineT : public EngineBase {
     }
     if (gemm_impl_cls[TAG] == 6) return fail(ECAD_E_UNSUPPORTED, "split-K is instantiated for the read-modify-write epilogue of the FF2 / small call sites");
     if (gemm_impl_cls[TAG] == 5 || few_rows(g)) return launch_quarter<EPI, TAG>(g, s);
-    if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1) {
+    if constexpr (TAG == KC_GEMM_FF1 || TAG == KC_GEMM_TEXTKV || TAG == KC_GEMM_SMALL || TAG == KC_GEMM_KV1 || (TAG == KC_GEMM_QKV && EPI == EPI_BIAS)) {
       // wide 256x288 tiles -- unless they would leave half the chip idle (FF1 at batch 4-7 alone on the GPU: 128-224 tiles): then the 256x144 tiles below, twice as many
       const bool wide_underfills = g.N % G3_BN == 0 && ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN) * in_flight * 2 <= num_cus;
-      if (gemm_impl_cls[TAG] == 2 && g.N % G2_BN == 0 && !wide_underfills) {
+      // the stand-alone Q projection (N = 1152; Sigma-1024 and every geometry whose self-attention is its own launch): wide tiles as soon as they come in whole rounds of the
+      // chip -- M = 32768: 512 wide tiles, 80.2 us against 99.8 us on 1024 narrow ones (same box, hot operands); at M = 8192 (128 wide tiles) the two are level and the narrow tile stays
+      const int wide_tiles = ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN);
+      const bool wide_q = TAG == KC_GEMM_QKV && gemm_impl_cls[TAG] == 0 && g.N % G2_BN == 0 && wide_tiles >= num_cus && wide_tiles % num_cus == 0;
+      if ((gemm_impl_cls[TAG] == 2 || wide_q) && g.N % G2_BN == 0 && !wide_underfills) {
         if (!g2_attr[EPI][TAG]) {
           HIPCHK(hipFuncSetAttribute((const void*)gemm2w_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
           g2_attr[EPI][TAG] = true;

@@ -471,7 +471,7 @@ def main():
     log(f'timed region done: {elapsed:.3f}s')
     single_ctx = None
     if n_ctx > 1:  # the same workload one batch at a time (context 0 alone), for the record: `value` is the pipelined rate
-        k1 = max(2, min(args.steps, 6))
+        k1 = max(2, min(args.steps, 10))
         for _ in range(2):
             eng.run_schedule(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=use_graph)
         e1 = timed_steps(lambda: eng.run_schedule(enc, mask, latents, ts, coefs, GUIDANCE, use_graph=use_graph), k1, torch.cuda.synchronize, dist, device)

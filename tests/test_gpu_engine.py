@@ -554,8 +554,8 @@ def test_split_k_of_the_few_rows_ff2_tracks_the_oracle_and_is_deterministic(monk
     assert res["1"][3] == res["0"][3] > 0  # the LayerNorm fold takes the statistics splitk_rmw_kernel publishes
     step_diff = max(rel_l2(x, y) for x, y in zip(res["1"][0], res["0"][0]))
     assert 0.0 < step_diff  # the split path really ran (another summation order)
-    assert within(step_diff, 1e-3 if dtype == torch.float16 else 8e-3)
-    assert within(rel_l2(res["1"][1], res["0"][1]), 2e-3 if dtype == torch.float16 else 1.6e-2)
+    assert within(step_diff, 4.4e-4 if dtype == torch.float16 else 2.6e-3)  # measured 2.2e-4 / 1.3e-3
+    assert within(rel_l2(res["1"][1], res["0"][1]), 1.7e-3 if dtype == torch.float16 else 1.3e-2)  # measured 8.4e-4 / 6.4e-3 (final latents of the 6-step loop)
 
 
 def test_tail_split_of_a_partial_last_round_is_the_same_arithmetic(monkeypatch):

@@ -227,7 +227,7 @@ def test_split_k_latency_tiles_against_fp32_and_the_sequential_kernel(dtype_name
     assert within(tile_rel_l2(c, out_ref), TOL[dtype_name])
     assert within(tile_rel_l2(h, h_ref), TOL[dtype_name])
     assert not torch.equal(c, outs["latency64"][0])  # another summation order: this really is the split kernel
-    assert within(tile_rel_l2(c, outs["latency64"][0].float()), TOL[dtype_name])
+    assert within(tile_rel_l2(c, outs["latency64"][0].float()), {"float16": 4.5e-5, "bfloat16": 2.4e-4}[dtype_name])  # measured 2.3e-5 / 1.2e-4: a fraction of one output rounding
     with pytest.raises(ValueError, match="read-modify-write"):
         eng.op_gemm_ex("latency64_splitk", "ff2", 0, a, w, bias)
 

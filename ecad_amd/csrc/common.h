@@ -96,6 +96,18 @@ ECAD_DEV void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same DMA as inline asm.  hipcc's waitcnt pass tracks the builtin as an LDS store and puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove
+// disjoint from it -- every ds_read_b64_tr_b16 (the intrinsic carries no alias information), and plain reads of a ring slot picked at run time -- which turns a
+// prefetch that should fly for a whole tile into a round trip in the middle of the tile before it (round 5: found in the ISA of attn_dma_kernel, where the wait sat
+// in front of the first V fragment read of every chunk).  An asm statement is invisible to that pass: the kernel then owns the wait (its own counted
+// `s_waitcnt vmcnt(N)` + barrier before anybody reads the slot).  M0 carries the LDS destination and is not preserved around asm by the compiler: saved and
+// restored here (cdna_hip_programming.md 5.7).  lds_off = wave-uniform LDS byte address (lds_offset() of the slot pointer).
+ECAD_DEV unsigned lds_offset(const void* p) { return (unsigned)(size_t)(lds_void*)p; }
+ECAD_DEV void glds16_raw(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+
 ECAD_DEV Pack8 lds_read16(const void* p) {
   Pack8 r;
   r.u = *reinterpret_cast<const u32x4*>(p);

@@ -57,6 +57,7 @@ template <typename T> struct FGemmArgs {
   int rope_cols;        // 2 * D
   int pos_T;            // sequence position of image token j is pos_T + j; of text token j it is j
   float rope_eps;
+  float q_scale;        // 0 / 1: none; else the q third leaves the epilogue multiplied by it (softmax scale * log2 e folded into Q before its ONE rounding: attention_w4.h)
   T* C2;                // FEPI_QKV_ROPE_MLP: gelu(mlp) output
   int ldc2, n_split;
   int clip16;           // FEPI_BIAS_GATE_RESID: the updated rows are a FLUX block's output: fp16 saturates at +-65504 (cached_flux_transformer_block.py:127-128,288-289)
@@ -385,6 +386,10 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
           for (int j = 0; j < 4; ++j) {
             o[2 * j] = cosv[j] * x[2 * j] - sinv[j] * x[2 * j + 1];
             o[2 * j + 1] = sinv[j] * x[2 * j] + cosv[j] * x[2 * j + 1];
+          }
+          if (!isk && p.q_scale != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= p.q_scale;
           }
           v = pack8<T>(o);
         }

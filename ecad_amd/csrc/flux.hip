@@ -30,6 +30,7 @@
 #include "attention.h"
 #include "attention128.h"
 #include "attention_dma.h"
+#include "attention_w4.h"
 #include "common.h"
 #include "elementwise.h"
 #include "fgemm.h"
@@ -206,6 +207,12 @@ template <typename T> class FluxT : public FluxBase {
   static constexpr int attn_dma = 2;  // attention_dma.h (K / V chunks by LDS-DMA into a double-buffered image) with the partial last round of work items run as 128-row
                                       // items in a second launch; attention128.h takes the shapes it does not cover
   bool attn_dma_attr[1] = {};
+  // attention_w4.h: one wave per SIMD, hand-placed stream (round 5) for the whole rounds of 256-row work items; ECAD_FLUX_ATTN=dma restores attention_dma.h everywhere.
+  // With it on, the engine's plans fold softmax scale * log2 e into Q where Q is produced (RoPE epilogue / kernel: one rounding instead of two) and hand every
+  // attention kernel scale 1.
+  bool attn_w4 = true;
+  bool attn_w4_attr = false;
+  float q_fold() const { return attn_w4 ? (float)(1.4426950408889634 / sqrt((double)DH)) : 0.f; }
   const void* call_in = nullptr;
   void* call_out = nullptr;
 
@@ -338,6 +345,7 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     { hipDeviceProp_t pr; FHIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     if (const char* e = getenv("ECAD_FLUX_FP8")) fp8 = atoi(e) != 0;
+    if (const char* e = getenv("ECAD_FLUX_ATTN")) attn_w4 = strcmp(e, "dma") != 0;
     FHIPCHK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
     FHIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     FHIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -574,6 +582,7 @@ template <typename T> class FluxT : public FluxBase {
   void set_rope(FOp<T>& o, const Range& r, const float* wq, const float* wk) {
     o.epi = FEPI_QKV_ROPE;
     o.g.rope = rope; o.g.nq = wq; o.g.nk = wk; o.g.nq_txt = nullptr; o.g.nk_txt = nullptr; o.g.rope_cols = 2 * D; o.g.pos_T = Tt; o.g.rope_eps = cfg.norm_eps;
+    o.g.q_scale = q_fold();
     o.g.seg0 = r.seg0; o.g.rows_per_batch0 = r.rpb0; o.g.rows_per_batch1 = r.rpb1;
   }
   // append a block GEMM; in fp8 mode: quantise its A rows (per-row scale; both sources of a split-A GEMM in one pass), then the fp8 kernel
@@ -653,7 +662,8 @@ template <typename T> class FluxT : public FluxBase {
     ao.kind = FOp<T>::ATTN; ao.cls = FC_ATTN;
     AttnArgs& a = ao.a;
     a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.out = out; a.bias = nullptr; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
-    a.B = B; a.H = NH; a.Nq = a.Nk = Tt + N; a.dh = DH; a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)DH));
+    a.B = B; a.H = NH; a.Nq = a.Nk = Tt + N; a.dh = DH;
+    a.scale_log2e = attn_w4 ? 1.0f : (float)(1.4426950408889634 / sqrt((double)DH));  // attn_w4: already in Q (q_fold)
     a.seg_t = Tt; a.seg_bt = B * Tt;
     const double S = Tt + N;
     ao.flops = 4.0 * B * S * S * D;
@@ -946,16 +956,26 @@ template <typename T> class FluxT : public FluxBase {
       const int lds_dma = attn_dma_lds_bytes<128>();
       const void* k2 = (const void*)attn_dma_kernel<T, 128, 2>;
       const void* k1 = (const void*)attn_dma_kernel<T, 128, 1>;
+      const void* kw = (const void*)attn_w4a_kernel<T, 2>;
+      const void* kw1 = (const void*)attn_w4a_kernel<T, 1>;
       if (!attn_dma_attr[0]) {
         FHIPCHK(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
         FHIPCHK(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
+        FHIPCHK(hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+        FHIPCHK(hipFuncSetAttribute(kw1, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
         attn_dma_attr[0] = true;
       }
+      // attention_w4.h takes whole 256-row query blocks over Nk % 256 == 0 keys; in the joint layout the text segment must hold whole query blocks and the first
+      // three key tiles of a work item (its DMA stream starts there)
+      const bool w4_ok = attn_w4 && a.dh == 128 && !a.bias && a.Nk % 256 == 0 && a.Nq % 256 == 0 && a.q_off == 0 && a.q_cnt == 0 &&
+                         (a.seg_t == 0 || (a.seg_t % 256 == 0 && a.seg_t >= 3 * W4_KT && a.seg_t < a.Nk));
       auto launch = [&](const void* fn, int n_items, const AttnArgs& aa) {
         AttnArgs arg = aa;
         void* params[] = {&arg};
+        if (fn == kw || fn == kw1) return hipLaunchKernel(fn, dim3(n_items < num_cus ? n_items : num_cus), dim3(256), params, W4_LDS_BYTES, s);
         return hipLaunchKernel(fn, dim3(n_items < num_cus ? n_items : num_cus), dim3(512), params, lds_dma, s);
       };
+      if (w4_ok) { k2 = kw; k1 = kw1; }  // same arithmetic per row in both: a sample's rows do not depend on how the launch is cut
       // Tile-count quantisation: FLUX-1024 has 864 work items of 256 query rows on 256 CUs = 3.375 rounds, i.e. the launch takes 4.  Split: the
       // whole rounds run as they are and the rest of every (sample, head) as 128-row items (one query fragment per wave, half the MFMAs per item, the same K / V
       // stream) in a second launch that all CUs share: 3 + ~0.6 rounds.
@@ -982,10 +1002,10 @@ template <typename T> class FluxT : public FluxBase {
     else hipLaunchKernelGGL((attn_kernel<T, 128, false, 128>), dim3(grid), dim3(512), lds, s, a);
     return ECAD_OK;
   }
-  int launch_rope(T* buf, int rows, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* tab, int seg0, int T_, int N_, hipStream_t s) {
+  int launch_rope(T* buf, int rows, const float* wq, const float* wk, const float* wqt, const float* wkt, const float* tab, int seg0, int T_, int N_, hipStream_t s, float q_scale = 0.f) {
     const size_t items = (size_t)rows * NH * 2;
     hipLaunchKernelGGL((flux_qk_norm_rope_kernel<T>), dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, buf, rows, NH, DH, wq, wk, wqt, wkt, tab, seg0, T_ > 0 ? T_ : 1,
-                       N_ > 0 ? N_ : 1, cfg.norm_eps);
+                       N_ > 0 ? N_ : 1, cfg.norm_eps, q_scale);
     return ECAD_OK;
   }
   int launch_ln(const FluxRowArgs& f, hipStream_t s) {
@@ -1028,7 +1048,7 @@ template <typename T> class FluxT : public FluxBase {
         return launch_gemm8(o.epi, o.bn, q, s);
       }
       case FOp<T>::ATTN: return launch_attn(o.a, s);
-      case FOp<T>::ROPE: return launch_rope(qkv, B * (Tt + N), o.w[0], o.w[1], o.w[2], o.w[3], rope, B * Tt, Tt, N, s);
+      case FOp<T>::ROPE: return launch_rope(qkv, B * (Tt + N), o.w[0], o.w[1], o.w[2], o.w[3], rope, B * Tt, Tt, N, s, q_fold());
       case FOp<T>::LN: return launch_ln(o.f, s);
       case FOp<T>::REPLAY: launch_replay(o.f, s); break;
       case FOp<T>::COPY: FHIPCHK(hipMemcpyAsync(o.p3, o.p0, o.n, hipMemcpyDeviceToDevice, s)); break;

@@ -238,7 +238,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void flux_qk_norm_rope_kernel(T* __restrict__ qkv, int rows, int heads, int dh, const float* __restrict__ wq,
                                                                 const float* __restrict__ wk, const float* __restrict__ wq_txt,
                                                                 const float* __restrict__ wk_txt, const float* __restrict__ rope, int seg0, int T_txt,
-                                                                int N_img, float eps) {
+                                                                int N_img, float eps, float q_scale) {
   const int l16 = threadIdx.x & 15;
   const size_t item = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const size_t total = (size_t)rows * heads * 2;
@@ -272,6 +272,10 @@ __global__ __launch_bounds__(256) void flux_qk_norm_rope_kernel(T* __restrict__ 
   for (int j = 0; j < 4; ++j) {
     o[2 * j] = cosv[j] * x[2 * j] - sinv[j] * x[2 * j + 1];
     o[2 * j + 1] = sinv[j] * x[2 * j] + cosv[j] * x[2 * j + 1];
+  }
+  if (which == 0 && q_scale != 0.f) {  // softmax scale * log2 e folded into Q before its one rounding (attention_w4.h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= q_scale;
   }
   if (live) gstore16(ptr, pack8<T>(o));
 }

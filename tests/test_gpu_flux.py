@@ -139,6 +139,84 @@ def test_joint_attention_matches_sdpa(op_engine, dtype, tol, T, N):
     assert within(rel_l2(out.float(), want), tol)
 
 
+def _joint_sdpa_reference(qkv, B, T, N, H):
+    """fp32 softmax(q k^T / sqrt(128)) v per sample over its [text | image] rows of the engine's joint layout"""
+    S, D = T + N, H * 128
+    want = torch.zeros(B * S, D)
+    for b in range(B):
+        rows = torch.cat([torch.arange(b * T, (b + 1) * T), torch.arange(B * T + b * N, B * T + (b + 1) * N)])
+        x = qkv[rows].float().cpu()
+        q, k, v = [x[:, i * D : (i + 1) * D].view(S, H, 128).transpose(0, 1) for i in range(3)]
+        want[rows] = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(128), -1) @ v).transpose(0, 1).reshape(S, D)
+    return want
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_joint_attention_one_wave_per_simd_kernel_matches_sdpa(dtype, tol):
+    """attention_w4.h (round 5: one wave per SIMD, v_mfma 32x32x16, hand-placed stream of scripts/gen_attn_w4.py) takes the shapes with whole 256-row query blocks
+    and Nk % 256 == 0: T 256 + N 768 here.  Held to the fp32 reference like every other attention kernel (measured 3.2e-4 fp16 / 2.4e-3 bf16: Q is prescaled by
+    scale * log2 e and rounded once more on this entry point; the engine's plans fold the scale into Q where Q is produced instead).  Two launches give the same bits."""
+    from ecad_amd.flux_engine import EcadFluxEngine
+
+    B, T, N, H = 2, 256, 768, 2
+    qkv = torch.randn(B * (T + N), 3 * H * 128, generator=torch.Generator().manual_seed(5)).to(dtype).cuda()
+    eng = EcadFluxEngine(num_layers=0, num_single_layers=0, num_heads=H, max_batch=B, max_image_tokens=N, max_text_tokens=T, dtype=dtype)
+    got = eng.op_attention(qkv, B, T, N)
+    again = eng.op_attention(qkv, B, T, N)
+    torch.cuda.synchronize()
+    eng.close()
+    assert torch.equal(got, again)
+    assert within(rel_l2(got.float().cpu(), _joint_sdpa_reference(qkv, B, T, N, H)), tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 5e-3)])
+def test_joint_attention_running_maximum_that_jumps_late(dtype, tol):
+    """attention_w4.h defers the accumulator rescale: a row's running maximum moves only when a tile's maximum exceeds it by more than 2^8, and then every live
+    score register, the C-init registers, l and (at the end of the iteration) O are recentred -- a rare, data-dependent path that bounded random data never takes
+    after the first tile (cdna_hip_programming.md 5.4 rule 26).  Here keys far along the sequence are 6 x one query row each: that row's maximum jumps by ~70 nats
+    in a late tile (and in another tile for another row, and at the very last key).  Every row against the fp32 reference (measured 7.2e-4 fp16 / 1.9e-3 bf16)."""
+    from ecad_amd.flux_engine import EcadFluxEngine
+
+    B, T, N, H = 1, 256, 1792, 2
+    S, D = T + N, H * 128
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B * S, 3 * D, generator=g)
+    for j, (key, qrow) in enumerate(((700, 17), (1100, 333), (1500, 1200), (S - 1, 2040))):
+        for h in range(H):
+            qkv[key, D + h * 128 : D + (h + 1) * 128] = 6.0 * qkv[qrow + h, h * 128 : (h + 1) * 128]
+    qkv = qkv.to(dtype).cuda()
+    eng = EcadFluxEngine(num_layers=0, num_single_layers=0, num_heads=H, max_batch=B, max_image_tokens=N, max_text_tokens=T, dtype=dtype)
+    got = eng.op_attention(qkv, B, T, N)
+    torch.cuda.synchronize()
+    eng.close()
+    want = _joint_sdpa_reference(qkv, B, T, N, H)
+    assert torch.isfinite(got).all()
+    assert within(rel_l2(got.float().cpu(), want), tol)
+    for qrow in (17, 18, 333, 334, 1200, 1201, 2040, 2041):  # the rows that took the jump, one by one
+        assert within(rel_l2(got[qrow].float().cpu(), want[qrow]), 4 * tol), qrow
+
+
+def test_joint_attention_rows_do_not_depend_on_how_the_launch_is_cut():
+    """B 2 x 24 heads x (256 + 2816) rows = 576 work items of 256 rows on 256 CUs = 2.25 rounds: the engine runs 512 of them on attention_w4.h's 256-row items and
+    the rest of every (sample, head) as 128-row items (one query block per wave) in a second launch.  A row's arithmetic is the same in both and independent of its
+    neighbours: the batch of two equals each sample run alone, bit for bit; and every row is held to the fp32 reference."""
+    from ecad_amd.flux_engine import EcadFluxEngine
+
+    dtype = torch.bfloat16
+    B, T, N, H = 2, 256, 2816, 24
+    S, D = T + N, H * 128
+    qkv = (torch.randn(B * S, 3 * D, generator=torch.Generator().manual_seed(12)) * 0.5).to(dtype).cuda()
+    eng = EcadFluxEngine(num_layers=0, num_single_layers=0, num_heads=H, max_batch=B, max_image_tokens=N, max_text_tokens=T, dtype=dtype)
+    got = eng.op_attention(qkv, B, T, N)
+    for b in range(B):
+        rows = torch.cat([torch.arange(b * T, (b + 1) * T), torch.arange(B * T + b * N, B * T + (b + 1) * N)]).cuda()
+        alone = eng.op_attention(qkv[rows].contiguous(), 1, T, N)
+        assert torch.equal(alone, got[rows]), b
+    torch.cuda.synchronize()
+    eng.close()
+    assert within(rel_l2(got.float().cpu(), _joint_sdpa_reference(qkv, B, T, N, H)), 5e-3)
+
+
 def test_joint_attention_with_a_partial_last_round_of_work_items():
     """The FLUX engine's joint attention (attention_dma.h: K / V chunks by LDS-DMA into a double-buffered image) when the work items do not fill whole rounds of
     workgroups: the rest of every (sample, head) runs as 128-row items in a second launch.  B 2 x 24 heads x (128 + 2944) rows = 576 items on 256 CUs = 2.25 rounds,

@@ -944,7 +944,9 @@ template <typename T> class EngineT : public EngineBase {
       if (fold_plan) o.g.stat_out = hstat;
       push_gemm(ops, o);
       stats_ok = fold_plan;
-      last_rmw = (!ops.empty() && ops.back().kind == Op<T>::GEMM && xsrc_fold) ? (int)ops.size() - 1 : -1;
+      // only gemm3s_kernel / splitk_rmw_kernel implement GemmArgs::xsrc: an inner dim that is not a multiple of 144 goes to gemm_kernel<128,128> (launch_gemm),
+      // whose read-modify-write epilogue knows nothing of it -- the cached components then stay on the pending list (LayerNorm launch / replay flush)
+      last_rmw = (!ops.empty() && ops.back().kind == Op<T>::GEMM && xsrc_fold && ops.back().g.N % G3_BN == 0) ? (int)ops.size() - 1 : -1;
     };
     auto pend_push = [&](const Pending& q) {
       if (last_rmw >= 0 && last_rmw == (int)ops.size() - 1 && pend.empty() && ops[last_rmw].g.n_xsrc < G3_XSRC_MAX) {
@@ -1411,6 +1413,7 @@ template <typename T> class EngineT : public EngineBase {
       return fail(ECAD_E_INVALID, "no 144-column GEMM instantiation for epilogue %d class %d", epi, cls);
     }
     if (g.N % 128) return fail(ECAD_E_INVALID, "gemm N=%d must be a multiple of 144 or 128", g.N);
+    if (g.n_xsrc > 0) return fail(ECAD_E_INVALID, "gemm N=%d: %d replayed components attached to a kernel without the replay epilogue", g.N, g.n_xsrc);
     switch (epi) {
       case EPI_BIAS: launch_gemm_epi<EPI_BIAS>(g, s); break;
       case EPI_BIAS_GELU: launch_gemm_epi<EPI_BIAS_GELU>(g, s); break;

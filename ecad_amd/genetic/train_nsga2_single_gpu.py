@@ -183,7 +183,7 @@ class InProcessEvaluator:
         if not torch.cuda.is_available():
             raise RuntimeError("in-process evaluation needs a GPU: the hot path has no CPU fallback (use --print-not-submit to inspect the plan)")
         if isinstance(manager, FluxPopulationIOManager):
-            raise NotImplementedError("FLUX searches run through train_nsga2_multi_gpu.py --model flux (one rank is fine)")
+            return self._build_flux_score_fn(manager)
         from types import SimpleNamespace
 
         from ecad_amd.engine import EcadEngine
@@ -217,6 +217,39 @@ class InProcessEvaluator:
         for k in range(self.num_images_per_prompt):  # one latent draw per image of a prompt, seeds as the generators step them
             lat = torch.randn(prompts, 4, 32, 32, generator=torch.Generator().manual_seed(k))
             per_seed.append(engine_score_fn(engine, enc.cuda(), mask.cuda(), lat.cuda(), ts, coefs))
+        return lambda index, bits: float(np.mean([fn(index, bits) for fn in per_seed]))
+
+    def _build_flux_score_fn(self, manager) -> ScoreFn:
+        """`--image-generator FluxImageGenerator` (reference train_nsga2_single_gpu.py:73,115): a resident ``EcadFluxEngine`` of the manager's geometry scores
+        every candidate in process.  The 19 + 38-block geometry is FLUX.1-dev's (24 heads, 4096-wide text, random-init weights of its shapes: there is no
+        checkpoint offline); any other block count is a reduced test geometry (2 heads)."""
+        import torch
+        from types import SimpleNamespace
+
+        from ecad_amd.flux_engine import EcadFluxEngine
+        from ecad_amd.genetic.evaluate import flux_engine_score_fn
+        from ecad_amd.pipelines.flow_match import flow_match_sigmas, model_scalars
+        from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import synthetic_state_dict
+
+        nb, ns, steps = manager.num_blocks, manager.num_single_blocks, manager.num_inference_steps
+        full = (nb, ns) == (19, 38)
+        heads, jd, pd, T = (24, 4096, 768, 512) if full else (2, 128, 64, 32)
+        gh, gw = manager.height // 16, manager.width // 16
+        B = max(1, min(self.batch_size, 2))
+        eng = EcadFluxEngine(num_layers=nb, num_single_layers=ns, num_heads=heads, joint_attention_dim=jd, pooled_projection_dim=pd, max_batch=B, max_image_tokens=gh * gw,
+                             max_text_tokens=T, dtype=torch.bfloat16)
+        cfg = SimpleNamespace(num_layers=nb, num_single_layers=ns, num_attention_heads=heads, attention_head_dim=128, in_channels=64, joint_attention_dim=jd,
+                              pooled_projection_dim=pd, guidance_embeds=True)
+        eng.load_state_dict(synthetic_state_dict(cfg, 0, device="cuda" if full else "cpu", dtype=torch.bfloat16 if full else torch.float32))
+        sig = flow_match_sigmas(steps, gh * gw)
+        tm, gm = model_scalars(sig, float(manager.guidance_scale), torch.bfloat16)
+        per_seed = []
+        for k in range(self.num_images_per_prompt):
+            g = torch.Generator().manual_seed(1 + k)
+            enc = (torch.randn(B, T, jd, generator=g) * 0.1).bfloat16().cuda()
+            pooled = (torch.randn(B, pd, generator=g) * 0.5).bfloat16().cuda()
+            lat = torch.randn(B, gh * gw, 64, generator=g).cuda()
+            per_seed.append(flux_engine_score_fn(eng, enc, pooled, lat, gh, gw, tm, gm, sig, nb, ns))
         return lambda index, bits: float(np.mean([fn(index, bits) for fn in per_seed]))
 
     def __call__(self, manager) -> np.ndarray:

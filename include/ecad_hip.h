@@ -211,8 +211,8 @@ int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const flo
  * template instantiation of its call site (tests/test_gpu_ops.py).  kernel: ECAD_GEMM_K_*; call_site: ECAD_SITE_* = the engine's
  * call-site class (it only selects the kernel symbol rocprof reports).  ECAD_E_UNSUPPORTED if that kernel cannot run the shape
  * (never a silent substitution).  Bits 8 and up of `kernel`: 0 = the engine's K-loop schedule, 1 + v = force schedule variant v (A/B runs in one process). */
-enum { ECAD_GEMM_K_TILE144 = 0 /* gemm3s.h 256x144 */, ECAD_GEMM_K_PERSISTENT = 1 /* retired: ECAD_E_UNSUPPORTED */, ECAD_GEMM_K_WIDE288 = 2 /* gemm2w.h 256x288 */,
-       ECAD_GEMM_K_TILE128 = 3 /* gemm.h 128x128, N % 128 == 0 */, ECAD_GEMM_K_HALF144 = 4 /* gemm3s.h 128x144, four waves, two workgroups per CU */,
+enum { ECAD_GEMM_K_TILE144 = 0 /* gemm3s.h 256x144 */, ECAD_GEMM_K_WIDE288 = 2 /* gemm2w.h 256x288 */, ECAD_GEMM_K_TILE128 = 3 /* gemm.h 128x128, N % 128 == 0 */,
+       /* ids 1 and 4 belonged to kernels that left the tree in round 3 (persistent producer / consumer, 128x144 half tile): ECAD_E_UNSUPPORTED */
        ECAD_GEMM_K_LATENCY64 = 5 /* gemm3s.h 64x144, four waves of 16x144: what the engine launches when a GEMM has few rows (batch 1-4) */,
        ECAD_GEMM_K_LATENCY64_SPLITK = 6 /* the same tiles with K in four slices + splitk_rmw_kernel: few rows and K >= 2304 (FF2), epilogue 3 only */ };
 enum { ECAD_SITE_QKV = 0, ECAD_SITE_OUT1 = 1, ECAD_SITE_Q2 = 2, ECAD_SITE_OUT2 = 3, ECAD_SITE_FF1 = 4, ECAD_SITE_FF2 = 5, ECAD_SITE_TEXTKV = 6,

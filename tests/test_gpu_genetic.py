@@ -50,6 +50,32 @@ def test_single_gpu_trainer_real_evaluator(tmp_path):
     assert abs(algo.F[:, 1].max() - 5.71379613696) < 1e-9  # the uncached candidate survives with the reference's all-true TMACs
 
 
+def test_single_gpu_trainer_takes_the_flux_image_generator(tmp_path):
+    """`train_nsga2_single_gpu.py --image-generator FluxImageGenerator` (reference train_nsga2_single_gpu.py:73,115): the FluxPopulationIOManager contract with the
+    in-process evaluator on an EcadFluxEngine -- a reduced geometry (1 joint + 2 single blocks, 128 x 128) resumed from a manager_config.json, one generation:
+    the uncached candidate scores exactly 0, cached ones drift; scores.json / metrics on disk; generation 2 written."""
+    from ecad_amd.genetic import train_nsga2_single_gpu as T
+    from ecad_amd.genetic.population_io_manager import FluxPopulationIOManager
+
+    nb, ns, steps, pop = 1, 2, 20, 4
+    mgr = FluxPopulationIOManager("fx", tmp_path / "p", tmp_path / "b", generation_num=0, population_size=pop, num_blocks=nb, num_single_blocks=ns, height=128, width=128,
+                                  min_diff_from_default=0)
+    rng = np.random.default_rng(3)
+    seed = rng.random((pop, steps * (nb + ns) * 3)) < 0.6
+    seed[0] = True  # candidate 0: the uncached schedule
+    mgr.save_population(seed, 0)
+    mgr.to_json()
+    args = T.parse_args(["--image-generator", "FluxImageGenerator", "--name", "fx", "--all-populations-dir", str(tmp_path / "p"), "--all-benchmarks-dir", str(tmp_path / "b"),
+                         "--load-from", str(tmp_path / "p/fx/gen_000/manager_config.json"), "--batch-size", "1", "--num-images-per-prompt", "1", "--print-eval-outputs"])
+    out_mgr, algo = T.run(args)
+    assert isinstance(out_mgr, FluxPopulationIOManager) and out_mgr.generation_num == algo.n_gen == 2
+    assert len(list((tmp_path / "p/fx/gen_002/candidates").glob("cand_*.json"))) == pop
+    scores = [json.loads((tmp_path / f"b/fx/gen_001/candidates/cand_{i:03d}/scores.json").read_text())["total_score"] for i in range(pop)]
+    assert scores[0] == 0.0 and all(-1.0 < s < 0.0 for s in scores[1:])
+    for i in range(pop):
+        assert "total_macs_T" in json.loads((tmp_path / f"p/fx/gen_001/candidates/cand_{i:03d}.json").read_text())["metrics"]
+
+
 def test_multi_gpu_trainer_one_rank(tmp_path, monkeypatch, capsys):
     """train_nsga2_multi_gpu at world size 1 (the same code path every rank runs; the collectives degenerate to identities)."""
     from ecad_amd.genetic import train_nsga2_multi_gpu as M

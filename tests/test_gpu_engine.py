@@ -208,7 +208,7 @@ def test_run_schedule_parity_and_graph(p):
 
 
 def test_inner_dim_that_is_not_a_multiple_of_144_replays_cached_components():
-    """8 heads x 128 = 1024: N % 144 != 0, so every GEMM runs on gemm_kernel<128,128>, whose read-modify-write epilogue has no replay list (GemmArgs::xsrc is
+    """16 heads x 64 = 1024: N % 144 != 0, so every GEMM runs on gemm_kernel<128,128>, whose read-modify-write epilogue has no replay list (GemmArgs::xsrc is
     gemm3s_kernel's).  The plan must then keep cached components that follow an executed one on the pending list (LayerNorm launch / replay flush) instead of
     attaching them to that GEMM -- round-4 ADVICE: they were attached and silently dropped.  A schedule with cached components behind executed ones in every
     block, whole loop and step API, against the oracle; graph == eager."""
@@ -221,9 +221,9 @@ def test_inner_dim_that_is_not_a_multiple_of_144_replays_cached_components():
     bits[3, :, 0] = False       # attn1 cached in front, the rest executes
     bits[4, 1, :] = False       # a whole block cached between executed ones
     bits[5, :, 1] = False       # attn2 cached between two executed ones
-    cfg = PixArtConfig(num_layers=layers, num_attention_heads=8, attention_head_dim=128)
+    cfg = PixArtConfig(num_layers=layers, num_attention_heads=16, attention_head_dim=64)
     w = make_weights(cfg, seed=4)
-    eng = EcadEngine(num_layers=layers, num_heads=8, head_dim=128, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
+    eng = EcadEngine(num_layers=layers, num_heads=16, head_dim=64, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
     eng.load_state_dict(w)
     eng.set_schedule(bits)
     ref = PixArtOracle(cfg, w)

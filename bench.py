@@ -155,6 +155,27 @@ def stamped_traffic(workload: str, dtype: str) -> tuple[dict, str | None, str]:
     return {}, None, stamp
 
 
+def stamped_sq(workload: str, dtype: str) -> tuple[dict, str | None]:
+    """Counter-based MFMA utilisation per kernel class (scripts/pmc_sq.py: SQ_VALU_MFMA_BUSY_CYCLES over the launch's busy cycles, wave-state fractions, effective
+    clock from GRBM_GUI_ACTIVE) from the newest committed profile measured on exactly these kernel sources; otherwise nothing."""
+    stamp = kernel_source_stamp()
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_sq.json"), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        s = d.get("_stamp")
+        if s and s.get("kernel_sources") == stamp and s.get("workload") == workload and s.get("dtype") == dtype:
+            return d, f.name
+    return {}, None
+
+
+def sq_fields(sq: dict, sq_file: str | None, cls: str) -> dict:
+    e = sq.get(cls) or {}
+    return {"mfma_busy_frac": e.get("mfma_busy_frac"), "effective_clock_ghz": e.get("effective_clock_ghz"), "wave_parked_frac": e.get("wave_parked_frac"),
+            "wave_issue_stalled_frac": e.get("wave_issue_stalled_frac"), "wave_active_frac": e.get("wave_active_frac"), "sq_counters_source": sq_file}
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def device_weights(cfg_like, seed: int, device, dtype=None) -> dict:
     """Random-init weights of the PixArt-XL-2 architecture, generated on the device (fp16; bf16 for the --bf16 secondary)."""
@@ -310,12 +331,15 @@ def main_flux(args, world, rank, device, dist):
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "flops_per_launch": d["flops"] / d["launches"],
                                "avg_launch_ms": d["ms"] / d["launches"], "launches_measured": d["launches"],
                                "all_gemm_tflops": sum(v["flops"] for v in gem) / (sum(v["ms"] for v in gem) * 1e-3) / 1e12}
+            sq, sq_file = stamped_sq(f"flux1024_b{B}", "fp8" if args.fp8 else "bf16")
+            res["roofline"].update(sq_fields(sq, sq_file, "gemm_joint_attn_out+ff2" if dom in ("gemm_joint_attn_out", "gemm_joint_ff2") else dom))
             at = mf.get("attn_joint")
             if at:
                 tf = at["flops"] / (at["ms"] * 1e-3) / 1e12
                 res["attention"] = {"kernel": "attn_joint", "achieved": tf, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TFLOPS, "avg_launch_ms": at["ms"] / at["launches"],
                                     "launches_measured": at["launches"], "ms_per_batch": at["ms"], "flops_per_launch": at["flops"] / at["launches"],
-                                    "algorithmic_bytes_per_launch": at["bytes"] / at["launches"], "traffic": traffic_of("attn_joint"), "traffic_source": pmc_file}
+                                    "algorithmic_bytes_per_launch": at["bytes"] / at["launches"], "traffic": traffic_of("attn_joint"), "traffic_source": pmc_file,
+                                    **sq_fields(sq, sq_file, "attn_joint")}
             res["tflops_by_class"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["launches"] and v["flops"] > 0 and v["ms"] > 0}
             res["time_breakdown_ms_per_batch"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
             res["time_breakdown_ms_per_batch"]["_sum"] = round(sum(v["ms"] for v in prof.values()), 3)
@@ -432,7 +456,8 @@ def run_secondary(names: list[str]) -> dict:
             if "roofline" in d:
                 r = d["roofline"]
                 out[name]["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_measured", "flops_per_launch",
-                                                               "algorithmic_bytes_per_launch", "traffic", "traffic_source", "all_gemm_tflops")}
+                                                               "algorithmic_bytes_per_launch", "traffic", "traffic_source", "all_gemm_tflops", "mfma_busy_frac", "effective_clock_ghz",
+                                                               "sq_counters_source")}
                 if "attention" in d:
                     out[name]["attention"] = d["attention"]
                 out[name]["time_breakdown_ms_per_batch"] = d.get("time_breakdown_ms_per_batch")
@@ -641,6 +666,8 @@ def main():
                 "launches_measured": d["launches"],
                 "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12,
             }
+            sq, sq_file = stamped_sq(f"{args.workload}_b{batch}", "fp8" if args.fp8 else ("bf16" if args.bf16 else "f16"))
+            res["roofline"].update(sq_fields(sq, sq_file, dom))
             # HBM regime: the pure cache-hit steps are one (3L + 2)-stream sweep each (class / kernel symbol "cache_hit_step":
             # algorithmic bytes = (84 + 2) * Bt * N * D * 2 B at L = 28); the short mid-step replays are reported beside it.
             rep = prof.get("cache_hit_step") if prof.get("cache_hit_step", {}).get("launches") else prof.get("cache_replay")
@@ -662,7 +689,7 @@ def main():
                 tf = att[ak]["flops"] / (att[ak]["ms"] * 1e-3) / 1e12
                 res["attention"] = {"kernel": ak, "achieved": tf, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TFLOPS, "avg_launch_ms": att[ak]["ms"] / att[ak]["launches"],
                                     "launches_measured": att[ak]["launches"], "ms_per_batch": att[ak]["ms"] / reps, "flops_per_launch": att[ak]["flops"] / att[ak]["launches"],
-                                    "traffic": pmc.get(ak, {}).get("hbm_bytes_per_launch"), "traffic_source": pmc_file}
+                                    "traffic": pmc.get(ak, {}).get("hbm_bytes_per_launch"), "traffic_source": pmc_file, **sq_fields(sq, sq_file, ak)}
             tot = sum(v["ms"] for v in prof.values())
             res["time_breakdown_ms_per_batch"] = {k: round(v["ms"] / reps, 3) for k, v in prof.items() if v["launches"]}
             res["time_breakdown_ms_per_batch"]["_sum"] = round(tot / reps, 3)

@@ -23,7 +23,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/${PFX}_pmc_$c -- python3 bench.py $WARGS --streams 1 --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-secondary --no-decode-tail > /dev/null 2> gpurun_out/${PFX}_pmc_$c.log
 done
 python3 scripts/pmc_traffic.py gpurun_out/${PFX}_pmc_FETCH_SIZE gpurun_out/${PFX}_pmc_WRITE_SIZE gpurun_out/${PFX}_pmc_traffic.json $STAMP $DT | tail -20
-rm -rf gpurun_out/${PFX}_prof gpurun_out/${PFX}_pmc_FETCH_SIZE gpurun_out/${PFX}_pmc_WRITE_SIZE
+# SQ pass (matrix-pipe busy cycles, wave states) and GRBM pass (busy cycles -> effective clock) over the same product library: scripts/pmc_sq.py
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${PFX}_pmc_SQ -- python3 bench.py $WARGS --streams 1 --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-secondary --no-decode-tail > /dev/null 2> gpurun_out/${PFX}_pmc_SQ.log
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${PFX}_pmc_GRBM -- python3 bench.py $WARGS --streams 1 --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-secondary --no-decode-tail > /dev/null 2> gpurun_out/${PFX}_pmc_GRBM.log
+python3 scripts/pmc_sq.py gpurun_out/${PFX}_pmc_SQ gpurun_out/${PFX}_pmc_GRBM gpurun_out/${PFX}_kernel_stats.csv gpurun_out/${PFX}_pmc_sq.json $STAMP $DT | tail -24
+cp gpurun_out/${PFX}_pmc_sq.json profiles/${PFX}_pmc_sq.json
+rm -rf gpurun_out/${PFX}_prof gpurun_out/${PFX}_pmc_FETCH_SIZE gpurun_out/${PFX}_pmc_WRITE_SIZE gpurun_out/${PFX}_pmc_SQ gpurun_out/${PFX}_pmc_GRBM
 cp gpurun_out/${PFX}_pmc_traffic.json profiles/${PFX}_pmc_traffic.json   # so that the bench run below finds the stamped profile
 if [ "$WL" = alpha256 ]; then
   python3 bench.py > gpurun_out/${PFX}_bench.json 2> gpurun_out/${PFX}_bench.err

@@ -45,7 +45,7 @@ def classify_flux(name: str, tiles: int) -> str | None:
             (1, t(9216, 12288)): "gemm_single_mlp_gelu", (2, t(9216, 3072)): "gemm_single_proj_out",
         }
         return table.get((epi, tiles))
-    if "attn128_kernel" in name or "attn_kernel" in name or "attn_dma_kernel" in name:
+    if "attn128_kernel" in name or "attn_kernel" in name or "attn_dma_kernel" in name or "attn_w4a_kernel" in name:
         return "attn_joint"
     if "flux_ln_modulate" in name:
         return "ln_modulate"

@@ -204,14 +204,20 @@ ECAD_DEV void fgemm_mainloop(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
 }
 
 // bias / activation / rounding through the LDS C tile, then the row pass (plain store, gated residual, RoPE ...); shared with fgemm8.h
-template <typename T, int BN, int EPI>
-ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, f32x4 (&acc)[4][BN / 32]) {
-  [[maybe_unused]] constexpr int BM = 256, NW = 8, STAGES = fgemm_stages<BN>();
-  constexpr int FM = 4, FN = BN / 32;  // wave tile 64 x BN/2
+// Generic in the wave geometry: NW = 8 waves as 4 (M) x 2 (N) of 64 x BN/2 (fgemm_kernel, fgemm8_kernel), or NW = 4 waves as 2 x 2 of 128 x BN/2 (gemm4.h: the
+// accumulators live in a[0:255] and come back through `acc(i, j)`, i and j integral constants).  acc(i, j)[r] = row 16 i + (lane & 15), column 16 j + 4 (lane >> 4) + r
+// of the wave's block.
+template <typename T, int BN, int EPI, int NW, typename AccFn>
+ECAD_DEV void fgemm_epilogue_g(const FGemmArgs<T>& p, char* smem, int m0, int n0, AccFn&& acc) {
+  [[maybe_unused]] constexpr int BM = 256;
+  constexpr int WM = NW / 2;                    // waves along M (two along N)
+  constexpr int FM = BM / WM / 16, FN = BN / 32;  // wave tile (256 / WM) x BN/2
+  constexpr int WROWS = BM / WM;                // rows of a wave's block
+  constexpr int RPW = BM / NW;                  // rows a wave streams in the row pass
   constexpr int CS = BN + 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WM, wn = wave / WM;
   const int l15 = lane & 15, g = lane >> 4;
   // ---- direct epilogue of the GELU tiles (round 3, gemm2w.h has the description): FF1 of the joint blocks and the proj_mlp columns of the single blocks' stacked GEMM
   if constexpr (EPI == FEPI_BIAS_GELU || EPI == FEPI_QKV_ROPE_MLP) {
@@ -225,65 +231,68 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
         bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * (BN / 2) + 16 * j + 4 * g);
       }
-      auto cvt = [&](int i, int j) {
-        const f32x2 v01 = gelu_tanh2((f32x2){acc[i][j][0] + bvs[j][0], acc[i][j][1] + bvs[j][1]});
-        const f32x2 v23 = gelu_tanh2((f32x2){acc[i][j][2] + bvs[j][2], acc[i][j][3] + bvs[j][3]});
+      auto cvt = [&](auto ic, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const f32x4 av = acc(ic, jc);
+        const f32x2 v01 = gelu_tanh2((f32x2){av[0] + bvs[j][0], av[1] + bvs[j][1]});
+        const f32x2 v23 = gelu_tanh2((f32x2){av[2] + bvs[j][2], av[3] + bvs[j][3]});
         Pack4 o;
         float_to_elem4<T>(o, 0, v01[0]); float_to_elem4<T>(o, 1, v01[1]); float_to_elem4<T>(o, 2, v23[0]); float_to_elem4<T>(o, 3, v23[1]);
         return o;
       };
       static_assert(FN % 2 == 0, "fragment pairs");
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + l15;
+      static_for<FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = m0 + wm * WROWS + 16 * i + l15;
         T* crow = cbase + (size_t)(m < p.M ? m : 0) * ld + c0;
-#pragma unroll
-        for (int j = 0; j < FN; j += 2) {
-          Pack4 a = cvt(i, j), b = cvt(i, j + 1);
+        static_for<FN / 2>([&](auto jh) {
+          constexpr int j = 2 * decltype(jh)::value;
+          Pack4 a = cvt(ic, std::integral_constant<int, j>{}), b = cvt(ic, std::integral_constant<int, j + 1>{});
           asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[0]), "+v"(b.u[0]));
           asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[1]), "+v"(b.u[1]));
           Pack8 v;
           v.u = (u32x4){a.u[0], a.u[1], b.u[0], b.u[1]};
           if (m < p.M) gstore16(crow + 16 * (j + (g & 1)) + 8 * (g >> 1), v);
-        }
-      }
+        });
+      });
       return;
     }
   }
   // ---- epilogue 1: wave's 64 x BN/2 block -> row-major C tile in LDS (bias, activation, rounding)
   T* ctile = reinterpret_cast<T*>(smem);
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
+  static_for<FN>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     const int nl = wn * (BN / 2) + 16 * j + 4 * g;
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int ml = wm * 64 + 16 * i + l15;
+    static_for<FM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int ml = wm * WROWS + 16 * i + l15;
+      const f32x4 av = acc(ic, jc);
       Pack4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv[r];
+        float v = av[r] + bv[r];
         if (EPI == FEPI_BIAS_GELU || (EPI == FEPI_QKV_ROPE_MLP && n0 >= p.n_split)) v = gelu_tanh(v);
         if (EPI == FEPI_BIAS_SILU) v = silu(v);
         float_to_elem4<T>(o, r, v);
       }
       *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
-    }
-  }
+    });
+  });
   __syncthreads();
 
-  // ---- epilogue 2: wave w streams rows 32w .. 32w+31 in 16-byte chunks
+  // ---- epilogue 2: wave w streams rows RPW w .. RPW w + RPW - 1 in 16-byte chunks
   constexpr int CPR = BN / 8;
-  constexpr int CHUNKS = 32 * CPR;
+  constexpr int CHUNKS = RPW * CPR;
   if (EPI == FEPI_BIAS_GATE_RESID) {
     // 64 % CPR == 0: a lane keeps its column chunk for all its rows.  All hidden-state chunks of the wave's 32 rows are requested in
     // one batch (inside a loop each load would wait behind the previous row's store to the same buffer), and the gate of a strip that
-    // lies in one sample and segment is fetched once per lane instead of once per chunk.
+    // lies in one sample and segment is fetched once per lane instead of once per chunk.  (The strip = the RPW rows this wave streams.)
     constexpr int NIT = CHUNKS / 64, RSTEP = 64 / CPR;
     const int cchunk = lane % CPR, rl0 = lane / CPR;
     const int n = n0 + cchunk * 8;
-    const int mw = m0 + wave * 32;
+    const int mw = m0 + wave * RPW;
     Pack8 hpre[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -291,7 +300,7 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
       m = m < p.M ? m : p.M - 1;
       hpre[it] = gload16(p.resid + (size_t)m * p.ldr + n);
     }
-    const int m_last = (mw + 31 < p.M ? mw + 31 : p.M - 1);
+    const int m_last = (mw + RPW - 1 < p.M ? mw + RPW - 1 : p.M - 1);
     const int b_first = seg_batch(mw < p.M ? mw : p.M - 1, p.seg0, p.rows_per_batch0, p.rows_per_batch1);
     const bool uni = p.gate && (mw < p.seg0) == (m_last < p.seg0) && b_first == seg_batch(m_last, p.seg0, p.rows_per_batch0, p.rows_per_batch1);
     float gu[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -299,7 +308,7 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int rl = rl0 + it * RSTEP;
-      const int ml = wave * 32 + rl;
+      const int ml = wave * RPW + rl;
       const int m = m0 + ml;
       if (m >= p.M) continue;
       Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
@@ -331,7 +340,7 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
   }
   for (int id = lane; id < CHUNKS; id += 64) {
     const int rl = id / CPR, cchunk = id - rl * CPR;
-    const int ml = wave * 32 + rl;
+    const int ml = wave * RPW + rl;
     const int m = m0 + ml;
     if (m >= p.M) continue;
     const int n = n0 + cchunk * 8;
@@ -399,6 +408,12 @@ ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, 
       gstore16(p.C + (size_t)m * p.ldc + n, v);
     }
   }
+}
+
+
+template <typename T, int BN, int EPI>
+ECAD_DEV void fgemm_epilogue(const FGemmArgs<T>& p, char* smem, int m0, int n0, f32x4 (&acc)[4][BN / 32]) {
+  fgemm_epilogue_g<T, BN, EPI, 8>(p, smem, m0, n0, [&](auto ic, auto jc) -> f32x4 { return acc[decltype(ic)::value][decltype(jc)::value]; });
 }
 
 // tile id -> (tm, tn): blocks b, b + 8 share an XCD, so each XCD gets a contiguous run of ids; 4 x 4 patches inside the run

@@ -36,6 +36,7 @@
 #include "fgemm.h"
 #include "fgemm8.h"
 #include "flux_kernels.h"
+#include "gemm4.h"
 
 namespace ecad {
 
@@ -212,6 +213,7 @@ template <typename T> class FluxT : public FluxBase {
   // attention kernel scale 1.
   bool attn_w4 = true;
   bool attn_w4_attr = false;
+  bool gemm4_on = true;   // gemm4.h for the 256-column tiles; ECAD_FLUX_GEMM=8wave restores fgemm_kernel<256> (same results)
   float q_fold() const { return attn_w4 ? (float)(1.4426950408889634 / sqrt((double)DH)) : 0.f; }
   const void* call_in = nullptr;
   void* call_out = nullptr;
@@ -346,6 +348,7 @@ template <typename T> class FluxT : public FluxBase {
     { hipDeviceProp_t pr; FHIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     if (const char* e = getenv("ECAD_FLUX_FP8")) fp8 = atoi(e) != 0;
     if (const char* e = getenv("ECAD_FLUX_ATTN")) attn_w4 = strcmp(e, "dma") != 0;
+    if (const char* e = getenv("ECAD_FLUX_GEMM")) gemm4_on = strcmp(e, "8wave") != 0;
     FHIPCHK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
     FHIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     FHIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -395,6 +398,9 @@ template <typename T> class FluxT : public FluxBase {
     FATTR(256, FEPI_BIAS); FATTR(256, FEPI_BIAS_GELU); FATTR(256, FEPI_BIAS_GATE_RESID); FATTR(256, FEPI_BIAS_SILU);
     FATTR(128, FEPI_QKV_ROPE); FATTR(256, FEPI_QKV_ROPE); FATTR(128, FEPI_QKV_ROPE_MLP); FATTR(256, FEPI_QKV_ROPE_MLP);
 #undef FATTR
+#define F4ATTR(E) FHIPCHK(hipFuncSetAttribute((const void*)fgemm4_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES))
+    F4ATTR(FEPI_BIAS); F4ATTR(FEPI_BIAS_GELU); F4ATTR(FEPI_BIAS_GATE_RESID); F4ATTR(FEPI_BIAS_SILU); F4ATTR(FEPI_QKV_ROPE); F4ATTR(FEPI_QKV_ROPE_MLP);
+#undef F4ATTR
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
     FHIPCHK(hipFuncSetAttribute((const void*)attn128_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A128_LDS_BYTES));
@@ -929,6 +935,21 @@ template <typename T> class FluxT : public FluxBase {
   template <int BNT> int launch_gemm_bn(int epi, const FGemmArgs<T>& g, hipStream_t s) {
     const int tiles = ((g.M + 255) / 256) * (g.N / BNT);
     constexpr int lds = fgemm_lds_bytes<BNT>();
+    // gemm4.h: the same 256 x 256 tiles on four waves, one per SIMD, with the K loop as a hand-placed stream (round 5: +15-18 % on the block GEMM shapes, bit for
+    // bit fgemm_kernel<256>'s results); whole tiles and K segments in whole pairs of 64-deep stages.  Not the joint blocks' QKV projection: its RMSNorm + RoPE row pass
+    // is ALU-bound and takes twice as long on four waves as on eight, which eats the K loop's gain there (968 -> 939 TFLOP/s in the pipeline).
+    if (BNT == 256 && gemm4_on && epi != FEPI_QKV_ROPE && g.M % 256 == 0 && g.N % 256 == 0 && (g.A2 ? (g.k_split % 128 == 0 && (g.K - g.k_split) % 128 == 0) : g.K % 128 == 0)) {
+      switch (epi) {
+        case FEPI_BIAS: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
+        case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS_GELU>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
+        case FEPI_BIAS_GATE_RESID: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS_GATE_RESID>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
+        case FEPI_BIAS_SILU: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS_SILU>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
+        case FEPI_QKV_ROPE: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_QKV_ROPE>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
+        case FEPI_QKV_ROPE_MLP: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_QKV_ROPE_MLP>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
+        default: return fail(ECAD_E_INVALID, "bad epilogue %d", epi);
+      }
+      return ECAD_OK;
+    }
     switch (epi) {
       case FEPI_BIAS: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS>), dim3(tiles), dim3(512), lds, s, g); break;
       case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(512), lds, s, g); break;

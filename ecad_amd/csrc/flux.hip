@@ -398,8 +398,9 @@ template <typename T> class FluxT : public FluxBase {
     FATTR(256, FEPI_BIAS); FATTR(256, FEPI_BIAS_GELU); FATTR(256, FEPI_BIAS_GATE_RESID); FATTR(256, FEPI_BIAS_SILU);
     FATTR(128, FEPI_QKV_ROPE); FATTR(256, FEPI_QKV_ROPE); FATTR(128, FEPI_QKV_ROPE_MLP); FATTR(256, FEPI_QKV_ROPE_MLP);
 #undef FATTR
-#define F4ATTR(E) FHIPCHK(hipFuncSetAttribute((const void*)fgemm4_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES))
-    F4ATTR(FEPI_BIAS); F4ATTR(FEPI_BIAS_GELU); F4ATTR(FEPI_BIAS_GATE_RESID); F4ATTR(FEPI_BIAS_SILU); F4ATTR(FEPI_QKV_ROPE); F4ATTR(FEPI_QKV_ROPE_MLP);
+#define F4ATTR(BN, E) FHIPCHK(hipFuncSetAttribute((const void*)fgemm4_kernel<T, BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<BN>()))
+    F4ATTR(256, FEPI_BIAS); F4ATTR(256, FEPI_BIAS_GELU); F4ATTR(256, FEPI_BIAS_GATE_RESID); F4ATTR(256, FEPI_BIAS_SILU); F4ATTR(256, FEPI_QKV_ROPE_MLP);
+    F4ATTR(128, FEPI_BIAS); F4ATTR(128, FEPI_BIAS_GELU); F4ATTR(128, FEPI_BIAS_GATE_RESID); F4ATTR(128, FEPI_BIAS_SILU); F4ATTR(128, FEPI_QKV_ROPE_MLP);
 #undef F4ATTR
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
     FHIPCHK(hipFuncSetAttribute((const void*)attn_kernel<T, 128, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<128, 128>()));
@@ -494,6 +495,10 @@ template <typename T> class FluxT : public FluxBase {
       F8ATTR(128, FEPI_BIAS); F8ATTR(128, FEPI_BIAS_GELU); F8ATTR(128, FEPI_BIAS_GATE_RESID); F8ATTR(128, FEPI_QKV_ROPE); F8ATTR(128, FEPI_QKV_ROPE_MLP);
       F8ATTR(256, FEPI_BIAS); F8ATTR(256, FEPI_BIAS_GELU); F8ATTR(256, FEPI_BIAS_GATE_RESID); F8ATTR(256, FEPI_QKV_ROPE); F8ATTR(256, FEPI_QKV_ROPE_MLP);
 #undef F8ATTR
+#define F48ATTR(BN, E) FHIPCHK(hipFuncSetAttribute((const void*)fgemm48_kernel<T, BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<BN>()))
+      F48ATTR(128, FEPI_BIAS); F48ATTR(128, FEPI_BIAS_GELU); F48ATTR(128, FEPI_BIAS_GATE_RESID); F48ATTR(128, FEPI_QKV_ROPE_MLP);
+      F48ATTR(256, FEPI_BIAS); F48ATTR(256, FEPI_BIAS_GELU); F48ATTR(256, FEPI_BIAS_GATE_RESID); F48ATTR(256, FEPI_QKV_ROPE_MLP);
+#undef F48ATTR
       f8_engine_attr = f8_attr = true;
     }
     int64_t extra = 0;
@@ -935,17 +940,17 @@ template <typename T> class FluxT : public FluxBase {
   template <int BNT> int launch_gemm_bn(int epi, const FGemmArgs<T>& g, hipStream_t s) {
     const int tiles = ((g.M + 255) / 256) * (g.N / BNT);
     constexpr int lds = fgemm_lds_bytes<BNT>();
-    // gemm4.h: the same 256 x 256 tiles on four waves, one per SIMD, with the K loop as a hand-placed stream (round 5: +15-18 % on the block GEMM shapes, bit for
-    // bit fgemm_kernel<256>'s results); whole tiles and K segments in whole pairs of 64-deep stages.  Not the joint blocks' QKV projection: its RMSNorm + RoPE row pass
-    // is ALU-bound and takes twice as long on four waves as on eight, which eats the K loop's gain there (968 -> 939 TFLOP/s in the pipeline).
-    if (BNT == 256 && gemm4_on && epi != FEPI_QKV_ROPE && g.M % 256 == 0 && g.N % 256 == 0 && (g.A2 ? (g.k_split % 128 == 0 && (g.K - g.k_split) % 128 == 0) : g.K % 128 == 0)) {
+    // gemm4.h: the same tiles on four waves, one per SIMD, with the K loop as a hand-placed stream (round 5: +15-18 % on the 256-column block GEMM shapes, bit for bit
+    // the 8-wave kernel's results); whole tiles and K segments in whole trips of its loop.  Not the joint blocks' QKV projection: its RMSNorm + RoPE row pass is
+    // ALU-bound and takes twice as long on four waves as on eight, which eats the K loop's gain there (968 -> 939 TFLOP/s in the pipeline).
+    if (gemm4_on && epi != FEPI_QKV_ROPE && g4_shape_ok<T>(g, BNT)) {
+      constexpr int lds4 = g4_lds_bytes<BNT>();
       switch (epi) {
-        case FEPI_BIAS: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
-        case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS_GELU>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
-        case FEPI_BIAS_GATE_RESID: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS_GATE_RESID>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
-        case FEPI_BIAS_SILU: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_BIAS_SILU>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
-        case FEPI_QKV_ROPE: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_QKV_ROPE>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
-        case FEPI_QKV_ROPE_MLP: hipLaunchKernelGGL((fgemm4_kernel<T, FEPI_QKV_ROPE_MLP>), dim3(tiles), dim3(256), G4_LDS_BYTES, s, g); break;
+        case FEPI_BIAS: hipLaunchKernelGGL((fgemm4_kernel<T, BNT, FEPI_BIAS>), dim3(tiles), dim3(256), lds4, s, g); break;
+        case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm4_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(256), lds4, s, g); break;
+        case FEPI_BIAS_GATE_RESID: hipLaunchKernelGGL((fgemm4_kernel<T, BNT, FEPI_BIAS_GATE_RESID>), dim3(tiles), dim3(256), lds4, s, g); break;
+        case FEPI_BIAS_SILU: hipLaunchKernelGGL((fgemm4_kernel<T, BNT, FEPI_BIAS_SILU>), dim3(tiles), dim3(256), lds4, s, g); break;
+        case FEPI_QKV_ROPE_MLP: hipLaunchKernelGGL((fgemm4_kernel<T, BNT, FEPI_QKV_ROPE_MLP>), dim3(tiles), dim3(256), lds4, s, g); break;
         default: return fail(ECAD_E_INVALID, "bad epilogue %d", epi);
       }
       return ECAD_OK;
@@ -1246,6 +1251,17 @@ template <typename T> class FluxT : public FluxBase {
   template <int BNT> int launch_gemm8_bn(int epi, const FGemm8Args<T>& q, hipStream_t s) {
     const int tiles = ((q.e.M + 255) / 256) * (q.e.N / BNT);
     constexpr int lds = fgemm_lds_bytes<BNT>();
+    if (gemm4_on && f8_engine_attr && epi != FEPI_QKV_ROPE && g4_shape_ok_fp8(q.e.M, q.e.N, q.e.K, BNT)) {  // gemm4.h, e4m3 loops (same tiles, K order and epilogue: same bits)
+      constexpr int lds4 = g4_lds_bytes<BNT>();
+      switch (epi) {
+        case FEPI_BIAS: hipLaunchKernelGGL((fgemm48_kernel<T, BNT, FEPI_BIAS>), dim3(tiles), dim3(256), lds4, s, q); break;
+        case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm48_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(256), lds4, s, q); break;
+        case FEPI_BIAS_GATE_RESID: hipLaunchKernelGGL((fgemm48_kernel<T, BNT, FEPI_BIAS_GATE_RESID>), dim3(tiles), dim3(256), lds4, s, q); break;
+        case FEPI_QKV_ROPE_MLP: hipLaunchKernelGGL((fgemm48_kernel<T, BNT, FEPI_QKV_ROPE_MLP>), dim3(tiles), dim3(256), lds4, s, q); break;
+        default: return fail(ECAD_E_INVALID, "no fp8 instantiation for epilogue %d", epi);
+      }
+      return ECAD_OK;
+    }
     switch (epi) {
       case FEPI_BIAS: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_BIAS>), dim3(tiles), dim3(512), lds, s, q); break;
       case FEPI_BIAS_GELU: hipLaunchKernelGGL((fgemm8_kernel<T, BNT, FEPI_BIAS_GELU>), dim3(tiles), dim3(512), lds, s, q); break;

@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
-"""Generator of the hand-placed K loop of the one-wave-per-SIMD GEMM (ecad_amd/csrc/gemm4_asm.h): C[256 x 256] += A[256 x K] W[256 x K]^T per workgroup.
+"""Generator of the hand-placed K loops of the one-wave-per-SIMD GEMMs (ecad_amd/csrc/gemm4_asm.h): C[256 x BN] += A[256 x K] W[BN x K]^T per workgroup.
 
 Why: the 8-wave GEMMs of this tree (fgemm.h 64 x 128 wave tiles, gemm2w.h 64 x 144) read 22-23 bytes of LDS per KFLOP and issue their MFMAs 65-72 % of the time
 under hipcc's schedule; the attention kernel of round 5 (attention_w4.h) showed what a hand-placed one-wave-per-SIMD stream does on this chip (789 -> 1207 TFLOP/s
-for the same algorithm, 22 % less energy per flop).  Here: 4 waves as 2 x 2, a wave owns 128 x 128 of the tile -- 8 x 8 accumulator fragments of
-v_mfma_f32_16x16x32 in a[0:255] -- so a 32-deep K step reads 8 A + 8 W fragments (16 KiB) for 64 MFMAs: 15.6 B/KFLOP, a third less than the 8-wave tile.
-Stages of 64 K elements (A rows then W rows, 128-byte rows, 16-byte pieces XOR-swizzled by (row >> 1) & 7 on the DMA source side: the layout of fgemm.h) arrive
-by LDS-DMA into a two-slot ring; one barrier per stage; fragment reads run one 32-deep sub-step ahead of their MFMAs in two register sets.
+for the same algorithm, 22 % less energy per flop).  Here: 4 waves as 2 x 2, a wave owns 128 x BN/2 of the tile -- 8 x BN/32 accumulator fragments of
+v_mfma_f32_16x16x32 (16-bit operands) or v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 operands, unit block scales: fgemm8.h) in AGPRs; at BN = 256 a 32-deep K step
+reads 8 A + 8 W fragments (16 KiB) for 64 MFMAs: 15.6 B/KFLOP, a third less than the 8-wave tile.
+Stages of 128 bytes of K per row (64 16-bit or 128 e4m3 elements: A rows then W rows, 16-byte pieces XOR-swizzled by (row >> 1) & 7 on the DMA source side: the
+layout of fgemm.h / fgemm8.h) arrive by LDS-DMA into a ring of NS slots (2 at BN 256: 128 KiB; 3 at BN 128: 144 KiB); ONE barrier per stage behind a counted
+s_waitcnt vmcnt; fragment reads run ahead of their MFMAs in register sets that alternate.
 
-The statement leaves the accumulators in a[0:255] (fragment (i, j) = a[4 (8 i + j) ..]: element r is row m = 16 i + (lane & 15), column n = 16 j + 4 (lane >> 4) + r
-of the wave's 128 x 128 block -- the orientation of fgemm.h's acc[i][j]) and the C++ epilogue reads them with v_accvgpr_read statements (gemm4.h).
+The statement leaves the accumulators in AGPRs (fragment (i, j) = a[4 (8 i + j) ..]: element r is row m = 16 i + (lane & 15), column n = 16 j + 4 (lane >> 4) + r
+of the wave's block -- the orientation of fgemm.h's acc[i][j]) and the C++ epilogue reads them with v_accvgpr_read statements (gemm4.h).
 
-Register map: a[0:255] accumulators; v[0:63] fragment set X (A 0..7, W 0..7), v[64:127] set Y; v[128:131] A read addresses [stage][sub-step], v[132:135] W read
-addresses; v[136:143] DMA lane offsets A [piece], v[144:151] W [piece]; v[152:159] temporaries.
+Measured on the FLUX shapes (scripts/probe_gemm4.hip, bf16, BN 256, TFLOP/s at 9216 x 21504 x 3072 / 8192 x 12288 x 3072; fgemm_kernel<256>: 1258 / 1251):
+   DMA pieces every 2nd MFMA of sub-step 0, barrier after MFMA 29 of sub-step 1, reads every 2nd MFMA behind it   1378 / 1354
+   DMA every 4th (the whole sub-step), barrier after MFMA 45, one read per MFMA behind it                          1453 / 1479   <- product
+   DMA every 3rd, barrier 45                                                                                      1434 / 1460
+   DMA every 2nd, barrier 45                                                                                      1374 / 1387
 """
 from __future__ import annotations
 
@@ -20,13 +25,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-SETX, SETY = 0, 64
-AADR, WADR = 128, 132
-AOFF, WOFF = 136, 144
-TMP = 152
-NV = 160
-STAGE = 65536          # bytes per ring slot: (256 + 256) rows x 128 B
-SG = dict(loop=60, ldsw=61, ap=62, ap_hi=63, wp=64, wp_hi=65, m0save=66, tmp0=67, tmp1=68)
+SG = dict(loop=60, ldsw=61, ap=62, ap_hi=63, wp=64, wp_hi=65, m0save=66, tmp0=67, tmp1=68, ldsw2=69)
 
 
 def s(n):
@@ -46,12 +45,42 @@ def a(i, n=1):
 
 
 class Gen:
-    def __init__(self, dtype, dma_stride=2, barrier_at=29, reads_per_mfma_after=0.5):
-        self.dma_stride, self.barrier_at, self.rpm = dma_stride, barrier_at, reads_per_mfma_after
-        self.dt = dtype
-        self.mfma = f"v_mfma_f32_16x16x32_{dtype}"
-        self.lines = []
-        self.q = []
+    """dtype bf16 | f16: two 32-deep sub-steps per 64-element stage, fragments of 4 registers, two whole fragment sets alternate.
+    dtype fp8: one 128-deep step per stage, fragments of 8 registers (two 16-byte reads), A in two alternating sets, W in a rolling window of four."""
+
+    def __init__(self, dtype, bn):
+        self.dt, self.BN = dtype, bn
+        self.fp8 = dtype == "fp8"
+        self.FN = bn // 32                       # W fragments per wave (wave tile 128 x BN/2)
+        self.NS = 2 if bn == 256 else 3          # ring slots
+        self.STAGE = (256 + bn) * 128
+        self.WP = bn // 8 // 4                   # W pieces per wave and stage
+        self.NP = 8 + self.WP                    # DMA pieces per wave and stage
+        self.NM = 8 * self.FN                    # MFMAs per (sub-)step
+        self.AX = 0
+        if self.fp8:
+            self.AY, self.WB = 64, 128            # A sets X / Y (8 x 8 registers), W window 4 x 8
+            nxt = 160
+        else:
+            self.WX, self.AY = 32, 32 + 4 * self.FN
+            self.WY = self.AY + 32
+            nxt = self.WY + 4 * self.FN
+        self.AADR = nxt                           # [slot][2]: sub-step 0 / 1 (16-bit) or low / high 16-byte half (e4m3)
+        self.WADR = self.AADR + 2 * self.NS
+        self.AOFF = self.WADR + 2 * self.NS
+        self.WOFF = self.AOFF + 8
+        self.TMP = self.WOFF + self.WP
+        self.SC = self.TMP + 8                    # e4m3: the unit block scale
+        self.NV = self.SC + 1
+        self.lines, self.q = [], []
+        self.mfma = "v_mfma_scale_f32_16x16x128_f8f6f4" if self.fp8 else f"v_mfma_f32_16x16x32_{dtype}"
+        nreads = 10 if self.fp8 else 8 + self.FN   # read groups behind the barrier
+        self.barrier_at = self.NM - nreads - 3
+        # every piece of a stage is issued BEFORE the barrier of the (sub-)step that carries it: the counted vmcnt there relies on it.  16-bit: sub-step 0 carries the
+        # pieces, sub-step 1 the barrier; e4m3: one step carries both
+        self.dma_stride = max(1, (self.barrier_at // self.NP) if self.fp8 else (self.NM // self.NP))
+        assert self.dma_stride * (self.NP - 1) < (self.barrier_at if self.fp8 else self.NM)
+        self.period = self.NS if (not self.fp8 or self.NS % 2 == 0) else 2 * self.NS
 
     def I(self, t):
         self.lines.append("\t" + t)
@@ -74,69 +103,123 @@ class Gen:
         self.I(f"s_waitcnt lgkmcnt({min(after, 15)})")
         self.q = self.q[last + 1:]
 
-    def frag_read(self, which, f, stage, sub, fset):
-        """fragment f (0..7) of A ('a') or W ('w') for K sub-step `sub` of ring slot `stage` into register set fset"""
-        base = fset + (0 if which == "a" else 32) + 4 * f
-        adr = (AADR if which == "a" else WADR) + 2 * stage + sub
-        self.ds(f"ds_read_b128 {v(base, 4)}, {v(adr)} offset:{f * 2048}", f"{fset}{which}{f}")
-
-    def dma_piece(self, which, p, stage):
-        off = (AOFF if which == "a" else WOFF) + p
+    def dma_piece(self, which, p, slot):
+        off = (self.AOFF if which == "a" else self.WOFF) + p
         ptr = "ap" if which == "a" else "wp"
-        imm = stage * STAGE + (0 if which == "a" else 32768) + p * 1024
-        return [f"s_add_u32 m0, {s('ldsw')}, {imm}", "s_nop 0", f"global_load_lds_dwordx4 {v(off)}, {s2(ptr)}"]
+        base = "ldsw" if which == "a" else "ldsw2"
+        imm = slot * self.STAGE + (0 if which == "a" else 32768) + p * 1024
+        return [f"s_add_u32 m0, {s(base)}, {imm}", "s_nop 0", f"global_load_lds_dwordx4 {v(off)}, {s2(ptr)}"]
 
-    def substep(self, stage, sub, cur, nxt, fillers, reads_next, barrier_at=None, after_barrier_reads=None):
-        """64 MFMAs of one 32-deep sub-step from register set `cur`; `reads_next` = list of (which, f, stage, sub) issued one per two MFMAs into set `nxt`;
-        `fillers` = dict MFMA index -> instruction list; at MFMA `barrier_at`: drain + barrier, after which `after_barrier_reads` are issued"""
-        rd = list(reads_next)
-        ab = list(after_barrier_reads or [])
+    def advance(self):
+        return [f"s_add_u32 {s('ap')}, {s('ap')}, 128", f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, 0", f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"]
+
+    def dma_stage(self, slot):
+        out = {}
+        k = 0
+        for which, n in (("a", 8), ("w", self.WP)):
+            for p in range(n):
+                out[self.dma_stride * k] = self.dma_piece(which, p, slot)
+                k += 1
+        last = self.NM - 1
+        out[last] = out.get(last, []) + self.advance()
+        return out
+
+    # ------------------------------------------------------------------ 16-bit operands
+    def frag_read16(self, which, f, slot, sub, aset, wset):
+        base = (aset + 4 * f) if which == "a" else (wset + 4 * f)
+        adr = (self.AADR if which == "a" else self.WADR) + 2 * slot + sub
+        self.ds(f"ds_read_b128 {v(base, 4)}, {v(adr)} offset:{f * 2048}", f"{aset}{which}{f}")
+
+    def order16(self):
+        return [("w", 0)] + [("a", i) for i in range(8)] + [("w", j) for j in range(1, self.FN)]
+
+    def substep16(self, aset, wset, naset, nwset, fillers, reads_next, barrier=None, after_barrier_reads=None):
+        rd, ab = list(reads_next), list(after_barrier_reads or [])
         n = 0
-        for j in range(8):            # W fragment j with every A fragment: the W operand stays, accumulators a[4 (8 i + j)]
+        for j in range(self.FN):
             for i in range(8):
                 if i == 0:
-                    self.need(f"{cur}w{j}")
+                    self.need(f"{aset}w{j}")
                 if j == 0:
-                    self.need(f"{cur}a{i}")
+                    self.need(f"{aset}a{i}")
                 acc = 4 * (8 * i + j)
-                self.I(f"{self.mfma} {a(acc, 4)}, {v(cur + 32 + 4 * j, 4)}, {v(cur + 4 * i, 4)}, {a(acc, 4)}")
+                self.I(f"{self.mfma} {a(acc, 4)}, {v(wset + 4 * j, 4)}, {v(aset + 4 * i, 4)}, {a(acc, 4)}")
                 for t in fillers.get(n, []):
                     self.I(t)
-                if barrier_at is not None and n == barrier_at:
-                    self.I("s_waitcnt vmcnt(0)")
+                if barrier is not None and n == barrier[0]:
+                    self.I(f"s_waitcnt vmcnt({barrier[1]})")
                     self.I("s_waitcnt lgkmcnt(0)")
                     self.q = []
                     self.I("s_barrier")
-                if rd and n % 2 == 1 and (barrier_at is None or n < barrier_at):
-                    self.frag_read(*rd.pop(0), nxt)
-                elif ab and barrier_at is not None and n > barrier_at and (self.rpm >= 1 or n % 2 == 1):
-                    self.frag_read(*ab.pop(0), nxt)
+                if rd and n % 2 == 1 and (barrier is None or n < barrier[0]):
+                    self.frag_read16(*rd.pop(0), naset, nwset)
+                elif ab and barrier is not None and n > barrier[0]:
+                    self.frag_read16(*ab.pop(0), naset, nwset)
                 n += 1
         assert not rd and not ab, (len(rd), len(ab))
 
-    def step(self, stage, last):
-        """one 64-deep stage: sub-step 0 from set X (already read), its MFMAs carry the DMA of the next stage and the reads of sub-step 1 into set Y;
-        sub-step 1 from set Y carries the barrier and the reads of the next stage's sub-step 0 into set X"""
-        nst = stage ^ 1
-        fill = {}
-        if not last:
-            k = 0
-            for which in ("a", "w"):
-                for p in range(8):
-                    fill[self.dma_stride * k] = self.dma_piece(which, p, nst)
-                    k += 1
-            fill[63] = fill.get(63, []) + [f"s_add_u32 {s('ap')}, {s('ap')}, 128", f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, 0",
-                        f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"]
-        order = [("w", 0), ("a", 0), ("a", 1), ("a", 2), ("a", 3), ("a", 4), ("a", 5), ("a", 6), ("a", 7)] + [("w", j) for j in range(1, 8)]
-        self.substep(stage, 0, SETX, SETY, fill, [(w, f, stage, 1) for w, f in order])
+    def step16(self, slot, dma_slot, vm, last):
+        """one 64-deep stage of ring slot `slot`: sub-step 0 from set X carries the DMA of `dma_slot` (None: nothing left to fetch) and the reads of sub-step 1 into
+        set Y; sub-step 1 from set Y carries the barrier (vmcnt(vm)) and the reads of the next slot's sub-step 0 into set X"""
+        nslot = (slot + 1) % self.NS
+        fill = self.dma_stage(dma_slot) if dma_slot is not None else {}
+        self.substep16(self.AX, self.WX, self.AY, self.WY, fill, [(w, f, slot, 1) for w, f in self.order16()])
         if last:
-            self.substep(stage, 1, SETY, SETX, {}, [])
+            self.substep16(self.AY, self.WY, self.AX, self.WX, {}, [])
         else:
-            self.substep(stage, 1, SETY, SETX, {}, [], barrier_at=self.barrier_at, after_barrier_reads=[(w, f, nst, 0) for w, f in order])
+            self.substep16(self.AY, self.WY, self.AX, self.WX, {}, [], barrier=(self.barrier_at, vm), after_barrier_reads=[(w, f, nslot, 0) for w, f in self.order16()])
 
+    # ------------------------------------------------------------------ e4m3 operands
+    def a_read8(self, i, slot, aset):
+        for h in range(2):
+            self.ds(f"ds_read_b128 {v(aset + 8 * i + 4 * h, 4)}, {v(self.AADR + 2 * slot + h)} offset:{i * 2048}", f"{aset}a{i}" if h else f"{aset}a{i}lo")
+
+    def w_read8(self, j, slot):
+        base = self.WB + 8 * (j % 4)
+        for h in range(2):
+            self.ds(f"ds_read_b128 {v(base + 4 * h, 4)}, {v(self.WADR + 2 * slot + h)} offset:{j * 2048}", f"w{j}" if h else f"w{j}lo")
+
+    def step8(self, slot, dma_slot, vm, last, aset, naset):
+        """one 128-deep stage: W fragment j + 2 is requested when fragment j's MFMAs start (window of four); behind the barrier the next slot's A fragments (other
+        set) and its first two W fragments"""
+        nslot = (slot + 1) % self.NS
+        fill = self.dma_stage(dma_slot) if dma_slot is not None else {}
+        ab = [] if last else [("w", 0)] + [("a", i) for i in range(8)] + [("w", 1)]
+        n = 0
+        for j in range(self.FN):
+            for i in range(8):
+                if i == 0:
+                    self.need(f"w{j}")
+                    if j + 2 < self.FN:
+                        self.w_read8(j + 2, slot)
+                if j == 0:
+                    self.need(f"{aset}a{i}")
+                acc = 4 * (8 * i + j)
+                self.I(f"{self.mfma} {a(acc, 4)}, {v(self.WB + 8 * (j % 4), 8)}, {v(aset + 8 * i, 8)}, {a(acc, 4)}, {v(self.SC)}, {v(self.SC)} op_sel_hi:[0,0,0]")
+                for t in fill.get(n, []):
+                    self.I(t)
+                if not last and n == self.barrier_at:
+                    self.I(f"s_waitcnt vmcnt({vm})")
+                    self.I("s_waitcnt lgkmcnt(0)")
+                    self.q = []
+                    self.I("s_barrier")
+                if ab and n > self.barrier_at:
+                    # the window registers of W 0 / W 1 of the next stage are those of this stage's fragments FN-4 / FN-3: free once their MFMAs have been issued
+                    w, f = ab[0]
+                    free_at = 8 * (self.FN - 4 + f) + 7 if w == "w" else -1
+                    if n > free_at:
+                        ab.pop(0)
+                        if w == "a":
+                            self.a_read8(f, nslot, naset)
+                        else:
+                            self.w_read8(f, nslot)
+                n += 1
+        assert not ab, ab
+
+    # ------------------------------------------------------------------ whole statement
     def build(self):
-        I = self.I
-        T = TMP
+        I, T = self.I, self.TMP
+        NS = self.NS
         I(f"s_mov_b32 {s('m0save')}, m0")
         I(f"v_mbcnt_lo_u32_b32 {v(T)}, -1, 0")
         I(f"v_mbcnt_hi_u32_b32 {v(T)}, -1, {v(T)}")                 # lane
@@ -146,71 +229,95 @@ class Gen:
         I(f"s_and_b32 {s('tmp0')}, %[wave], 1")                     # wm
         I(f"s_lshr_b32 {s('tmp1')}, %[wave], 1")                    # wn
         I(f"s_lshl_b32 {s('tmp0')}, {s('tmp0')}, 14")               # wm * 128 rows * 128 B
-        I(f"s_lshl_b32 {s('tmp1')}, {s('tmp1')}, 14")
+        I(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {self.BN // 2 * 128}")   # wn * BN/2 rows * 128 B
         I(f"v_lshlrev_b32_e32 {v(T + 4)}, 7, {v(T + 1)}")           # l15 * 128
         I(f"v_add_u32_e32 {v(T + 4)}, %[lds], {v(T + 4)}")
-        for stage in range(2):
-            for sub in range(2):
-                I(f"v_add_u32_e32 {v(T + 5)}, {4 * sub}, {v(T + 2)}")            # piece 4 sub + g
+        for slot in range(NS):
+            for h in range(2):
+                # 16-bit: sub-step h reads piece 4 h + g; e4m3: the lane's 32 K-elements are pieces 2 g and 2 g + 1
+                if self.fp8:
+                    I(f"v_lshl_add_u32 {v(T + 5)}, {v(T + 2)}, 1, {h}")
+                else:
+                    I(f"v_add_u32_e32 {v(T + 5)}, {4 * h}, {v(T + 2)}")
                 I(f"v_xor_b32_e32 {v(T + 5)}, {v(T + 5)}, {v(T + 3)}")
                 I(f"v_lshl_add_u32 {v(T + 5)}, {v(T + 5)}, 4, {v(T + 4)}")
-                I(f"v_add_u32_e32 {v(AADR + 2 * stage + sub)}, {s('tmp0')}, {v(T + 5)}")
-                I(f"v_add_u32_e32 {v(WADR + 2 * stage + sub)}, {s('tmp1')}, {v(T + 5)}")
-                if stage:
-                    I(f"v_add_u32_e32 {v(AADR + 2 * stage + sub)}, {STAGE}, {v(AADR + 2 * stage + sub)}")
-                I(f"v_add_u32_e32 {v(WADR + 2 * stage + sub)}, {stage * STAGE + 32768}, {v(WADR + 2 * stage + sub)}")
-        # DMA lane offsets: piece q of this wave = piece 8 wave + q of the 32 (rows 8 (8 wave + q) + (lane >> 3)), position lane & 7 holds source piece
-        # position ^ ((row >> 1) & 7) = position ^ (((q & 1) << 2) | (lane >> 4))
+                I(f"v_add_u32_e32 {v(self.AADR + 2 * slot + h)}, {s('tmp0')}, {v(T + 5)}")
+                I(f"v_add_u32_e32 {v(self.WADR + 2 * slot + h)}, {s('tmp1')}, {v(T + 5)}")
+                if slot:
+                    I(f"v_add_u32_e32 {v(self.AADR + 2 * slot + h)}, {slot * self.STAGE}, {v(self.AADR + 2 * slot + h)}")
+                I(f"v_add_u32_e32 {v(self.WADR + 2 * slot + h)}, {slot * self.STAGE + 32768}, {v(self.WADR + 2 * slot + h)}")
+        # DMA lane offsets: piece q of this wave's share covers rows 8 (n wave + q) + (lane >> 3); position lane & 7 holds source piece position ^ ((row >> 1) & 7),
+        # (row >> 1) & 7 = (4 (n wave + q) + (lane >> 4)) & 7 = ((q & 1) << 2) | (lane >> 4) because 4 n wave is a multiple of 8 (n = 8 or 4)
         I(f"v_lshrrev_b32_e32 {v(T + 4)}, 3, {v(T)}")               # lane >> 3
         I(f"v_and_b32_e32 {v(T + 5)}, 7, {v(T)}")                   # position
-        I(f"s_lshl_b32 {s('tmp0')}, %[wave], 6")                    # first row of this wave's pieces
-        for q in range(8):
-            I(f"v_or_b32_e32 {v(T + 6)}, {(q & 1) << 2}, {v(T + 2)}")
-            I(f"v_xor_b32_e32 {v(T + 6)}, {v(T + 6)}, {v(T + 5)}")
-            I(f"v_lshlrev_b32_e32 {v(T + 6)}, 4, {v(T + 6)}")
-            I(f"v_add_u32_e32 {v(T + 7)}, {8 * q}, {v(T + 4)}")
-            I(f"v_add_u32_e32 {v(T + 7)}, {s('tmp0')}, {v(T + 7)}")
-            I(f"v_mad_u32_u24 {v(AOFF + q)}, {v(T + 7)}, %[rsa], {v(T + 6)}")
-            I(f"v_mad_u32_u24 {v(WOFF + q)}, {v(T + 7)}, %[rsw], {v(T + 6)}")
-        I(f"s_lshl_b32 {s('tmp0')}, %[wave], 13")                   # 8 pieces x 1 KiB
+        for which, n, off, rs in (("a", 8, self.AOFF, "%[rsa]"), ("w", self.WP, self.WOFF, "%[rsw]")):
+            I(f"s_mul_i32 {s('tmp0')}, %[wave], {8 * n}")            # first row of this wave's pieces
+            for q in range(n):
+                I(f"v_or_b32_e32 {v(T + 6)}, {(q & 1) << 2}, {v(T + 2)}")
+                I(f"v_xor_b32_e32 {v(T + 6)}, {v(T + 6)}, {v(T + 5)}")
+                I(f"v_lshlrev_b32_e32 {v(T + 6)}, 4, {v(T + 6)}")
+                I(f"v_add_u32_e32 {v(T + 7)}, {8 * q}, {v(T + 4)}")
+                I(f"v_add_u32_e32 {v(T + 7)}, {s('tmp0')}, {v(T + 7)}")
+                I(f"v_mad_u32_u24 {v(off + q)}, {v(T + 7)}, {rs}, {v(T + 6)}")
+        I(f"s_lshl_b32 {s('tmp0')}, %[wave], 13")                   # this wave's 8 A pieces
         I(f"s_add_u32 {s('ldsw')}, %[lds], {s('tmp0')}")
+        I(f"s_mul_i32 {s('tmp0')}, %[wave], {self.WP * 1024}")       # and its WP W pieces
+        I(f"s_add_u32 {s('ldsw2')}, %[lds], {s('tmp0')}")
         I(f"s_mov_b64 {s2('ap')}, %[ap]")
         I(f"s_mov_b64 {s2('wp')}, %[wp]")
+        if self.fp8:
+            I(f"v_mov_b32_e32 {v(self.SC)}, 0x7f7f7f7f")
         I("s_cmp_eq_u32 %[zero], 0")      # a second K segment (split-A GEMM: another A buffer for the rest of K) goes on accumulating
         I(f"s_cbranch_scc1 {self.lbl('KEEP')}")
-        for i in range(256):
-            I(f"v_accvgpr_write_b32 {a(i)}, 0")
+        for i in range(8):
+            for j in range(self.FN):
+                for r in range(4):
+                    I(f"v_accvgpr_write_b32 {a(4 * (8 * i + j) + r)}, 0")
         self.L("KEEP")
-        # stage 0 (ring slot 0), then the first fragment set
-        for which in ("a", "w"):
-            for p in range(8):
-                for t in self.dma_piece(which, p, 0):
-                    I(t)
-        for t in (f"s_add_u32 {s('ap')}, {s('ap')}, 128", f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, 0", f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"):
-            I(t)
-        I("s_waitcnt vmcnt(0)")
+        for slot in range(NS - 1):          # the first NS - 1 stages
+            for which, n in (("a", 8), ("w", self.WP)):
+                for p in range(n):
+                    for t in self.dma_piece(which, p, slot):
+                        I(t)
+            for t in self.advance():
+                I(t)
+        I(f"s_waitcnt vmcnt({self.NP * (NS - 2)})")
         I("s_barrier")
-        order = [("w", 0)] + [("a", i) for i in range(8)] + [("w", j) for j in range(1, 8)]
-        for w, f in order:
-            self.frag_read(w, f, 0, 0, SETX)
+        if self.fp8:
+            self.w_read8(0, 0)
+            for i in range(8):
+                self.a_read8(i, 0, self.AX)
+            self.w_read8(1, 0)
+        else:
+            for w, f in self.order16():
+                self.frag_read16(w, f, 0, 0, self.AX, self.WX)
         canonical = list(self.q)
-        # pairs of stages (ring slots 0, 1); %[pairs] = K / 128 - 1 full pairs, then the last pair without a successor for its second stage
-        I(f"s_mov_b32 {s('loop')}, %[pairs]")
+        # %[trips] = K stages / period - 1 full trips, then the last trip: its stages fetch nothing beyond the end of K
+        I(f"s_mov_b32 {s('loop')}, %[trips]")
         I(f"s_cmp_eq_u32 {s('loop')}, 0")
         I(f"s_cbranch_scc1 {self.lbl('LAST')}")
+        vm = self.NP * (NS - 2)
+
+        def emit(k, dma, vmc, last):
+            slot = k % NS
+            if self.fp8:
+                aset, naset = (self.AX, self.AY) if k % 2 == 0 else (self.AY, self.AX)
+                self.q = [f"{aset}{t[len(str(self.AX)):]}" if t.startswith(f"{self.AX}a") else t for t in canonical]
+                self.step8(slot, (slot + NS - 1) % NS if dma else None, vmc, last, aset, naset)
+            else:
+                self.q = list(canonical)
+                self.step16(slot, (slot + NS - 1) % NS if dma else None, vmc, last)
+
         self.L("LOOP")
-        self.q = list(canonical)
-        self.step(0, False)
-        self.q = list(canonical)
-        self.step(1, False)
+        for k in range(self.period):
+            emit(k, True, vm, False)
         I(f"s_sub_u32 {s('loop')}, {s('loop')}, 1")
         I(f"s_cmp_eq_u32 {s('loop')}, 0")
         I(f"s_cbranch_scc0 {self.lbl('LOOP')}")
         self.L("LAST")
-        self.q = list(canonical)
-        self.step(0, False)
-        self.q = list(canonical)
-        self.step(1, True)
+        for k in range(self.period):
+            left = self.period - 1 - k           # stages after this one
+            emit(k, left >= NS - 1, vm if left >= NS - 1 else 0, left == 0)
         I("s_nop 15")
         I("s_barrier")   # every wave is done with the ring: the epilogue's C tile may overwrite it
         I(f"s_mov_b32 m0, {s('m0save')}")
@@ -218,35 +325,28 @@ class Gen:
 
 
 OPERANDS = """\
-      : /* accumulators stay in a[0:255] */
-      : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [pairs] "s"(pairs), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
+      : /* accumulators stay in AGPRs */
+      : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
 """
 
 
-def clobbers():
-    c = ['"memory"', '"vcc"', '"scc"'] + [f'"v{i}"' for i in range(NV)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(60, 69)]
+def clobbers(nv):
+    c = ['"memory"', '"vcc"', '"scc"'] + [f'"v{i}"' for i in range(nv)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(60, 70)]
     return ", ".join(c)
-
-
-# measured on the FLUX shapes (scripts/probe_gemm4.hip, TFLOP/s at 9216 x 21504 x 3072 / 8192 x 12288 x 3072; fgemm_kernel<256>: 1258 / 1251):
-#   DMA pieces every 2nd MFMA of sub-step 0, barrier after MFMA 29 of sub-step 1, reads every 2nd MFMA behind it   1378 / 1354
-#   DMA every 4th (the whole sub-step), barrier after MFMA 45, one read per MFMA behind it                          1453 / 1479   <- product
-#   DMA every 3rd, barrier 45                                                                                      1434 / 1460
-#   DMA every 2nd, barrier 45                                                                                      1374 / 1387
-VARIANTS = {0: dict(dma_stride=4, barrier_at=45, reads_per_mfma_after=1)}
 
 
 def main():
     out = ROOT / "ecad_amd" / "csrc" / "gemm4_asm.h"
     parts = ["// gemm4_asm.h -- GENERATED by scripts/gen_gemm4.py (register map, schedule and rationale there); do not edit.\n#pragma once\n"]
-    for dt in ("bf16", "f16"):
-        for vid, kw in VARIANTS.items():
-            g = Gen(dt, **kw)
+    for dt in ("bf16", "f16", "fp8"):
+        for bn in (256, 128):
+            g = Gen(dt, bn)
             lines = g.build()
-            print(f"{dt} v{vid}: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs", file=sys.stderr)
+            print(f"{dt} BN {bn}: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs, {g.NV} VGPRs, stages per trip {g.period}, barrier at {g.barrier_at}, DMA stride {g.dma_stride}", file=sys.stderr)
             body = "\n".join('    "' + ln + '\\n"' for ln in lines)
-            parts.append(f"#define GEMM4_ASM_{dt.upper()}_V{vid}(ap, wp, rsa, rsw, pairs, lds, wave, zero) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
-                         + "\n".join(x + " \\" for x in OPERANDS.rstrip("\n").split("\n")) + "\n      : " + clobbers() + ")\n")
+            parts.append(f"#define GEMM4_PERIOD_{dt.upper()}_{bn} {g.period}  // K stages per trip of the loop: a K segment must hold a whole number of them\n"
+                         f"#define GEMM4_ASM_{dt.upper()}_{bn}(ap, wp, rsa, rsw, trips, lds, wave, zero) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
+                         + "\n".join(x + " \\" for x in OPERANDS.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV) + ")\n")
     out.write_text("\n".join(parts))
 
 

@@ -16,7 +16,7 @@ static float bf16_val(unsigned short v) { unsigned u = (unsigned)v << 16; float 
 static unsigned rng = 99u;
 static float rnd() { rng = rng * 1664525u + 1013904223u; return ((int)(rng >> 8) % 2001 - 1000) * 0.001f; }
 
-template <int EPI> static void run(const char* name, int M, int N, int K, int ksplit, int reps) {
+template <int EPI, int BN = 256> static void run(const char* name, int M, int N, int K, int ksplit, int reps) {
   std::vector<unsigned short> ha((size_t)M * K), hw((size_t)N * K), hr((size_t)M * N), hg((size_t)4 * N);
   for (auto& v : ha) v = bf16_bits(rnd());
   for (auto& v : hw) v = bf16_bits(rnd() * 0.03f);
@@ -29,11 +29,11 @@ template <int EPI> static void run(const char* name, int M, int N, int K, int ks
   for (int i = 0; i < 2; ++i) { CK(hipMalloc(&C[i], (size_t)M * N * 2)); CK(hipMalloc(&R[i], (size_t)M * N * 2)); }
   CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(G, hg.data(), hg.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), N * 4, hipMemcpyHostToDevice));
-  const void* k4 = (const void*)fgemm4_kernel<bf16_t, EPI>;
-  const void* k8 = (const void*)fgemm_kernel<bf16_t, 256, EPI>;
-  CK(hipFuncSetAttribute(k4, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES));
-  CK(hipFuncSetAttribute(k8, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<256>()));
-  const int tiles = (M / 256) * (N / 256);
+  const void* k4 = (const void*)fgemm4_kernel<bf16_t, BN, EPI>;
+  const void* k8 = (const void*)fgemm_kernel<bf16_t, BN, EPI>;
+  CK(hipFuncSetAttribute(k4, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<BN>()));
+  CK(hipFuncSetAttribute(k8, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<BN>()));
+  const int tiles = (M / 256) * (N / BN);
   auto args = [&](int which) {
     FGemmArgs<bf16_t> g{};
     g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = B; g.C = (bf16_t*)C[which]; g.M = M; g.N = N; g.K = K; g.lda = ksplit ? ksplit : K; g.ldw = K; g.ldc = N;
@@ -42,8 +42,8 @@ template <int EPI> static void run(const char* name, int M, int N, int K, int ks
     g.epi_direct = 1;
     return g;
   };
-  auto l4 = [&]() { hipLaunchKernelGGL((fgemm4_kernel<bf16_t, EPI>), dim3(tiles), dim3(256), G4_LDS_BYTES, 0, args(0)); };
-  auto l8 = [&]() { hipLaunchKernelGGL((fgemm_kernel<bf16_t, 256, EPI>), dim3(tiles), dim3(512), fgemm_lds_bytes<256>(), 0, args(1)); };
+  auto l4 = [&]() { hipLaunchKernelGGL((fgemm4_kernel<bf16_t, BN, EPI>), dim3(tiles), dim3(256), g4_lds_bytes<BN>(), 0, args(0)); };
+  auto l8 = [&]() { hipLaunchKernelGGL((fgemm_kernel<bf16_t, BN, EPI>), dim3(tiles), dim3(512), fgemm_lds_bytes<BN>(), 0, args(1)); };
   for (int i = 0; i < 2; ++i) { CK(hipMemset(C[i], 0xFF, (size_t)M * N * 2)); CK(hipMemcpy(R[i], hr.data(), hr.size() * 2, hipMemcpyHostToDevice)); }
   l4(); l8();
   CK(hipDeviceSynchronize());
@@ -72,10 +72,64 @@ template <int EPI> static void run(const char* name, int M, int N, int K, int ks
       if (round) best[w] = std::min(best[w], ms / reps);
     }
   const double fl = 2.0 * M * N * K;
-  printf("%-22s M %5d N %5d K %5d: gemm4 %8.1f us %5.0f TF | fgemm<256> %8.1f us %5.0f TF | words differing %zu%s\n", name, M, N, K, best[0] * 1e3, fl / (best[0] * 1e-3) / 1e12,
+  printf("%-22s BN %3d M %5d N %5d K %5d: gemm4 %8.1f us %5.0f TF | 8-wave %8.1f us %5.0f TF | words differing %zu%s\n", name, BN, M, N, K, best[0] * 1e3, fl / (best[0] * 1e-3) / 1e12,
          best[1] * 1e3, fl / (best[1] * 1e-3) / 1e12, diff, diff ? "  FAIL" : "");
   if (EPI == FEPI_BIAS && !ksplit) printf("%-22s rel-L2 vs fp64 on sampled elements %.2e\n", "", std::sqrt(num / den));
   CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(G)); CK(hipFree(B));
+  for (int i = 0; i < 2; ++i) { CK(hipFree(C[i])); CK(hipFree(R[i])); }
+}
+
+// e4m3 operands: fgemm48_kernel against fgemm8_kernel (random e4m3 bytes, NaN encodings masked out; per-row / per-channel scales)
+template <int EPI, int BN> static void run8(const char* name, int M, int N, int K, int reps) {
+  std::vector<unsigned char> ha((size_t)M * K), hw((size_t)N * K);
+  for (auto& v : ha) { rng = rng * 1664525u + 1013904223u; v = (unsigned char)(rng >> 13); if ((v & 0x7F) == 0x7F) v &= 0x7E; if ((v & 0x78) == 0x78) v &= 0x3F; }
+  for (auto& v : hw) { rng = rng * 1664525u + 1013904223u; v = (unsigned char)(rng >> 13); if ((v & 0x7F) == 0x7F) v &= 0x7E; if ((v & 0x78) == 0x78) v &= 0x3F; }
+  std::vector<float> hsa(M), hsw(N), hb(N);
+  for (auto& v : hsa) v = 0.001f * (1.5f + rnd());
+  for (auto& v : hsw) v = 0.01f * (1.5f + rnd());
+  for (auto& v : hb) v = rnd();
+  std::vector<unsigned short> hr((size_t)M * N), hg((size_t)4 * N);
+  for (auto& v : hr) v = bf16_bits(rnd());
+  for (auto& v : hg) v = bf16_bits(rnd());
+  unsigned char *A, *W; unsigned short *C[2], *R[2], *G; float *SA, *SW, *B;
+  CK(hipMalloc(&A, ha.size())); CK(hipMalloc(&W, hw.size())); CK(hipMalloc(&SA, M * 4)); CK(hipMalloc(&SW, N * 4)); CK(hipMalloc(&B, N * 4)); CK(hipMalloc(&G, hg.size() * 2));
+  for (int i = 0; i < 2; ++i) { CK(hipMalloc(&C[i], (size_t)M * N * 2)); CK(hipMalloc(&R[i], (size_t)M * N * 2)); }
+  CK(hipMemcpy(A, ha.data(), ha.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), hw.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(G, hg.data(), hg.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(SA, hsa.data(), M * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(SW, hsw.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), N * 4, hipMemcpyHostToDevice));
+  CK(hipFuncSetAttribute((const void*)fgemm48_kernel<bf16_t, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<BN>()));
+  CK(hipFuncSetAttribute((const void*)fgemm8_kernel<bf16_t, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<BN>()));
+  const int tiles = (M / 256) * (N / BN);
+  auto args = [&](int which) {
+    FGemm8Args<bf16_t> q{};
+    q.A8 = A; q.W8 = W; q.sa = SA; q.sw = SW; q.lda8 = K;
+    q.e.bias = B; q.e.C = (bf16_t*)C[which]; q.e.M = M; q.e.N = N; q.e.K = K; q.e.ldc = N; q.e.epi_direct = 1;
+    if (EPI == FEPI_BIAS_GATE_RESID) { q.e.resid = (bf16_t*)R[which]; q.e.ldr = N; q.e.gate = (const bf16_t*)G; q.e.gate_stride = N; q.e.seg0 = 0; q.e.rows_per_batch0 = 1; q.e.rows_per_batch1 = M / 4; }
+    return q;
+  };
+  auto l4 = [&]() { hipLaunchKernelGGL((fgemm48_kernel<bf16_t, BN, EPI>), dim3(tiles), dim3(256), g4_lds_bytes<BN>(), 0, args(0)); };
+  auto l8 = [&]() { hipLaunchKernelGGL((fgemm8_kernel<bf16_t, BN, EPI>), dim3(tiles), dim3(512), fgemm_lds_bytes<BN>(), 0, args(1)); };
+  for (int i = 0; i < 2; ++i) { CK(hipMemset(C[i], 0xFF, (size_t)M * N * 2)); CK(hipMemcpy(R[i], hr.data(), hr.size() * 2, hipMemcpyHostToDevice)); }
+  l4(); l8();
+  CK(hipDeviceSynchronize());
+  std::vector<unsigned short> c0((size_t)M * N), c1((size_t)M * N), r0((size_t)M * N), r1((size_t)M * N);
+  CK(hipMemcpy(c0.data(), C[0], c0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), C[1], c1.size() * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(r0.data(), R[0], r0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), R[1], r1.size() * 2, hipMemcpyDeviceToHost));
+  size_t diff = 0, nonfinite = 0;
+  for (size_t i = 0; i < c0.size(); ++i) { diff += (c0[i] != c1[i]) + (r0[i] != r1[i]); nonfinite += (c0[i] & 0x7F80) == 0x7F80; }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best[2] = {1e9f, 1e9f};
+  for (int round = 0; round < 4; ++round)
+    for (int w = 0; w < 2; ++w) {
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; ++r) { if (w == 0) l4(); else l8(); }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (round) best[w] = std::min(best[w], ms / reps);
+    }
+  const double fl = 2.0 * M * N * K;
+  printf("fp8 %-18s BN %3d M %5d N %5d K %5d: gemm4 %8.1f us %5.0f TF | 8-wave %8.1f us %5.0f TF | words differing %zu, non-finite %zu%s\n", name, BN, M, N, K, best[0] * 1e3,
+         fl / (best[0] * 1e-3) / 1e12, best[1] * 1e3, fl / (best[1] * 1e-3) / 1e12, diff, nonfinite, diff ? "  FAIL" : "");
+  CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(SA)); CK(hipFree(SW)); CK(hipFree(B)); CK(hipFree(G));
   for (int i = 0; i < 2; ++i) { CK(hipFree(C[i])); CK(hipFree(R[i])); }
 }
 
@@ -88,5 +142,15 @@ int main(int argc, char** argv) {
   run<FEPI_BIAS_GATE_RESID>("gate+resid (ff2)", 8192, 3072, 12288, 0, reps);
   run<FEPI_BIAS_GATE_RESID>("gate+resid split-A", 9216, 3072, 15360, 3072, reps);
   run<FEPI_BIAS_SILU>("silu", 1024, 3072, 3072, 0, reps);
+  run<FEPI_BIAS, 128>("bias", 512, 512, 384, 0, 2);
+  run<FEPI_BIAS_GATE_RESID, 128>("gate+resid (ff2)", 8192, 3072, 12288, 0, reps);
+  run<FEPI_BIAS_GATE_RESID, 128>("gate+resid (attn out)", 8192, 3072, 3072, 0, reps);
+  run<FEPI_BIAS_GATE_RESID, 128>("gate+resid split-A", 9216, 3072, 15360, 3072, reps);
+  run8<FEPI_BIAS, 256>("bias", 512, 512, 768, 2);
+  run8<FEPI_BIAS, 256>("single qkv third", 9216, 9216, 3072, reps);
+  run8<FEPI_BIAS_GELU, 256>("gelu (ff1)", 8192, 12288, 3072, reps);
+  run8<FEPI_BIAS, 128>("bias", 512, 512, 768, 2);
+  run8<FEPI_BIAS_GATE_RESID, 128>("gate+resid (ff2)", 8192, 3072, 12288, reps);
+  run8<FEPI_BIAS_GATE_RESID, 128>("proj_out", 9216, 3072, 15360, reps);
   return 0;
 }

@@ -34,12 +34,14 @@ template <typename T> struct FGemm8Args {
   FGemmArgs<T> e;     // M, N, K (elements), bias, outputs and every epilogue field; A / W / lda / ldw unused
 };
 
-// sa[m] * sw[n] as ONE rounded product, whatever -ffast-math would like to reassociate around it: fgemm8_kernel and gemm4.h's fgemm48_kernel must scale an
-// accumulator by the same number to stay bit-identical
-ECAD_DEV float fp8_descale(float sa, float sw) {
+// acc * (sa[m] * sw[n]) with exactly these two roundings, whatever -ffast-math would like to reassociate or contract around them: fgemm8_kernel and gemm4.h's
+// fgemm48_kernel must hand the shared epilogue the same numbers to stay bit-identical
+ECAD_DEV float fp8_descale(float acc, float sa, float sw) {
   float sc = sa * sw;
   asm volatile("" : "+v"(sc));
-  return sc;
+  float v = acc * sc;
+  asm volatile("" : "+v"(v));  // nor may the product be contracted into the epilogue's bias add in one kernel and not in the other
+  return v;
 }
 
 ECAD_DEV uint32_t pack_fp8x4(float a, float b, float c, float d) {
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(512) void fgemm8_kernel(const FGemm8Args<T> q) {
     for (int j = 0; j < FN; ++j) {
       const f32x4 sv = *reinterpret_cast<const f32x4*>(q.sw + n0 + wn * (BN / 2) + 16 * j + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] *= fp8_descale(sam, sv[r]);
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = fp8_descale(acc[i][j][r], sam, sv[r]);
     }
   }
   fgemm_epilogue<T, BN, EPI>(p, smem, m0, n0, acc);

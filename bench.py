@@ -417,8 +417,8 @@ def main_ga_shard(args, world, rank, device, dist):
 # secondary workloads reported inside the default line (never in `value`): each is this script run as a CHILD process with its own flags
 SECONDARY = {
     "alpha256_batch1_latency": ["--batch", "1", "--steps", "20", "--warmup", "3", "--streams", "1"],
-    # opt-in split-K of the few-rows FF2 (ECAD_SPLIT_K=1): faster at batch 1-2, but a sample run alone then differs in the last bits from the same sample in a batch
-    "alpha256_batch1_latency_split_k": ["ENV:ECAD_SPLIT_K=1", "--batch", "1", "--steps", "20", "--warmup", "3", "--streams", "1"],
+    # the same without the split-K of the few-rows FF2 (the default since round 5): what the bit-identity across batch sizes that ECAD_SPLIT_K=0 restores costs
+    "alpha256_batch1_latency_no_split_k": ["ENV:ECAD_SPLIT_K=0", "--batch", "1", "--steps", "20", "--warmup", "3", "--streams", "1"],
     "alpha256_batch4_x4_contexts": ["--batch", "4", "--streams", "4", "--steps", "24", "--warmup", "2"],  # small-batch serving: four batches of 4 in flight
     "alpha256_batch100_paper_latency_config": ["--batch", "100", "--steps", "3", "--warmup", "1"],
     "alpha256_fp8_block_gemms": ["--fp8", "--steps", "5", "--warmup", "1"],

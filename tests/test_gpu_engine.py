@@ -315,7 +315,17 @@ def test_baseline_batch16_properties():
     idx = 5
     sel = torch.tensor([idx, 16 + idx])
     one = eng.run_schedule(enc[sel].cuda(), mask[sel].cuda(), inp["latents"][idx : idx + 1].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
-    assert torch.equal(one, a[idx : idx + 1])  # bit for bit: a row's arithmetic does not depend on its neighbours in the batch
+    import os
+
+    if os.environ.get("ECAD_LATENCY_TILES", "1") == "0" or os.environ.get("ECAD_SPLIT_K", "1") == "0":
+        assert torch.equal(one, a[idx : idx + 1])  # bit for bit: a row's arithmetic does not depend on its neighbours in the batch
+    else:
+        # product default since round 5: a batch of 1-3 runs FF2 as four K-slices (split-K): the fp32 sum of that one GEMM is taken in another order, so the
+        # sample alone agrees with its row in the batch of 16 to rounding, not bit for bit (measured 1.6e-3 over 28 blocks x 20 steps; the reference's cuBLAS heuristics
+        # give no cross-batch-size guarantee either).  From batch 4 up every kernel is the sequential-K one and rows are exact again (the rows256 run of this test).
+        err = rel_l2(one, a[idx : idx + 1])
+        print(f"[parity] sample alone (split-K FF2) vs its row in the batch of 16: measured {err:.3e} tol 3e-3")
+        assert within(err, 3e-3)
 
 
 @pytest.mark.parametrize("dtype,side", [(torch.float16, 32), (torch.bfloat16, 32), (torch.float16, 64)])
@@ -525,6 +535,7 @@ def test_latency_tiles_for_few_rows_are_the_same_arithmetic(monkeypatch, dtype, 
     solver = DPMSolverPP2M(steps)
     coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
     res = {}
+    monkeypatch.setenv("ECAD_SPLIT_K", "0")  # the split-K FF2 of the few-rows regime is another summation order by design (its own tests below); this one is about the tiles
     for lat in ("1", "0"):
         monkeypatch.setenv("ECAD_LATENCY_TILES", lat)
         eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=dtype)
@@ -555,7 +566,7 @@ def test_latency_tiles_for_few_rows_are_the_same_arithmetic(monkeypatch, dtype, 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
 def test_split_k_of_the_few_rows_ff2_tracks_the_oracle_and_is_deterministic(monkeypatch, dtype, tol):
-    """DESIGN 5f, opt-in (ECAD_SPLIT_K=1): with few rows FF2 (K = 4608) runs as four K-slices per latency tile + splitk_rmw_kernel (fp32 partial sums added in slice order, one rounding, then the
+    """DESIGN 5f (the default since round 5; ECAD_SPLIT_K=0 off): with few rows FF2 (K = 4608) runs as four K-slices per latency tile + splitk_rmw_kernel (fp32 partial sums added in slice order, one rounding, then the
     read-modify-write epilogue incl. replayed components and the row statistics of the LayerNorm fold).  Held to the oracle per step; equal to the sequential-K latency
     tiles within the rounding of one output; graph == eager and run == re-run bit for bit (no atomics anywhere)."""
     from ecad_amd.engine import EcadEngine

@@ -32,7 +32,7 @@ def classify_flux(name: str, tiles: int) -> str | None:
     """FLUX-1024 batch 2 (flux.hip): the GEMM symbols are fgemm_kernel<T, BN, EPI> (fgemm8_kernel in fp8 mode) without a class tag, so a class is
     (EPI, BN, grid): R = 9216 rows (single-stream), 8192 image / 1024 text rows (joint blocks), D = 3072.  The joint attention out-projection and
     the joint FF2 share symbol AND grid (N = 3072, gated residual epilogue; only K differs): one merged class."""
-    m = re.search(r"fgemm8?_kernel.*?Li(\d+)ELi(\d+)E", name) or re.search(r"fgemm8?_kernel<[^,]+, *(\d+), *(\d+)>", name)
+    m = re.search(r"fgemm(?:4|8|48)?_kernel.*?Li(\d+)ELi(\d+)E", name) or re.search(r"fgemm(?:4|8|48)?_kernel<[^,]+, *(\d+), *(\d+)>", name)  # gemm4.h: fgemm4 / fgemm48
     if m:
         bn, epi = int(m.group(1)), int(m.group(2))
         def t(rows, n):

@@ -35,6 +35,7 @@
 #include "gemm.h"
 #include "final_layer.h"
 #include "gemm2w.h"
+#include "gemm2w4.h"
 #include "gemm3s.h"
 #include "gemm3s8.h"
 
@@ -344,6 +345,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_LATENCY_TILES")) latency_tiles = atoi(l) != 0;
     if (const char* l = getenv("ECAD_TAIL_SPLIT")) tail_split = atoi(l) != 0;
     if (const char* l = getenv("ECAD_SPLIT_K")) split_k = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_GEMM4")) gemm4_wide = atoi(l) != 0;
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
     // ---- weight arena
@@ -1277,6 +1279,8 @@ template <typename T> class EngineT : public EngineBase {
   int gemm_impl_cls[KC_COUNT];
   bool fuse_attn = true;  // attention in the tail of the query projection when the geometry allows (env ECAD_FUSE_ATTN=0: separate launches; bit-identical)
   bool g2_attr[4][KC_COUNT] = {};
+  bool gemm4_wide = true;  // the wide tile on four waves with the hand-placed K loop (gemm2w4.h; env ECAD_GEMM4=0: the 8-wave gemm2w.h; bit-identical)
+  bool g2w4_attr[4][KC_COUNT] = {};
   // Few rows (batch 1-4): a launch whose 256-row tiles cover less than half the chip is a latency chain (18-72 K-steps of ~0.8 us whatever the tile count);
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
@@ -1343,6 +1347,17 @@ template <typename T> class EngineT : public EngineBase {
           g2_attr[EPI][TAG] = true;
         }
         const int tiles2 = ((rows_of(g) + G2_BM - 1) / G2_BM) * (g.N / G2_BN);
+        if constexpr (EPI != EPI_BIAS_CACHE_RESID) {
+          // whole 256-row tiles: the same tile on four waves, one per SIMD, K loop hand-placed (gemm2w4.h): bit-identical, 9-14 % less time per launch stand-alone
+          if (gemm4_wide && g2w4_shape_ok(g)) {
+            if (!g2w4_attr[EPI][TAG]) {
+              HIPCHK(hipFuncSetAttribute((const void*)gemm2w4_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2W4_LDS_BYTES));
+              g2w4_attr[EPI][TAG] = true;
+            }
+            hipLaunchKernelGGL((gemm2w4_kernel<T, EPI, TAG>), dim3(tiles2 > num_cus && tiles2 % num_cus == 0 ? num_cus : tiles2), dim3(256), G2W4_LDS_BYTES, s, g);
+            return ECAD_OK;
+          }
+        }
         // direct epilogue (LDS-free): one workgroup per CU walks its tiles and fetches the next tile's first K-step under the epilogue (gemm2w.h)
         const bool walk = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && g.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1) && tiles2 > num_cus && tiles2 % num_cus == 0;
         hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(walk ? num_cus : tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);

@@ -1,0 +1,211 @@
+// gemm2w4.h -- gemm2w.h's 256 x 288 tile (FF1 + GELU, the wide K,V projection, text K/V) on four waves, one per SIMD: 2 x 2 waves of 128 x 144, the K loop as a
+// hand-placed asm statement (gemm4_asm.h, scripts/gen_gemm4.py: BN 288 variant -- 8 A + 9 W fragments per 32-deep step for 72 MFMAs, 14.4 bytes of LDS per KFLOP
+// instead of 22; 64 of the wave's 72 accumulator fragments in a[0:255], the ninth column in eight "+v" operands).  Same tile order, LDS image, K order per accumulator
+// and epilogue arithmetic as gemm2w_kernel: bit-identical results (scripts/probe_gemm2w4.hip).  The tile walk has no early first K-step (the statement owns its prologue);
+// with the direct epilogue the next tile's DMA prologue starts while this tile's stores drain.
+#pragma once
+#include "common.h"
+#include "gemm.h"
+#include "gemm2w.h"
+#include "gemm4.h"
+
+namespace ecad {
+
+#ifdef G2W4_STAMP
+__device__ unsigned long long g2w4_stamp[4 * 1024];
+#endif
+
+constexpr int G2W4_CST = G2_TILE_BYTES;               // bias[288] | c1[288] | (rstd, -rstd * mean)[256]: 1152 + 1152 + 2048 bytes behind the operand ring / C tile
+constexpr int G2W4_LDS_BYTES = G2W4_CST + 4352;
+static_assert(G2W4_LDS_BYTES <= 160 * 1024, "ring + C tile + epilogue constants");
+
+template <typename T> inline bool g2w4_shape_ok(const GemmArgs<T>& g) {
+  const int rows = (g.m_end ? g.m_end : g.M) - g.m_begin;
+  return g.M % G2_BM == 0 && rows % G2_BM == 0 && g.m_begin % G2_BM == 0 && g.N % G2_BN == 0 && g.K % (2 * GEMM_BK) == 0;
+}
+
+template <typename T, int EPI, int TAG>
+__global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
+  constexpr int FM = 8, FN = 9;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tiles_n = p.N / G2_BN;
+  const int tiles_m = ((p.m_end ? p.m_end : p.M) - p.m_begin) / G2_BM;
+  const int nwg = tiles_m * tiles_n;
+  const unsigned rsa = (unsigned)(p.lda * sizeof(T)), rsw = (unsigned)(p.ldw * sizeof(T));
+  const unsigned trips = (unsigned)(p.K / (2 * GEMM_BK) - 1);
+  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+#ifdef G2W4_STAMP  // diagnostic build only (scripts/probe_gemm2w4.hip): cycles in the K loop / in the epilogue and the clock held, per workgroup
+  unsigned long long st_loop = 0, st_epi = 0;
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+#ifdef G2W4_STAMP
+    unsigned long long st_a, st_b, st_c;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_a)::"memory");
+#endif
+    int m0, n0;
+    {  // tile id -> origin exactly as gemm2w_kernel: XCD-contiguous runs, then tile_coords
+      const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
+      const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      int tm, tn;
+      tile_coords(bid, tiles_m, tiles_n, tm, tn);
+      m0 = p.m_begin + tm * G2_BM;
+      n0 = tn * G2_BN;
+    }
+    const bool fold = p.ln_stat != nullptr;
+    // Epilogue constants of the tile, put into the LDS behind the ring BEFORE the K loop (nothing of the epilogue then waits on global memory between the tile's stores):
+    // the 288 bias values (and the 288 c1 of a folded LayerNorm) by LDS-DMA -- older than every operand piece, so the loop's first counted wait covers them, and the
+    // loop's barriers order them before the readers -- and the row coefficients rstd, -rstd * mean of the 256 rows (gemm2w.h) from the per-tile partial sums.
+    {
+      char* cst = smem + G2W4_CST;
+      const int t = threadIdx.x;
+      if (t < 72) {
+        if (p.bias) glds16_raw(p.bias + n0 + 4 * t, lds + (unsigned)G2W4_CST + (unsigned)wave * 1024u);
+        if (fold) glds16_raw(p.ln_c1 + n0 + 4 * t, lds + (unsigned)G2W4_CST + 1152u + (unsigned)wave * 1024u);
+      }
+      if (fold) {
+        float ca[1], cb[1];
+        ln_row_coeffs<1>(p, m0 + t, ca, cb);
+        reinterpret_cast<f32x2*>(cst + 2304)[t] = (f32x2){ca[0], cb[0]};
+      }
+    }
+    f32x4 c8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c8[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const char* ap = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+      const char* wp = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
+      const unsigned zero = 1u;
+      if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_288(ap, wp, rsa, rsw, trips, lds, wave, zero, c8); }
+      else { GEMM4_ASM_F16_288(ap, wp, rsa, rsw, trips, lds, wave, zero, c8); }
+    }
+#ifdef G2W4_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_b)::"memory");
+#endif
+    // every per-lane value of the epilogue is derived from this laundered id, so none of it is computed above the K loop and carried across it in the 54 registers the
+    // statement leaves (hipcc hoisted the row pointers and spilled them; each scratch reload is an `s_waitcnt vmcnt(0)` between the tile's stores)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const char* cst = smem + G2W4_CST;
+    auto raw = [&](auto ic, auto jc) -> f32x4 {
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      if constexpr (j < 8) return g4_acc<i, j>();
+      else return c8[i];
+    };
+    const bool has_bias = p.bias != nullptr;
+    auto epilogue = [&](auto foldc) {
+    constexpr bool FOLD = decltype(foldc)::value;
+    f32x4 bvs[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bvs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (has_bias) bvs[j] = *reinterpret_cast<const f32x4*>(cst + (wn * 144 + 16 * j + 4 * g) * 4);
+    }
+    // LayerNorm folded into this GEMM (gemm2w.h): acc <- rstd_m * acc - rstd_m * mean_m * c1[n]
+    float ra[FM], rb[FM];
+    f32x4 c1v[FN];
+    if constexpr (FOLD) {
+      const f32x2* rowab = reinterpret_cast<const f32x2*>(cst + 2304);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const f32x2 ab = rowab[wm * 128 + 16 * i + l15];
+        ra[i] = ab[0];
+        rb[i] = ab[1];
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) c1v[j] = *reinterpret_cast<const f32x4*>(cst + 1152 + (wn * 144 + 16 * j + 4 * g) * 4);
+    }
+    // (the operation order of gemm2w.h, pinned: under -ffast-math hipcc otherwise merges the bias into the fold as fma(c1, rb, bias) -- one rounding elsewhere)
+    auto acc = [&](auto ic, auto jc) -> f32x4 {
+#pragma clang fp reassociate(off) contract(off)
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      f32x4 v = raw(ic, jc);
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], ra[i], rb[i] * c1v[j][r]);
+      }
+      return v;
+    };
+    auto cvt = [&](auto ic, auto jc) {
+#pragma clang fp reassociate(off) contract(off)
+      constexpr int j = decltype(jc)::value;
+      const f32x4 av = acc(ic, jc);
+      const f32x4 bv = bvs[j];
+      Pack4 o;
+      if constexpr (EPI == EPI_BIAS_GELU) {
+        const f32x2 v01 = gelu_tanh2((f32x2){av[0] + bv[0], av[1] + bv[1]});
+        const f32x2 v23 = gelu_tanh2((f32x2){av[2] + bv[2], av[3] + bv[3]});
+        float_to_elem4<T>(o, 0, v01[0]); float_to_elem4<T>(o, 1, v01[1]); float_to_elem4<T>(o, 2, v23[0]); float_to_elem4<T>(o, 3, v23[1]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = av[r] + bv[r];
+          if (EPI == EPI_BIAS_SILU) v = silu(v);
+          float_to_elem4<T>(o, r, v);
+        }
+      }
+      return o;
+    };
+    const bool direct = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1);
+    if (direct) {
+      // rows leave straight from the registers: fragments j, j + 1 paired by v_permlane16_swap into 16-byte pieces (gemm2w.h), the ninth fragment in 8-byte stores
+      static_for<FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = m0 + wm * 128 + 16 * i + l15;
+        T* crow = p.C + (size_t)m * p.ldc + n0 + wn * 144;
+        static_for<FN / 2>([&](auto pc) {
+          constexpr int j = 2 * decltype(pc)::value;
+          Pack4 a = cvt(ic, std::integral_constant<int, j>{}), b = cvt(ic, std::integral_constant<int, j + 1>{});
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[0]), "+v"(b.u[0]));
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.u[1]), "+v"(b.u[1]));
+          Pack8 v;
+          v.u = (u32x4){a.u[0], a.u[1], b.u[0], b.u[1]};
+          gstore16(crow + 16 * (j + (g & 1)) + 8 * (g >> 1), v);
+        });
+        const Pack4 o = cvt(ic, std::integral_constant<int, FN - 1>{});
+        *reinterpret_cast<u32x2*>(crow + 16 * (FN - 1) + 4 * g) = o.u;
+      });
+      return;
+    }
+    // staged: the wave's 128 x 144 block -> row-major C tile in LDS, one barrier, wave w streams rows 64 w .. 64 w + 63 in 16-byte pieces
+    T* ctile = reinterpret_cast<T*>(smem);
+    static_for<FN>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int nl = wn * 144 + 16 * j + 4 * g;
+      static_for<FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int ml = wm * 128 + 16 * i + l15;
+        const Pack4 o = cvt(ic, jc);
+        *reinterpret_cast<u32x2*>(ctile + ml * G2_CS + nl) = o.u;
+      });
+    });
+    __syncthreads();
+    constexpr int CPR = G2_BN / 8;
+    constexpr int CHUNKS = 64 * CPR;
+    for (int id = lane; id < CHUNKS; id += 64) {
+      const int rl = id / CPR, cchunk = id - rl * CPR;
+      const int ml = wave * 64 + rl;
+      gstore16(p.C + (size_t)(m0 + ml) * p.ldc + n0 + cchunk * 8, lds_read16(ctile + ml * G2_CS + cchunk * 8));
+    }
+    };
+    if (fold) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+    if (vb + (int)gridDim.x < nwg) __syncthreads();  // the C tile and the constants have been read before the next tile overwrites them
+#ifdef G2W4_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c)::"memory");
+    st_loop += st_b - st_a; st_epi += st_c - st_b;
+#endif
+  }
+#ifdef G2W4_STAMP
+  if (threadIdx.x == 0) {
+    const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o = g2w4_stamp + 4 * blockIdx.x;
+    o[0] = st_loop; o[1] = st_epi; o[2] = st_c1 - st_c0; o[3] = st_r1 - st_r0;
+  }
+#endif
+}
+
+}  // namespace ecad

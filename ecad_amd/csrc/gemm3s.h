@@ -20,6 +20,9 @@ static_assert(G3A_LDS_BYTES <= G3_LDS_BYTES, "the fused attention tail (Q tile +
 constexpr int LN_PARTS = 8;  // D = 1152 = 8 column tiles of 144 (the engine folds only then)
 template <int NR, typename T>
 ECAD_DEV void ln_row_coeffs(const GemmArgs<T>& p, int row0, float (&ra)[NR], float (&rb)[NR]) {
+  // every kernel that folds a LayerNorm must produce the same two numbers per row: -ffast-math may otherwise re-associate the eight-term sums or contract the
+  // products differently from one inlining context to the next (round 5: gemm2w4.h, same source, 1-ulp differences in a few rows)
+#pragma clang fp reassociate(off) contract(off)
   f32x2 v[NR][LN_PARTS];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {

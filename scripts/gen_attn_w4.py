@@ -28,6 +28,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
+import os
+ABLATE = set(filter(None, os.environ.get("W4_ABLATE", "").split(",")))   # timing experiments only (wrong results): dma, exp, kread, vread, max, sum, cvt
 
 S0, SX, SY, CI = 0, 32, 64, 96
 PX, PY, PZ = 128, 144, 160
@@ -114,11 +116,15 @@ class Gen:
     # ---- pieces of the stream
     def k_read(self, f, slot):
         kb, ks = divmod(f, 8)
+        if "kread" in ABLATE:
+            return
         self.ds(f"ds_read_b128 {v(KW + 4 * (f % K_WIN), 4)}, {v(KA + ks)} offset:{slot * SLOT + kb * 8192}", f"K{f}")
 
     def v_read(self, f, slot):
         db, kst = divmod(f, 4)
         base = VW + 4 * (f % V_WIN)
+        if "vread" in ABLATE:
+            return
         self.ds(f"ds_read_b64_tr_b16 {v(base, 2)}, {v(VA + db)} offset:{slot * SLOT + kst * 4096}", f"V{f}a")
         self.ds(f"ds_read_b64_tr_b16 {v(base + 2, 2)}, {v(VA + db)} offset:{slot * SLOT + kst * 4096 + 2048}", f"V{f}")
 
@@ -187,7 +193,7 @@ class Gen:
         ops = []
         n = len(regs)
         for k, (reg, rq) in enumerate(regs):
-            cur = [f"v_exp_f32_e32 {v(TMP + k % 4)}, {v(reg)}"]
+            cur = [f"{'v_mov_b32_e32' if 'exp' in ABLATE else 'v_exp_f32_e32'} {v(TMP + k % 4)}, {v(reg)}"]
             if k >= 1:
                 preg, prq = regs[k - 1]
                 cur.append(f"v_add_f32_e32 {v(LRUN + prq)}, {v(LRUN + prq)}, {v(TMP + (k - 1) % 4)}")
@@ -314,7 +320,7 @@ class Gen:
             gaps[k * 32 // n] += ex[k]
         gaps[31] += ex[n]
         # DMA of tile t + 3: one piece every fourth gap, the scalar bookkeeping behind the last
-        for pc in range(8):
+        for pc in range(0 if "dma" in ABLATE else 8):
             m0w, ld = self.dma_piece(pc, d_slot)
             g = 1 + 4 * pc
             gaps[g] = [m0w] + (gaps[g][:1] or ["s_nop 0"]) + [ld] + gaps[g][1:]   # one instruction between the M0 write and the DMA that reads it

@@ -52,7 +52,7 @@ class Gen:
         self.dt, self.BN = dtype, bn
         self.fp8 = dtype == "fp8"
         self.FN = bn // 32                       # W fragments per wave (wave tile 128 x BN/2)
-        self.NS = 2 if bn == 256 else 3          # ring slots
+        self.NS = 3 if bn == 128 else 2          # ring slots (BN 288: the PixArt FF1 / K,V tile of gemm2w.h, 2 x 68 KiB)
         self.STAGE = (256 + bn) * 128
         self.WP = bn // 8 // 4                   # W pieces per wave and stage
         self.NP = 8 + self.WP                    # DMA pieces per wave and stage
@@ -81,6 +81,10 @@ class Gen:
         self.dma_stride = max(1, (self.barrier_at // self.NP) if self.fp8 else (self.NM // self.NP))
         assert self.dma_stride * (self.NP - 1) < (self.barrier_at if self.fp8 else self.NM)
         self.period = self.NS if (not self.fp8 or self.NS % 2 == 0) else 2 * self.NS
+
+    def acc(self, i, j):
+        """accumulator fragment (i, j): AGPRs a[4 (8 i + j) ..] for j < 8; the ninth column of the 288-wide tile lives in eight "+v" operands of the statement"""
+        return a(4 * (8 * i + j), 4) if j < 8 else f"%[c8_{i}]"
 
     def I(self, t):
         self.lines.append("\t" + t)
@@ -142,8 +146,7 @@ class Gen:
                     self.need(f"{aset}w{j}")
                 if j == 0:
                     self.need(f"{aset}a{i}")
-                acc = 4 * (8 * i + j)
-                self.I(f"{self.mfma} {a(acc, 4)}, {v(wset + 4 * j, 4)}, {v(aset + 4 * i, 4)}, {a(acc, 4)}")
+                self.I(f"{self.mfma} {self.acc(i, j)}, {v(wset + 4 * j, 4)}, {v(aset + 4 * i, 4)}, {self.acc(i, j)}")
                 for t in fillers.get(n, []):
                     self.I(t)
                 if barrier is not None and n == barrier[0]:
@@ -253,7 +256,11 @@ class Gen:
         for which, n, off, rs in (("a", 8, self.AOFF, "%[rsa]"), ("w", self.WP, self.WOFF, "%[rsw]")):
             I(f"s_mul_i32 {s('tmp0')}, %[wave], {8 * n}")            # first row of this wave's pieces
             for q in range(n):
-                I(f"v_or_b32_e32 {v(T + 6)}, {(q & 1) << 2}, {v(T + 2)}")
+                # (row >> 1) & 7 with row = 8 (n wave + q) + (lane >> 3): ((4 (n wave + q)) & 7) | (lane >> 4) -- n = 9 makes the first term depend on the wave
+                I(f"s_mul_i32 {s('tmp1')}, %[wave], {4 * n}")
+                I(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, {4 * q}")
+                I(f"s_and_b32 {s('tmp1')}, {s('tmp1')}, 7")
+                I(f"v_or_b32_e32 {v(T + 6)}, {s('tmp1')}, {v(T + 2)}")
                 I(f"v_xor_b32_e32 {v(T + 6)}, {v(T + 6)}, {v(T + 5)}")
                 I(f"v_lshlrev_b32_e32 {v(T + 6)}, 4, {v(T + 6)}")
                 I(f"v_add_u32_e32 {v(T + 7)}, {8 * q}, {v(T + 4)}")
@@ -270,7 +277,7 @@ class Gen:
         I("s_cmp_eq_u32 %[zero], 0")      # a second K segment (split-A GEMM: another A buffer for the rest of K) goes on accumulating
         I(f"s_cbranch_scc1 {self.lbl('KEEP')}")
         for i in range(8):
-            for j in range(self.FN):
+            for j in range(min(self.FN, 8)):     # (the ninth column's operands are zeroed by the caller)
                 for r in range(4):
                     I(f"v_accvgpr_write_b32 {a(4 * (8 * i + j) + r)}, 0")
         self.L("KEEP")
@@ -328,6 +335,10 @@ OPERANDS = """\
       : /* accumulators stay in AGPRs */
       : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
 """
+OPERANDS_288 = """\
+      : [c8_0] "+v"(c8[0]), [c8_1] "+v"(c8[1]), [c8_2] "+v"(c8[2]), [c8_3] "+v"(c8[3]), [c8_4] "+v"(c8[4]), [c8_5] "+v"(c8[5]), [c8_6] "+v"(c8[6]), [c8_7] "+v"(c8[7])
+      : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
+"""
 
 
 def clobbers(nv):
@@ -339,14 +350,16 @@ def main():
     out = ROOT / "ecad_amd" / "csrc" / "gemm4_asm.h"
     parts = ["// gemm4_asm.h -- GENERATED by scripts/gen_gemm4.py (register map, schedule and rationale there); do not edit.\n#pragma once\n"]
     for dt in ("bf16", "f16", "fp8"):
-        for bn in (256, 128):
+        for bn in (256, 128, 288):
+            if bn == 288 and dt == "fp8":
+                continue
             g = Gen(dt, bn)
             lines = g.build()
             print(f"{dt} BN {bn}: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs, {g.NV} VGPRs, stages per trip {g.period}, barrier at {g.barrier_at}, DMA stride {g.dma_stride}", file=sys.stderr)
             body = "\n".join('    "' + ln + '\\n"' for ln in lines)
             parts.append(f"#define GEMM4_PERIOD_{dt.upper()}_{bn} {g.period}  // K stages per trip of the loop: a K segment must hold a whole number of them\n"
-                         f"#define GEMM4_ASM_{dt.upper()}_{bn}(ap, wp, rsa, rsw, trips, lds, wave, zero) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
-                         + "\n".join(x + " \\" for x in OPERANDS.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV) + ")\n")
+                         f"#define GEMM4_ASM_{dt.upper()}_{bn}(ap, wp, rsa, rsw, trips, lds, wave, zero{', c8' if bn == 288 else ''}) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
+                         + "\n".join(x + " \\" for x in (OPERANDS_288 if bn == 288 else OPERANDS).rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV) + ")\n")
     out.write_text("\n".join(parts))
 
 

@@ -118,6 +118,33 @@ def test_gemm2w_direct_epilogue_stores_the_staged_epilogues_bytes(dtype_name, ep
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("site,epi,M,N,K,sched", [("ff1", 1, 8192, 4608, 1152, 0), ("ff1", 1, 2048, 4608, 1152, 8), ("attn1_kv", 0, 8192, 2304, 1152, 0), ("attn1_kv", 0, 8192, 2304, 1152, 4),
+                                                   ("small", 2, 512, 576, 256, 0), ("small", 0, 32768, 1152, 128, 4)])
+def test_wide_tile_on_four_waves_stores_the_eight_wave_kernels_bytes(dtype_name, site, epi, M, N, K, sched, monkeypatch):
+    """gemm2w4.h (round 5): the 256 x 288 tile on one wave per SIMD with the hand-placed K loop of scripts/gen_gemm4.py -- what the engine launches for whole 256-row
+    tiles (ECAD_GEMM4=0: gemm2w.h's eight waves).  Same K order per accumulator and the same epilogue arithmetic: the same bytes, direct and staged epilogue, one tile
+    per workgroup and two (8192 x 4608: 512 tiles on 256 CUs), a single trip of the loop (K = 256) and none (K = 128); both against fp32 torch."""
+    from ecad_amd.engine import EcadEngine
+
+    dt = getattr(torch, dtype_name)
+    a, w = _r((M, K), dt, 1.0, 61), _r((N, K), dt, 0.05, 62)
+    bias = _r((N,), torch.float32, 0.5, 63)
+    outs = []
+    for four in ("1", "0"):
+        monkeypatch.setenv("ECAD_GEMM4", four)
+        eng = EcadEngine(num_layers=1, max_batch=2, max_tokens=256, max_text_tokens=120, dtype=dt)
+        buf = torch.full((M, N + 64), 3.0, dtype=dt, device="cuda")
+        eng.op_gemm_ex("wide288", site, epi, a, w, bias, out=buf[:, 32 : 32 + N], sched=sched)
+        assert bool((buf[:, :32] == 3.0).all()) and bool((buf[:, 32 + N :] == 3.0).all())
+        outs.append(buf[:, 32 : 32 + N].clone())
+        del eng
+    assert torch.equal(outs[0], outs[1])
+    ref = a.float() @ w.float().t() + bias
+    ref = {0: lambda x: x, 1: lambda x: F.gelu(x, approximate="tanh"), 2: F.silu}[epi](ref)
+    assert within(tile_rel_l2(outs[0], ref), TOL[dtype_name])
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
     """The split QKV launch of the engine: Q on 256x144 tiles into columns [0, D), K,V on 256x288 tiles into columns [D, 3D) of one [M, 3D] buffer
     (row stride 3D on the output) -- together they must equal one fused projection, and neither may touch the other's columns."""

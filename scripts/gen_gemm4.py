@@ -25,6 +25,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
+import os
+ABLATE = set(filter(None, os.environ.get("G4_ABLATE", "").split(",")))   # timing experiments only (wrong results): mfma, read, dma
 SG = dict(loop=60, ldsw=61, ap=62, ap_hi=63, wp=64, wp_hi=65, m0save=66, tmp0=67, tmp1=68, ldsw2=69)
 
 
@@ -87,6 +89,8 @@ class Gen:
         return a(4 * (8 * i + j), 4) if j < 8 else f"%[c8_{i}]"
 
     def I(self, t):
+        if ("mfma" in ABLATE and t.startswith("v_mfma")) or ("read" in ABLATE and t.startswith("ds_read")) or ("dma" in ABLATE and t.startswith("global_load_lds")):
+            return
         self.lines.append("\t" + t)
 
     def L(self, l):

@@ -59,7 +59,7 @@ def classify_flux(name: str, tiles: int) -> str | None:
 
 
 def classify(name: str) -> str | None:
-    m = re.search(r"(gemm2w|gemm3s|pgemm)_kernel.*?Li(\d+)ELi(\d+)E", name) or re.search(r"(gemm2w|gemm3s|pgemm)_kernel<[^,]+, *(\d+), *(\d+)>", name)
+    m = re.search(r"(gemm2w4|gemm2w|gemm3s|pgemm)_kernel.*?Li(\d+)ELi(\d+)E", name) or re.search(r"(gemm2w4|gemm2w|gemm3s|pgemm)_kernel<[^,]+, *(\d+), *(\d+)>", name)
     if m:
         return GEMM_TAGS.get(int(m.group(3)))
     if "cache_accumulate" in name:  # cache_accumulate_kernel<T, TAG> / cache_accumulate_rows_kernel<T, TAG, R>

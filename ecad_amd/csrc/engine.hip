@@ -145,6 +145,9 @@ template <typename T> class EngineT : public EngineBase {
   // destroying the donor first leaves the borrowers intact.  `gen` counts changes of the arena's content (ecad_load_weights / ecad_finalize_weights on the owner):
   // a borrower that sees a generation it has not lowered its plans for drops them (plan sets, hipGraph, the LayerNorm-fold copies W' / c1 / c2 are all
   // derived from the weights) before it runs anything.
+  // Shared by an owner and its borrowers (share_weights).  refs / gen / finalized are plain fields: ecad_create / ecad_share_weights / ecad_load_weights /
+  // ecad_finalize_weights / ecad_destroy of engines that share an arena must be serialized by the caller (include/ecad_hip.h says so at ecad_share_weights);
+  // the per-batch calls only read them.
   struct SharedArena { char* base; int refs; uint64_t gen; bool finalized; };
   SharedArena* sarena = nullptr;
   uint64_t seen_gen = 0;
@@ -217,6 +220,7 @@ template <typename T> class EngineT : public EngineBase {
   // one float per (sample, key), broadcast over heads and queries.  self: [Bt][N] for attn1; enc: [Bt][T] replaces the bias derived from the 0/1 mask.
   float *self_bias_buf = nullptr, *enc_bias_user = nullptr;
   bool self_bias_on = false, enc_bias_on = false;
+  int bias_bt = 0, bias_n = 0, bias_t = 0;  // geometry the active attention bias was copied with (set_attention_bias)
   SrcDesc* desc_dev = nullptr;
   size_t desc_cap = 0;
   // ---- schedule / plans
@@ -548,6 +552,7 @@ template <typename T> class EngineT : public EngineBase {
       drop_all_plans();
       fold_release_current();
       batch_begun = false;
+      std::fill(valid_rt.begin(), valid_rt.end(), 0);  // cache slots computed with the donor's previous weights are not usable (a keep_caches rebind must not keep them)
       seen_gen = sarena->gen;
     }
     return ECAD_OK;
@@ -634,6 +639,7 @@ template <typename T> class EngineT : public EngineBase {
     }
     if (self_bias) HIPCHK(hipMemcpyAsync(self_bias_buf, self_bias, (size_t)Bt_ * N_ * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (enc_bias) HIPCHK(hipMemcpyAsync(enc_bias_user, enc_bias, (size_t)Bt_ * T_ * sizeof(float), hipMemcpyDeviceToDevice, s));
+    bias_bt = Bt_; bias_n = self_bias ? N_ : 0; bias_t = enc_bias ? T_ : 0;  // the rows are strided by these: begin_batch refuses another geometry
     return ECAD_OK;
   }
   int quant_weight(const T* w, size_t rows, int K) {
@@ -1653,6 +1659,10 @@ template <typename T> class EngineT : public EngineBase {
       return fail(ECAD_E_NOT_READY, "ecad_rebind_batch_inputs: no batch of that geometry has begun");
     int rc = ensure_shapes(Bt_, H_, W_, T_);
     if (rc) return rc;
+    if (keep_caches && !batch_begun)  // ensure_shapes found new weights in the shared arena (weights_current): the batch this call wants to continue is gone
+      return fail(ECAD_E_NOT_READY, "ecad_rebind_batch_inputs: the weights changed since the batch began; call ecad_begin_image_batch");
+    if ((self_bias_on && (bias_bt != Bt_ || bias_n != N)) || (enc_bias_on && (bias_bt != Bt_ || bias_t != T_)))
+      return fail(ECAD_E_INVALID, "the attention bias was set for batch %d, %d tokens, %d text tokens; this batch has %d, %d, %d: call ecad_set_attention_bias for it", bias_bt, bias_n, bias_t, Bt_, N, T_);
     if (cfg.use_additional_conditions && cond_bt != Bt_)
       return fail(ECAD_E_NOT_READY, "`added_cond_kwargs` cannot be None when using additional conditions for `adaln_single`: call ecad_set_added_cond for batch %d first", Bt_);
     rc = stage_inputs(enc, mask, s);

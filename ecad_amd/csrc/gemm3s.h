@@ -213,6 +213,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       if (p.bias) bvs[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * g);
     }
   };
+  // Invariant of the last step's `s_waitcnt vmcnt(NCH)` (step_top): the newest NCH vector-memory operations of every wave at that point are exactly the residual
+  // prefetches of step nk - 2 -- no LDS-DMA piece, bias load, store or stamp may be issued between prefetch_resid() and step_top(nk - 1).  Hence: the read-modify-write
+  // epilogue never loads its bias inside the loop (below), step_stagger never runs the last two steps, and the stamps sit outside that window.
   const bool bias_in_loop = EPI != EPI_BIAS_CACHE_RESID && EPI != EPI_SPLITK && nk >= 2;
   int stage = 0;
   // top of K-step kt: stage kt has landed when at most the newest stage's DMA (A_INST + 2 = 6 per wave) is outstanding; in the step after the

@@ -99,7 +99,9 @@ int ecad_finalize_weights(EcadEngine* e);
  * submitted to different contexts on different HIP streams overlap on the device (one batch's kernel boundaries and HBM-bound kernels hide behind the other's
  * GEMMs), which is how a caller keeps several batches in flight -- the reference has one pipeline object per process and runs batches back to back
  * (image_generator.py:161-186, `generate_from_saved_prompts`).  The donor must outlive `e`.  ECAD_E_INVALID for mismatched configurations,
- * ECAD_E_UNSUPPORTED in fp8 mode (the e4m3 weight copies are per engine). */
+ * ECAD_E_UNSUPPORTED in fp8 mode (the e4m3 weight copies are per engine).  Thread safety: the per-batch calls of different contexts may run on different host
+ * threads; ecad_create / ecad_share_weights / ecad_load_weights / ecad_finalize_weights / ecad_destroy of engines that share an arena must be serialized by the
+ * caller (the arena's reference count and weight generation are plain fields). */
 int ecad_share_weights(EcadEngine* e, EcadEngine* donor);
 /* LayerNorm + modulate folded into the consumer GEMMs of the whole-loop plan (default on, env ECAD_LN_FOLD): the per-(step, block) pre-scaled weights are
  * built on the first ecad_run_schedule of a (schedule, timestep grid) -- a few milliseconds that a caller running each schedule for one batch only (the genetic

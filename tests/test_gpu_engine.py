@@ -819,6 +819,39 @@ def test_contexts_follow_new_weights_of_the_donor_and_outlive_it():
     ctx.close()
 
 
+def test_rebind_refuses_caches_of_old_weights_and_a_bias_of_another_geometry():
+    """Two state checks of the batch API (round-4 review).  (i) ecad_rebind_batch_inputs keeps the block caches; if the donor of a borrowing context has loaded
+    new weights since the batch began, those caches were computed with the OLD weights: the context drops them and refuses the rebind (ECAD_E_NOT_READY) instead
+    of replaying them under the new weights.  (ii) ecad_set_attention_bias copies [Bt, keys] floats; a batch of another geometry would read them mis-strided:
+    ecad_begin_image_batch refuses (ECAD_E_INVALID) until the bias is set again for that batch."""
+    layers, steps, B = 2, 3, 2
+    bits = rand_bits(steps, layers, 0.5, seed=9)
+    bits[0] = True
+    eng, w, cfg = make_pair(layers, bits, max_batch=2 * B)
+    inp, enc, mask = cfg_inputs(B)
+    ctx = eng.new_context()
+    ctx.begin_image_batch(enc.cuda(), mask.cuda(), 32, 32)
+    lat = inp["latents"].cuda().repeat(2, 1, 1, 1)[: 2 * B]
+    ctx.step(0, lat, torch.full((2 * B,), 900.0))
+    ctx.rebind_batch_inputs(enc.cuda(), mask.cuda(), 32, 32)  # same weights: allowed
+    eng.load_state_dict(make_weights(cfg, seed=31))
+    with pytest.raises(RuntimeError, match="weights changed since the batch began"):
+        ctx.rebind_batch_inputs(enc.cuda(), mask.cuda(), 32, 32)
+    ctx.begin_image_batch(enc.cuda(), mask.cuda(), 32, 32)  # a fresh batch is fine
+    ctx.step(0, lat, torch.full((2 * B,), 900.0))
+    # (ii)
+    bias = torch.zeros(2 * B, 256)
+    eng.set_attention_bias(bias, None)
+    eng.begin_image_batch(enc.cuda(), mask.cuda(), 32, 32)
+    with pytest.raises(ValueError, match="call ecad_set_attention_bias for it"):
+        eng.begin_image_batch(enc[:2].cuda(), mask[:2].cuda(), 32, 32)  # batch 2 against a bias copied for batch 4
+    eng.set_attention_bias(None, None)
+    eng.begin_image_batch(enc[:2].cuda(), mask[:2].cuda(), 32, 32)
+    torch.cuda.synchronize()
+    ctx.close()
+    eng.close()
+
+
 def test_layernorm_fold_respects_its_memory_budget(monkeypatch):
     """The pre-scaled weight copies of the LayerNorm fold cost 8-10.6 MB per folded (step, block, component) at D = 1152 (3.3 GB for `ours_fast`, ~10 GB for an
     all-executed 20-step schedule), per plan set and per execution context.  ECAD_LN_FOLD_BUDGET_MB bounds what an engine holds; a plan set that does not fit is

@@ -350,6 +350,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_TAIL_SPLIT")) tail_split = atoi(l) != 0;
     if (const char* l = getenv("ECAD_SPLIT_K")) split_k = atoi(l) != 0;
     if (const char* l = getenv("ECAD_GEMM4")) gemm4_wide = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_WIDE_RMW")) wide_rmw = atoi(l) != 0;
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
     // ---- weight arena
@@ -1287,6 +1288,8 @@ template <typename T> class EngineT : public EngineBase {
   bool g2_attr[4][KC_COUNT] = {};
   bool gemm4_wide = true;  // the wide tile on four waves with the hand-placed K loop (gemm2w4.h; env ECAD_GEMM4=0: the 8-wave gemm2w.h; bit-identical)
   bool g2w4_attr[4][KC_COUNT] = {};
+  bool force_wide_rmw = false;  // ecad_op_gemm_ex(kernel 2) at a read-modify-write site
+  bool wide_rmw = true;  // the read-modify-write launches on that tile where it pays (launch_pg; env ECAD_WIDE_RMW=0: always gemm3s.h; bit-identical)
   // Few rows (batch 1-4): a launch whose 256-row tiles cover less than half the chip is a latency chain (18-72 K-steps of ~0.8 us whatever the tile count);
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
@@ -1368,6 +1371,23 @@ template <typename T> class EngineT : public EngineBase {
         const bool walk = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && g.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1) && tiles2 > num_cus && tiles2 % num_cus == 0;
         hipLaunchKernelGGL((gemm2w_kernel<T, EPI, TAG>), dim3(walk ? num_cus : tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, g);
         return ECAD_OK;
+      }
+    }
+    if constexpr (EPI == EPI_BIAS_CACHE_RESID && (TAG == KC_GEMM_OUT1 || TAG == KC_GEMM_OUT2 || TAG == KC_GEMM_FF2)) {
+      // Read-modify-write launches on the wide 256 x 288 tile (gemm2w4.h; bit-identical to gemm3s, so the choice may depend on the batches in flight): 1.5x the
+      // MFMA work per operand byte of the 256 x 144 tile.  Taken when the wide tiles come in whole rounds of the chip (Sigma-1024: 512; -13 % per launch), or when
+      // they cover half of it and another batch is in flight on its own stream -- two half-chip launches of different streams run side by side: 24-25 us per
+      // launch against 27.3 (N = K = 1152), 65-68 against 81 (FF2) at M = 8192; alone on the GPU the same launch would take 41 / 99 us, hence the condition.
+      if (gemm4_wide && wide_rmw && gemm_impl_cls[TAG] == 0 && g.N % G2_BN == 0 && g2w4_shape_ok(g) && g2w4_rmw_ok(g)) {
+        const int tiles2 = (rows_of(g) / G2_BM) * (g.N / G2_BN);
+        if (force_wide_rmw || tiles2 % num_cus == 0 || (in_flight >= 2 && 2 * tiles2 >= num_cus && tiles2 < num_cus)) {
+          if (!g2w4_attr[EPI][TAG]) {
+            HIPCHK(hipFuncSetAttribute((const void*)gemm2w4_kernel<T, EPI, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G2W4_LDS_BYTES));
+            g2w4_attr[EPI][TAG] = true;
+          }
+          hipLaunchKernelGGL((gemm2w4_kernel<T, EPI, TAG>), dim3(tiles2 > num_cus ? num_cus : tiles2), dim3(256), G2W4_LDS_BYTES, s, g);
+          return ECAD_OK;
+        }
       }
     }
     if (gemm_impl_cls[TAG] == 0 || (gemm_impl_cls[TAG] == 2 && g.N % G3_BN == 0)) {  // (2: a wide call site whose wide tiles would underfill the chip)
@@ -1941,18 +1961,27 @@ template <typename T> class EngineT : public EngineBase {
     if (kernel == 6 && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "split-K exists for the read-modify-write epilogue only");
     if ((kernel < 0 || kernel > 2) && kernel != 5 && kernel != 6) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
     if (Nn % G3_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
+    // kernel 2 at a read-modify-write site = that epilogue on the wide tile (gemm2w4.h), whatever the tile count and the batches in flight say
+    const bool rmw_wide = kernel == 2 && epi == EPI_BIAS_CACHE_RESID && (site == KC_GEMM_OUT1 || site == KC_GEMM_OUT2 || site == KC_GEMM_FF2);
     if (kernel == 2) {
       if (Nn % G2_BN) return fail(ECAD_E_UNSUPPORTED, "gemm2w tiles need N %% 288 == 0, got %d", Nn);
-      if (site != KC_GEMM_FF1 && site != KC_GEMM_TEXTKV && site != KC_GEMM_SMALL && site != KC_GEMM_KV1)
-        return fail(ECAD_E_UNSUPPORTED, "gemm2w is instantiated for the FF1 / text-KV / attn1-KV / small call sites only");
+      if (rmw_wide) {
+        if (!g2w4_shape_ok(g) || !g2w4_rmw_ok(g)) return fail(ECAD_E_UNSUPPORTED, "the read-modify-write epilogue on the wide tile needs whole 256-row tiles inside one sample each and K %% 128 == 0");
+      } else if (site != KC_GEMM_FF1 && site != KC_GEMM_TEXTKV && site != KC_GEMM_SMALL && site != KC_GEMM_KV1)
+        return fail(ECAD_E_UNSUPPORTED, "gemm2w is instantiated for the FF1 / text-KV / attn1-KV / small call sites (and, with the read-modify-write epilogue, both out-projections and FF2) only");
     }
     const int keep = gemm_impl_cls[site];
-    const bool keep_lat = latency_tiles;
-    gemm_impl_cls[site] = kernel;
+    const bool keep_lat = latency_tiles, keep_wide = wide_rmw;
+    const int keep_force = force_wide_rmw;
+    gemm_impl_cls[site] = rmw_wide ? 0 : kernel;
     latency_tiles = false;  // the caller named the kernel: no few-rows substitution (kernel 5 IS the latency tile)
+    wide_rmw = rmw_wide;    // ... and no wide-tile substitution either
+    force_wide_rmw = rmw_wide;
     const int rc = launch_gemm(epi, site, g, s);
     gemm_impl_cls[site] = keep;
     latency_tiles = keep_lat;
+    wide_rmw = keep_wide;
+    force_wide_rmw = keep_force;
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return ECAD_OK;

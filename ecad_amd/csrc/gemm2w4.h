@@ -19,6 +19,11 @@ constexpr int G2W4_CST = G2_TILE_BYTES;               // bias[288] | c1[288] | (
 constexpr int G2W4_LDS_BYTES = G2W4_CST + 4352;
 static_assert(G2W4_LDS_BYTES <= 160 * 1024, "ring + C tile + epilogue constants");
 
+// read-modify-write epilogue on this tile: no replayed components (gemm3s.h carries those), the gate of one sample per tile, whole tiles of the residual
+template <typename T> inline bool g2w4_rmw_ok(const GemmArgs<T>& g) {
+  return g.resid && g.n_xsrc == 0 && !g.ln_stat && (!g.gate_table || (g.rows_per_batch > 0 && g.rows_per_batch % G2_BM == 0));
+}
+
 template <typename T> inline bool g2w4_shape_ok(const GemmArgs<T>& g) {
   const int rows = (g.m_end ? g.m_end : g.M) - g.m_begin;
   return g.M % G2_BM == 0 && rows % G2_BM == 0 && g.m_begin % G2_BM == 0 && g.N % G2_BN == 0 && g.K % (2 * GEMM_BK) == 0;
@@ -63,6 +68,7 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
       const int t = threadIdx.x;
       if (t < 72) {
         if (p.bias) glds16_raw(p.bias + n0 + 4 * t, lds + (unsigned)G2W4_CST + (unsigned)wave * 1024u);
+        else if (EPI == EPI_BIAS_CACHE_RESID) reinterpret_cast<f32x4*>(cst)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the statement's own C-tile staging adds what it finds here
         if (fold) glds16_raw(p.ln_c1 + n0 + 4 * t, lds + (unsigned)G2W4_CST + 1152u + (unsigned)wave * 1024u);
       }
       if (fold) {
@@ -70,15 +76,31 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
         ln_row_coeffs<1>(p, m0 + t, ca, cb);
         reinterpret_cast<f32x2*>(cst + 2304)[t] = (f32x2){ca[0], cb[0]};
       }
+      if constexpr (EPI == EPI_BIAS_CACHE_RESID) {  // the gate of the tile's sample (g2w4_shape_ok: the tile lies inside one): table[288] fp32 | modulation[288] T, raw; added at use
+        if (p.gate_table) {
+          if (t < 72) glds16_raw(p.gate_table + n0 + 4 * t, lds + (unsigned)G2W4_CST + 1152u + (unsigned)wave * 1024u);
+          if (p.gate_mod && t < 36) glds16_raw(p.gate_mod + (size_t)(m0 / p.rows_per_batch) * p.gate_mod_stride + n0 + 8 * t, lds + (unsigned)G2W4_CST + 2304u);
+        }
+      }
     }
     f32x4 c8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) c8[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-      const char* ap = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
-      const char* wp = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
+      // (scalar operands of the statement: said so explicitly -- hipcc does not always prove a tile origin uniform)
+      auto uniform = [](const void* q) {
+        const unsigned long long u = (unsigned long long)q;
+        return reinterpret_cast<const char*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u) |
+                                             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32)) << 32));
+      };
+      const char* ap = uniform(p.A + (size_t)m0 * p.lda);
+      const char* wp = uniform(p.W + (size_t)n0 * p.ldw);
       const unsigned zero = 1u;
-      if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_288(ap, wp, rsa, rsw, trips, lds, wave, zero, c8); }
+      if constexpr (EPI == EPI_BIAS_CACHE_RESID) {  // K loop + round(acc + bias) into the C tile, all inside the statement (scripts/gen_gemm4.py, stage_c)
+        const unsigned cst = lds + (unsigned)G2W4_CST;
+        if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_288S(ap, wp, rsa, rsw, trips, lds, wave, zero, cst); }
+        else { GEMM4_ASM_F16_288S(ap, wp, rsa, rsw, trips, lds, wave, zero, cst); }
+      } else if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_288(ap, wp, rsa, rsw, trips, lds, wave, zero, c8); }
       else { GEMM4_ASM_F16_288(ap, wp, rsa, rsw, trips, lds, wave, zero, c8); }
     }
 #ifdef G2W4_STAMP
@@ -149,6 +171,79 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
       }
       return o;
     };
+    if constexpr (EPI == EPI_BIAS_CACHE_RESID) {
+      // cache <- out; h += gate . out (cached_transformer_block.py:243-246,317-320,355-360) and the row statistics of the updated h for a LayerNorm folded into the next
+      // GEMM -- gemm3s.h's read-modify-write epilogue on this tile: the same operations on the same values in the same order (per 144-column half for the statistics),
+      // so a launch may run on either kernel.  Wave w streams rows 64 w .. 64 w + 63: 36 sixteen-byte chunks per lane.
+      constexpr int CPR = G2_BN / 8, NIT = 64 * CPR / 64;
+      // The statement has already rounded acc + bias into the C tile (a C++ staging short of registers had its spills land in the AGPRs, i.e. in the accumulators).
+      T* ctile = reinterpret_cast<T*>(smem);
+      const int rlane = lane;
+      Pack8 hpre[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = rlane + it * 64;
+        const int rl = id / CPR, cchunk = id - rl * CPR;
+        hpre[it] = gload16(p.resid + (size_t)(m0 + wave * 64 + rl) * p.ldr + n0 + cchunk * 8);
+      }
+      __syncthreads();
+      const bool gated = p.gate_table != nullptr, modulated = gated && p.gate_mod != nullptr;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = rlane + it * 64;
+        const int rl = id / CPR, cchunk = id - rl * CPR;
+        const int ml = wave * 64 + rl;
+        const int m = m0 + ml, n = n0 + cchunk * 8;
+        const Pack8 v = lds_read16(ctile + ml * G2_CS + cchunk * 8);
+        if (p.C) gstore16_nt(p.C + (size_t)m * p.ldc + n, v);
+        float o[8], h[8];
+        unpack8<T>(v, o);
+        unpack8<T>(hpre[it], h);
+        if (gated) {
+          // gemm3s.h: gate = table + modulation as one fp32 sum (it passes through LDS there), then h <- fma(gate, out, h), written as the builtin in both files: left to
+          // -ffast-math the two kernels came out with different mixtures of fused and unfused updates (they differ on exact ties of the final rounding)
+#pragma clang fp reassociate(off) contract(off)
+          f32x4 g0 = *reinterpret_cast<const f32x4*>(cst + 1152 + cchunk * 32), g1 = *reinterpret_cast<const f32x4*>(cst + 1152 + cchunk * 32 + 16);
+          if (modulated) {
+            float gm[8];
+            unpack8<T>(lds_read16(cst + 2304 + cchunk * 16), gm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g0[e] += gm[e]; g1[e] += gm[4 + e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h[e] = __builtin_fmaf(g0[e], o[e], h[e]); h[4 + e] = __builtin_fmaf(g1[e], o[4 + e], h[4 + e]); }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] += o[e];
+        }
+        const Pack8 hn = pack8<T>(h);
+        gstore16(p.resid + (size_t)m * p.ldr + n, hn);
+        if (p.stat_out) *reinterpret_cast<u32x4*>(ctile + ml * G2_CS + cchunk * 8) = hn.u;  // the wave's own rows of the C tile now hold the updated hidden states
+      }
+      if (p.stat_out) {
+        // lane l: row l of the wave's 64, both 144-column halves; per half chunks 0..8 then 9..17 in order, lower sum + upper sum (gemm3s.h's order, pinned)
+#pragma clang fp reassociate(off) contract(off)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int tn2 = 2 * (n0 / G2_BN);
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          float sx[2] = {0.f, 0.f}, sxx[2] = {0.f, 0.f};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+              float x[8];
+              unpack8<T>(lds_read16(ctile + (wave * 64 + rlane) * G2_CS + (part * 18 + hh * 9 + c) * 8), x);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { sx[hh] += x[e]; sxx[hh] = __builtin_fmaf(x[e], x[e], sxx[hh]); }
+            }
+          float* dst = p.stat_out + ((size_t)(tn2 + part) * p.M + m0 + wave * 64 + rlane) * 2;
+          dst[0] = sx[0] + sx[1];
+          dst[1] = sxx[0] + sxx[1];
+        }
+      }
+      return;
+    }
     const bool direct = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.epi_direct > (EPI == EPI_BIAS_GELU ? 0 : 1);
     if (direct) {
       // rows leave straight from the registers: fragments j, j + 1 paired by v_permlane16_swap into 16-byte pieces (gemm2w.h), the ninth fragment in 8-byte stores

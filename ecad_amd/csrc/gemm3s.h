@@ -461,9 +461,10 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       unpack8<T>(v, o);
       unpack8<T>(hv, h);
       if (gate_lds) {
+#pragma clang fp reassociate(off) contract(off)  // one fused multiply-add per element, said explicitly: gemm2w4.h's read-modify-write epilogue reproduces this update bit for bit
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gwave + cchunk * 8), g1 = *reinterpret_cast<const f32x4*>(gwave + cchunk * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { h[e] += g0[e] * o[e]; h[4 + e] += g1[e] * o[4 + e]; }
+        for (int e = 0; e < 4; ++e) { h[e] = __builtin_fmaf(g0[e], o[e], h[e]); h[4 + e] = __builtin_fmaf(g1[e], o[4 + e], h[4 + e]); }
       } else if (p.gate_table) {
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.gate_table + n);
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.gate_table + n + 4);
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void gemm3s_kernel(const GemmArgs<T> p
       // row statistics for a LayerNorm folded into the NEXT GEMM (gemm.h): lane l sums row (l & 31), chunks [9 (l >> 5), 9 (l >> 5) + 9) of the wave's 32 rows in
       // fixed order, the two halves meet through one shuffle: deterministic, and no atomics anywhere.  Values are the ROUNDED hidden states, i.e. exactly what
       // the LayerNorm kernel would read back from memory.
+#pragma clang fp reassociate(off) contract(off)  // the order below is the definition of these numbers: gemm2w4.h's read-modify-write epilogue reproduces it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int rl = lane & (WTM - 1), hh = (lane / WTM) & 1;  // 16-row wave tiles: lanes 32-63 repeat lanes 0-31 and do not store
       float sx = 0.f, sxx = 0.f;

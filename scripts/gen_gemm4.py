@@ -50,8 +50,9 @@ class Gen:
     """dtype bf16 | f16: two 32-deep sub-steps per 64-element stage, fragments of 4 registers, two whole fragment sets alternate.
     dtype fp8: one 128-deep step per stage, fragments of 8 registers (two 16-byte reads), A in two alternating sets, W in a rolling window of four."""
 
-    def __init__(self, dtype, bn):
+    def __init__(self, dtype, bn, stage=False):
         self.dt, self.BN = dtype, bn
+        self.stage = stage                       # BN 288 only: after the K loop the statement itself rounds acc + bias into the row-major C tile in LDS (see stage_c)
         self.fp8 = dtype == "fp8"
         self.FN = bn // 32                       # W fragments per wave (wave tile 128 x BN/2)
         self.NS = 3 if bn == 128 else 2          # ring slots (BN 288: the PixArt FF1 / K,V tile of gemm2w.h, 2 x 68 KiB)
@@ -74,6 +75,9 @@ class Gen:
         self.TMP = self.WOFF + self.WP
         self.SC = self.TMP + 8                    # e4m3: the unit block scale
         self.NV = self.SC + 1
+        if stage:
+            self.C8 = self.NV                     # the ninth accumulator column in registers of the statement (nobody outside reads the accumulators of this variant)
+            self.NV += 32
         self.lines, self.q = [], []
         self.mfma = "v_mfma_scale_f32_16x16x128_f8f6f4" if self.fp8 else f"v_mfma_f32_16x16x32_{dtype}"
         nreads = 10 if self.fp8 else 8 + self.FN   # read groups behind the barrier
@@ -86,7 +90,9 @@ class Gen:
 
     def acc(self, i, j):
         """accumulator fragment (i, j): AGPRs a[4 (8 i + j) ..] for j < 8; the ninth column of the 288-wide tile lives in eight "+v" operands of the statement"""
-        return a(4 * (8 * i + j), 4) if j < 8 else f"%[c8_{i}]"
+        if j < 8:
+            return a(4 * (8 * i + j), 4)
+        return v(self.C8 + 4 * i, 4) if self.stage else f"%[c8_{i}]"
 
     def I(self, t):
         if ("mfma" in ABLATE and t.startswith("v_mfma")) or ("read" in ABLATE and t.startswith("ds_read")) or ("dma" in ABLATE and t.startswith("global_load_lds")):
@@ -285,6 +291,9 @@ class Gen:
                 for r in range(4):
                     I(f"v_accvgpr_write_b32 {a(4 * (8 * i + j) + r)}, 0")
         self.L("KEEP")
+        if self.stage:
+            for r in range(32):
+                I(f"v_mov_b32_e32 {v(self.C8 + r)}, 0")
         for slot in range(NS - 1):          # the first NS - 1 stages
             for which, n in (("a", 8), ("w", self.WP)):
                 for p in range(n):
@@ -331,8 +340,54 @@ class Gen:
             emit(k, left >= NS - 1, vm if left >= NS - 1 else 0, left == 0)
         I("s_nop 15")
         I("s_barrier")   # every wave is done with the ring: the epilogue's C tile may overwrite it
+        if self.stage:
+            self.stage_c()
         I(f"s_mov_b32 m0, {s('m0save')}")
         return self.lines
+
+    def stage_c(self):
+        """round(acc + bias) of the wave's 128 x 144 block into the row-major C tile at the start of the LDS (row stride 592 bytes = gemm2w.h's G2_CS), the 288 bias
+        values read from LDS at %[cst].  Inside the statement because hipcc treats the AGPRs as free spill space once the K loop is behind it: a C++ epilogue that is
+        short of registers (the read-modify-write row pass holds 36 residual chunks per lane) had its spills land in the accumulators.  Same arithmetic as the C++
+        epilogues: fp32 add, then one conversion with the default rounding."""
+        I, T = self.I, self.TMP
+        BV, TT, PK, B0 = 0, 40, 56, 64       # bias [9][4] | 4 x 4 temporaries | 4 x 2 packed | two row bases (fragment rows 0-3 / 4-7: 16-bit ds offsets)
+        cvt = "v_cvt_pk_bf16_f32" if self.dt == "bf16" else "v_cvt_pk_f16_f32"
+        I(f"v_mbcnt_lo_u32_b32 {v(T)}, -1, 0")
+        I(f"v_mbcnt_hi_u32_b32 {v(T)}, -1, {v(T)}")
+        I(f"v_and_b32_e32 {v(T + 1)}, 15, {v(T)}")                  # l15
+        I(f"v_lshrrev_b32_e32 {v(T + 2)}, 4, {v(T)}")               # g
+        I(f"s_and_b32 {s('tmp0')}, %[wave], 1")                     # wm
+        I(f"s_lshr_b32 {s('tmp1')}, %[wave], 1")                    # wn
+        I(f"s_mul_i32 {s('tmp0')}, {s('tmp0')}, {128 * 592}")
+        I(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, 144")               # first column of the wave's block
+        I(f"v_lshl_add_u32 {v(T + 3)}, {v(T + 2)}, 2, {s('tmp1')}")  # column wn 144 + 4 g
+        I(f"v_mul_u32_u24_e32 {v(B0)}, 592, {v(T + 1)}")             # (wm 128 + l15) rows (VOP3 takes no literal on gfx9)
+        I(f"v_add_u32_e32 {v(B0)}, {s('tmp0')}, {v(B0)}")
+        I(f"v_lshl_add_u32 {v(B0)}, {v(T + 3)}, 1, {v(B0)}")         # + 2 bytes per column
+        I(f"v_add_u32_e32 {v(B0)}, %[lds], {v(B0)}")
+        I(f"v_add_u32_e32 {v(B0 + 1)}, {4 * 16 * 592}, {v(B0)}")
+        I(f"v_lshl_add_u32 {v(T + 4)}, {v(T + 3)}, 2, %[cst]")       # bias: 4 bytes per column
+        for j in range(9):
+            I(f"ds_read_b128 {v(BV + 4 * j, 4)}, {v(T + 4)} offset:{64 * j}")
+        I("s_waitcnt lgkmcnt(0)")
+        n = 0
+        for i in range(8):
+            for j in range(9):
+                t, pk = TT + 4 * (n % 4), PK + 2 * (n % 4)
+                if j < 8:
+                    for r in range(4):
+                        I(f"v_accvgpr_read_b32 {v(t + r)}, {a(4 * (8 * i + j) + r)}")
+                    src = t
+                else:
+                    src = self.C8 + 4 * i
+                I(f"v_pk_add_f32 {v(t, 2)}, {v(src, 2)}, {v(BV + 4 * j, 2)}")
+                I(f"v_pk_add_f32 {v(t + 2, 2)}, {v(src + 2, 2)}, {v(BV + 4 * j + 2, 2)}")
+                I(f"{cvt} {v(pk)}, {v(t)}, {v(t + 1)}")
+                I(f"{cvt} {v(pk + 1)}, {v(t + 2)}, {v(t + 3)}")
+                I(f"ds_write_b64 {v(B0 + i // 4)}, {v(pk, 2)} offset:{(i % 4) * 16 * 592 + 32 * j}")
+                n += 1
+        I("s_waitcnt lgkmcnt(0)")
 
 
 OPERANDS = """\
@@ -342,6 +397,12 @@ OPERANDS = """\
 OPERANDS_288 = """\
       : [c8_0] "+v"(c8[0]), [c8_1] "+v"(c8[1]), [c8_2] "+v"(c8[2]), [c8_3] "+v"(c8[3]), [c8_4] "+v"(c8[4]), [c8_5] "+v"(c8[5]), [c8_6] "+v"(c8[6]), [c8_7] "+v"(c8[7])
       : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
+"""
+
+
+OPERANDS_288S = """\
+      : /* accumulators stay inside the statement: it leaves the rounded C tile in LDS */
+      : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero), [cst] "s"(cst)
 """
 
 
@@ -364,6 +425,13 @@ def main():
             parts.append(f"#define GEMM4_PERIOD_{dt.upper()}_{bn} {g.period}  // K stages per trip of the loop: a K segment must hold a whole number of them\n"
                          f"#define GEMM4_ASM_{dt.upper()}_{bn}(ap, wp, rsa, rsw, trips, lds, wave, zero{', c8' if bn == 288 else ''}) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
                          + "\n".join(x + " \\" for x in (OPERANDS_288 if bn == 288 else OPERANDS).rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV) + ")\n")
+    for dt in ("bf16", "f16"):
+        g = Gen(dt, 288, stage=True)
+        lines = g.build()
+        print(f"{dt} BN 288 + C-tile staging: {len(lines)} lines, {g.NV} VGPRs", file=sys.stderr)
+        body = "\n".join('    "' + ln + '\\n"' for ln in lines)
+        parts.append(f"#define GEMM4_ASM_{dt.upper()}_288S(ap, wp, rsa, rsw, trips, lds, wave, zero, cst) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
+                     + "\n".join(x + " \\" for x in OPERANDS_288S.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV) + ")\n")
     out.write_text("\n".join(parts))
 
 

@@ -109,8 +109,10 @@ int ecad_share_weights(EcadEngine* e, EcadEngine* donor);
 int ecad_set_ln_fold(EcadEngine* e, int on);
 /* How many image batches the caller keeps in flight on this GPU (this context and the ones sharing its weights; default 1).  With few rows per launch (batch 1-8) the
  * engine runs its GEMMs on 64-row latency tiles while the launch's 256-row tiles would cover at most half the chip; the tiles of the other batches in
- * flight count towards that half, so that a caller that fills the GPU with several small batches keeps the throughput kernels.  Results do not depend on it (both
- * tile shapes are the same arithmetic).  ECAD_E_INVALID outside 1..64. */
+ * flight count towards that half, so that a caller that fills the GPU with several small batches keeps the throughput kernels.  From two batches in flight on, the
+ * read-modify-write GEMMs whose wide tiles cover half the chip (batch 16: both out-projections and FF2) go out as half-chip launches that run beside another
+ * stream's kernels: faster per launch pair, slower than the full-chip kernel when nothing else runs -- say 1 when the batches are not really
+ * concurrent.  Results do not depend on it (every tile shape is the same arithmetic, bit for bit).  ECAD_E_INVALID outside 1..64. */
 int ecad_set_batches_in_flight(EcadEngine* e, int n);
 /* Opt-in OCP fp8 (e4m3) for the block GEMMs (QKV, attention out-projections, cross-attention Q, FF1, FF2): e4m3 weight copies with
  * per-output-channel scales at finalize, activations quantised per row in front of each GEMM (csrc/gemm3s8.h).  Call before

@@ -209,6 +209,20 @@ template <int TAG> static void rmw_case(const char* name, int M, int N, int K, b
     CK(hipMemcpy(sa.data(), ST[0], sa.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(sb.data(), ST[1], sb.size() * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < sa.size(); ++i) diff[2] += sa[i] != sb[i];
   }
+#ifdef G2W4_STAMP
+  {
+    for (int r = 0; r < 100; ++r) launch(0, 0);
+    CK(hipDeviceSynchronize());
+    const int nb = wide > cus && wide % cus == 0 ? cus : wide;
+    std::vector<unsigned long long> sv(4 * nb);
+    CK(hipMemcpyFromSymbol(sv.data(), HIP_SYMBOL(g2w4_stamp), sv.size() * 8));
+    std::vector<double> a, b, c, f;
+    for (int i = 0; i < nb; ++i) { a.push_back((double)sv[4 * i]); b.push_back((double)sv[4 * i + 1]); c.push_back((double)sv[4 * i + 2]); f.push_back((double)sv[4 * i + 2] / (double)sv[4 * i + 3] * 0.1); }
+    auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    const int per = (wide + nb - 1) / nb;
+    printf("    stamps (%d tiles per workgroup): K loop + C-tile staging %.0f cycles/tile, row pass %.0f cycles/tile, workgroup %.0f cycles, clock %.2f GHz\n", per, med(a) / per, med(b) / per, med(c), med(f));
+  }
+#endif
   hipStream_t st[3];
   for (auto& q : st) CK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

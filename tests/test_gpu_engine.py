@@ -311,6 +311,13 @@ def test_baseline_batch16_properties():
     c = eng.run_schedule(*args, use_graph=False)
     assert torch.isfinite(a).all()
     assert torch.equal(a, b) and torch.equal(a, c)
+    # with batches in flight (round 5) both out-projections and FF2 of this batch go out as half-chip launches on 256 x 288 tiles (gemm2w4.h's
+    # read-modify-write epilogue) instead of gemm3s.h's full-chip ones: another kernel, another plan set and graph -- the same bits
+    caps = eng.stats()["graph_captures"]
+    eng.set_batches_in_flight(3)
+    d = eng.run_schedule(*args, use_graph=True)
+    assert eng.stats()["graph_captures"] == caps + 1 and torch.equal(a, d)
+    eng.set_batches_in_flight(1)
     # sample 5 alone (its uncond/text rows only)
     idx = 5
     sel = torch.tensor([idx, 16 + idx])

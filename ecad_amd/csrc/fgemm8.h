@@ -61,6 +61,47 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const TS* __restric
   const TS* s1 = src1 + (size_t)row * ld1;
   const TS* s2 = src2 ? src2 + (size_t)row * ld2 : nullptr;
   const int c1 = K1 >> 3, ctot = c1 + (K2 >> 3);
+  u32x2* d = reinterpret_cast<u32x2*>(dst + (size_t)row * ldd);
+  // Rows of up to 16384 elements (every row of both models: K <= 5 D = 15360) stay in the wave's registers between the maximum and the conversion -- 32 chunks of
+  // 16 bytes per lane -- so the row is read once.  The two-pass form below re-read it "from L2", but with every CU holding 32 rows of 30 KB in flight the second
+  // pass came from the Infinity Cache / HBM: 5 bytes of traffic per element instead of 3 (round 5: fp8_quant_rows 48 -> ms per FLUX batch).
+  constexpr int NR = 32;
+  if (ctot <= 64 * NR) {
+    Pack8 buf[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      buf[i].u = (u32x4){0, 0, 0, 0};
+      if (64 * i < ctot) {  // wave-uniform
+        const int c = lane + 64 * i;
+        if (c < ctot) buf[i] = gload16(c < c1 ? s1 + c * 8 : s2 + (c - c1) * 8);
+      }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (64 * i < ctot) {
+        float v[8];
+        unpack8<TS>(buf[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (64 * i < ctot) {
+        const int c = lane + 64 * i;
+        float v[8];
+        unpack8<TS>(buf[i], v);
+        if (c < ctot) d[c] = (u32x2){pack_fp8x4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv), pack_fp8x4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv)};
+      }
+    }
+    return;
+  }
   float amax = 0.f;
   for (int c = lane; c < ctot; c += 64) {
     float v[8];
@@ -73,8 +114,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const TS* __restric
   const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
   const float inv = 1.0f / sc;
   if (lane == 0) scale[row] = sc;
-  u32x2* d = reinterpret_cast<u32x2*>(dst + (size_t)row * ldd);
-  for (int c = lane; c < ctot; c += 64) {  // second pass over the row: L2-resident
+  for (int c = lane; c < ctot; c += 64) {  // second pass over the row
     float v[8];
     unpack8<TS>(gload16(c < c1 ? s1 + c * 8 : s2 + (c - c1) * 8), v);
     d[c] = (u32x2){pack_fp8x4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv), pack_fp8x4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv)};

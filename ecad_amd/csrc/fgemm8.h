@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const TS* __restric
   u32x2* d = reinterpret_cast<u32x2*>(dst + (size_t)row * ldd);
   // Rows of up to 16384 elements (every row of both models: K <= 5 D = 15360) stay in the wave's registers between the maximum and the conversion -- 32 chunks of
   // 16 bytes per lane -- so the row is read once.  The two-pass form below re-read it "from L2", but with every CU holding 32 rows of 30 KB in flight the second
-  // pass came from the Infinity Cache / HBM: 5 bytes of traffic per element instead of 3 (round 5: fp8_quant_rows 48 -> ms per FLUX batch).
+  // pass came from the Infinity Cache / HBM: 5 bytes of traffic per element instead of 3 (round 5: fp8_quant_rows 48 -> 33 ms per FLUX batch).
   constexpr int NR = 32;
   if (ctot <= 64 * NR) {
     Pack8 buf[NR];

@@ -1,5 +1,5 @@
 // probe_fewrows.hip -- the 64-row latency tiles of gemm3s.h at batch-1 rows (M = 512) with weights that rotate through more bytes than the Infinity Cache holds, as the
-// 28 layers of a step do: microseconds per launch and the -DG_STAMP cycles of fill / K loop / epilogue, for the 3-stage ring (two workgroups per CU) and the 6-stage ring.
+// 28 layers of a step do: microseconds per launch and the -DG_STAMP cycles of fill / K loop / epilogue, for the 64-row tile on four waves (the product's) and a 128-row tile on eight (more waves issuing LDS-DMA per tile; the six-stage ring of round 5 is described in DESIGN 5f).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DECAD_DIAG -DG_STAMP scripts/probe_fewrows.hip -o build_tmp/probe_fewrows
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -74,11 +74,11 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 600;
   for (int M : {512, 2048}) {
     run_case("plain 64x144 3-stage", lat<EPI_BIAS, 0, 64, 4, 3>, M, 1152, 1152, 0, reps);
-    run_case("plain 64x144 6-stage", lat<EPI_BIAS, 0, 64, 4, 6>, M, 1152, 1152, 0, reps);
+    run_case("plain 128x144 8 waves", lat<EPI_BIAS, 0, 128, 8, 3>, M, 1152, 1152, 0, reps);
     run_case("rmw 64x144 3-stage", lat<EPI_BIAS_CACHE_RESID, 1, 64, 4, 3>, M, 1152, 1152, 3, reps);
-    run_case("rmw 64x144 6-stage", lat<EPI_BIAS_CACHE_RESID, 1, 64, 4, 6>, M, 1152, 1152, 3, reps);
+    run_case("rmw 128x144 8 waves", lat<EPI_BIAS_CACHE_RESID, 1, 128, 8, 3>, M, 1152, 1152, 3, reps);
     run_case("gelu N=4608 64x144 3-stage", lat<EPI_BIAS_GELU, 4, 64, 4, 3>, M, 4608, 1152, 1, reps);
-    run_case("gelu N=4608 64x144 6-stage", lat<EPI_BIAS_GELU, 4, 64, 4, 6>, M, 4608, 1152, 1, reps);
+    run_case("gelu N=4608 128x144 8 waves", lat<EPI_BIAS_GELU, 4, 128, 8, 3>, M, 4608, 1152, 1, reps);
     run_case("plain 256x144 8 waves", lat<EPI_BIAS, 0, 256, 8, 3>, M, 1152, 1152, 0, reps);
   }
   return 0;

@@ -138,6 +138,8 @@ int main(int argc, char** argv) {
   run<FEPI_BIAS>("bias", 512, 512, 256, 0, 2);
   run<FEPI_BIAS>("bias", 1024, 3072, 3072, 0, reps);
   run<FEPI_BIAS>("bias (single qkv)", 9216, 9216, 3072, 0, reps);
+  run<FEPI_BIAS>("pixart ff1 shape", 8192, 4608, 1152, 0, 4 * reps);
+  run<FEPI_BIAS, 128>("pixart ff1 shape", 8192, 4608, 1152, 0, 4 * reps);
   run<FEPI_BIAS_GELU>("gelu direct (ff1)", 8192, 12288, 3072, 0, reps);
   run<FEPI_BIAS_GATE_RESID>("gate+resid (ff2)", 8192, 3072, 12288, 0, reps);
   run<FEPI_BIAS_GATE_RESID>("gate+resid split-A", 9216, 3072, 15360, 3072, reps);

@@ -636,7 +636,13 @@ def main():
                          + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
                          + "\n".join(x + " \\" for x in OPERANDS.rstrip("\n").split("\n")) + "\n"
                          + "      : " + clobbers() + ")\n")
-    out.write_text("\n".join(parts))
+    text = "\n".join(parts)
+    if "--check" in sys.argv:   # the committed header is what this generator writes (tests/test_cpu_host.py)
+        if ABLATE or out.read_text() != text:
+            print(f"{out} differs from the generator's output", file=sys.stderr)
+            sys.exit(1)
+        return
+    out.write_text(text)
     print(f"wrote {out}", file=sys.stderr)
 
 

@@ -432,7 +432,13 @@ def main():
         body = "\n".join('    "' + ln + '\\n"' for ln in lines)
         parts.append(f"#define GEMM4_ASM_{dt.upper()}_288S(ap, wp, rsa, rsw, trips, lds, wave, zero, cst) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
                      + "\n".join(x + " \\" for x in OPERANDS_288S.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV) + ")\n")
-    out.write_text("\n".join(parts))
+    text = "\n".join(parts)
+    if "--check" in sys.argv:   # the committed header is what this generator writes (tests/test_cpu_host.py)
+        if ABLATE or out.read_text() != text:
+            print(f"{out} differs from the generator's output", file=sys.stderr)
+            sys.exit(1)
+        return
+    out.write_text(text)
 
 
 if __name__ == "__main__":

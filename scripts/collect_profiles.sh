@@ -4,7 +4,7 @@
 #   gpurun -- 'bash scripts/collect_profiles.sh r03_a'                      # headline: PixArt-alpha 256, batch 16
 #   gpurun -- 'bash scripts/collect_profiles.sh r03_a sigma1024'            # BASELINE config 3
 #   gpurun -- 'bash scripts/collect_profiles.sh r03_a flux1024 [--fp8]'     # BASELINE config 5 (bf16, or the fp8 mode it names)
-# Outputs under gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards.  The program sits directly after `--` (never env / bash -c).
+# Outputs under gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards (bash scripts/copy_profiles.sh <tag>: the box's own profiles/ is not merged back).  The program sits directly after `--` (never env / bash -c).
 set -u
 TAG=${1:-r03_x}
 WL=${2:-alpha256}

@@ -76,8 +76,18 @@ def main():
     eng = EcadEngine(num_layers=1, max_batch=2, dtype=torch.float16)
     gem = [("gemm_q (N=K=1152, plain)", "tile144", "qkv", 0, 8192, 1152, 1152), ("gemm_attn1_out (read-modify-write)", "tile144", "attn1_out", 3, 8192, 1152, 1152),
            ("gemm_ff2 (K=4608, read-modify-write)", "tile144", "ff2", 3, 8192, 1152, 4608), ("gemm_attn1_kv_wide", "wide288", "attn1_kv", 0, 8192, 2304, 1152),
-           ("gemm_ff1_gelu", "wide288", "ff1", 1, 8192, 4608, 1152)]
+           ("gemm_ff1_gelu", "wide288", "ff1", 1, 8192, 4608, 1152),
+           # round 5: the read-modify-write epilogue on the wide tile (gemm2w4.h).  Alone on the chip a 128-tile launch leaves half of it idle (the product takes it with batches in
+           # flight only); whole rounds at the Sigma-1024 row count
+           ("gemm_attn1_out on 256x288 tiles, half the chip", "wide288", "attn1_out", 3, 8192, 1152, 1152), ("gemm_ff2 on 256x288 tiles, half the chip", "wide288", "ff2", 3, 8192, 1152, 4608),
+           ("gemm_ff2 M=32768 (256x144 tiles)", "tile144", "ff2", 3, 32768, 1152, 4608), ("gemm_ff2 M=32768 on 256x288 tiles", "wide288", "ff2", 3, 32768, 1152, 4608)]
+    os.environ["ECAD_GEMM4"] = "0"
+    eng8 = EcadEngine(num_layers=1, max_batch=2, dtype=torch.float16)   # the 8-wave gemm2w.h behind the same kernel name
+    os.environ.pop("ECAD_GEMM4", None)
+    gem += [("gemm_attn1_kv_wide (gemm2w.h, 8 waves)", "wide288@8", "attn1_kv", 0, 8192, 2304, 1152), ("gemm_ff1_gelu (gemm2w.h, 8 waves)", "wide288@8", "ff1", 1, 8192, 4608, 1152)]
     for name, kernel, site, epi, M, N, K in gem:
+        eng_k = eng8 if kernel.endswith("@8") else eng
+        kernel = kernel.split("@")[0]
         per_set = (M * K + N * K + M * N * (2 if epi == 3 else 1)) * 2
         nsets = max(2, min(12, int(600e6 // per_set) + 1))
         sets = []
@@ -94,7 +104,7 @@ def main():
         def launch():
             a, w, o, r = sets[k[0] % nsets]
             k[0] += 1
-            eng.op_gemm_ex(kernel, site, epi, a, w, bias, resid=r, gate_table=gate, rows_per_batch=256, out=o)
+            eng_k.op_gemm_ex(kernel, site, epi, a, w, bias, resid=r, gate_table=gate, rows_per_batch=256, out=o)
 
         out[name] = measure(name, launch, 2.0 * M * N * K)
         del sets
@@ -103,6 +113,7 @@ def main():
     q, k_, v = qkv[:, : H * dh], qkv[:, H * dh: 2 * H * dh], qkv[:, 2 * H * dh:]
     out["attn_self Sigma-1024 (d_h 72)"] = measure("attn_self Sigma-1024 (d_h 72)", lambda: eng.op_attention(q, k_, v, B, H, N, N, dh), 4.0 * B * H * N * N * dh)
     eng.close()
+    eng8.close()
     del qkv
     for label, env in (("attn_joint FLUX (attention_w4.h)", None), ("attn_joint FLUX (attention_dma.h)", "dma")):
         if env:

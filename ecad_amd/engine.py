@@ -403,6 +403,7 @@ class EngineContexts:
         self._turn = 0
         for e in self.engines:  # the few-rows rule counts all the batches in flight: latency tiles only while the chip would otherwise idle
             e.set_batches_in_flight(n)
+        self._declared = [n] * n  # what each context was last told (submit() lowers it to 1 for a batch that finds the other streams idle)
 
     def __len__(self) -> int:
         return len(self.engines)
@@ -416,6 +417,13 @@ class EngineContexts:
         k = self._turn % len(self.engines)
         self._turn += 1
         st = self.streams[k]
+        # what this batch will run beside: with another context's batch still on the device the engine may launch half-chip kernels that share the chip with it;
+        # a batch that has the GPU to itself gets the full-chip ones.  Two plan sets (and graphs) per context, both kept; the results are the same bits.
+        busy = sum(1 for j, other in enumerate(self.streams) if j != k and not other.query())
+        want = len(self.engines) if busy else 1
+        if self._declared[k] != want:
+            self.engines[k].set_batches_in_flight(want)
+            self._declared[k] = want
         st.wait_stream(torch.cuda.current_stream(self.engines[k].device))  # inputs produced on the caller's stream are ready
         for t in (enc, mask, latents):  # and stay allocated until this stream has read them, even if the caller drops them right away
             if isinstance(t, torch.Tensor) and t.is_cuda:

@@ -145,7 +145,8 @@ def test_wide_tile_on_four_waves_stores_the_eight_wave_kernels_bytes(dtype_name,
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
-@pytest.mark.parametrize("site,K,B,Ntok,gated", [("attn1_out", 1152, 32, 256, True), ("attn2_out", 1152, 8, 256, False), ("ff2", 4608, 32, 256, True), ("ff2", 4608, 2, 4096, True), ("attn1_out", 256, 4, 256, True)])
+@pytest.mark.parametrize("site,K,B,Ntok,gated", [("attn1_out", 1152, 32, 256, True), ("attn2_out", 1152, 8, 256, False), ("ff2", 4608, 32, 256, True), ("ff2", 4608, 2, 4096, True), ("attn1_out", 256, 4, 256, True),
+                                                 ("attn2_out", 128, 4, 512, "table")])
 def test_read_modify_write_epilogue_on_the_wide_tile_is_gemm3s_bit_for_bit(dtype_name, site, K, B, Ntok, gated):
     """gemm2w4.h's read-modify-write epilogue (round 5): cache <- out; hidden += gate * out (cached_transformer_block.py:243-246,317-320,355-360) on 256 x 288 tiles, the
     rounding of acc + bias into the C tile inside the generated statement.  What the engine launches for both out-projections and FF2 when the wide tiles come in
@@ -158,16 +159,17 @@ def test_read_modify_write_epilogue_on_the_wide_tile_is_gemm3s_bit_for_bit(dtype
     bias = _r((D,), torch.float32, 0.1, 73)
     h0 = _r((M, D), dt, 1.0, 74)
     table = _r((D,), torch.float32, 1.0, 75) if gated else None
-    mod = _r((B, 6 * D), dt, 1.0, 76) if gated else None
+    mod = _r((B, 6 * D), dt, 1.0, 76) if gated is True else None   # "table": the gate table alone (no modulation rows), K = 128: no trip of the loop at all
     res = {}
     for kernel in ("wide288", "tile144"):
         h = h0.clone()
         cache = torch.zeros((M, D), dtype=dt, device="cuda")
-        eng.op_gemm_ex(kernel, site, 3, a, w, bias, resid=h, gate_table=table, gate_mod=mod[:, 2 * D :] if gated else None, gate_mod_stride=6 * D if gated else 0, rows_per_batch=Ntok, out=cache)
+        eng.op_gemm_ex(kernel, site, 3, a, w, bias, resid=h, gate_table=table, gate_mod=mod[:, 2 * D :] if mod is not None else None, gate_mod_stride=6 * D if mod is not None else 0, rows_per_batch=Ntok,
+                       out=cache)
         res[kernel] = (cache, h)
     assert torch.equal(res["wide288"][0], res["tile144"][0]) and torch.equal(res["wide288"][1], res["tile144"][1])
     out_ref = (a.float() @ w.float().t() + bias).to(dt).float()
-    gate = (table[None] + mod[:, 2 * D : 3 * D].float()).repeat_interleave(Ntok, 0) if gated else 1.0
+    gate = ((table[None] + mod[:, 2 * D : 3 * D].float()).repeat_interleave(Ntok, 0) if mod is not None else table[None]) if gated else 1.0
     assert within(tile_rel_l2(res["wide288"][0], out_ref), TOL[dtype_name])
     assert within(tile_rel_l2(res["wide288"][1], h0.float() + gate * out_ref), TOL[dtype_name])
 

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
     // loop's barriers order them before the readers -- and the row coefficients rstd, -rstd * mean of the 256 rows (gemm2w.h) from the per-tile partial sums.
     {
       char* cst = smem + G2W4_CST;
-      const int t = threadIdx.x;
+      int t;  // the thread id from v_mbcnt, per tile: everything derived from threadIdx.x is loop-invariant to hipcc, gets hoisted above the tile loop and then has to live
+              // across the statement -- in scratch, with an s_waitcnt vmcnt(0) per reload
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
+      t += wave * 64;
       if (t < 72) {
         if (p.bias) glds16_raw(p.bias + n0 + 4 * t, lds + (unsigned)G2W4_CST + (unsigned)wave * 1024u);
         else if (EPI == EPI_BIAS_CACHE_RESID) reinterpret_cast<f32x4*>(cst)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the statement's own C-tile staging adds what it finds here
@@ -108,9 +111,11 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
 #endif
     // every per-lane value of the epilogue is derived from this laundered id, so none of it is computed above the K loop and carried across it in the 54 registers the
     // statement leaves (hipcc hoisted the row pointers and spilled them; each scratch reload is an `s_waitcnt vmcnt(0)` between the tile's stores)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    // (the lane id is re-derived by v_mbcnt behind the statement rather than kept: threadIdx.x carried across it was a scratch spill + reload with a full vmcnt(0))
+    int lane_fresh;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_fresh));
+    const int tid = wave * 64 + lane_fresh;
+    const int lane = lane_fresh, l15 = lane & 15, g = lane >> 4;
     const char* cst = smem + G2W4_CST;
     auto raw = [&](auto ic, auto jc) -> f32x4 {
       constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
@@ -179,12 +184,16 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
       // The statement has already rounded acc + bias into the C tile (a C++ staging short of registers had its spills land in the AGPRs, i.e. in the accumulators).
       T* ctile = reinterpret_cast<T*>(smem);
       const int rlane = lane;
+      // wave-uniform bases + 32-bit lane offsets: 36 (row, chunk) positions per lane would otherwise be 72 64-bit pointers beside the 144 registers of residual chunks
+      char* const hbase = reinterpret_cast<char*>(p.resid + (size_t)(m0 + wave * 64) * p.ldr + n0);
+      char* const cbase = p.C ? reinterpret_cast<char*>(p.C + (size_t)(m0 + wave * 64) * p.ldc + n0) : nullptr;
+      const unsigned hrow = (unsigned)p.ldr * (unsigned)sizeof(T), crow = (unsigned)p.ldc * (unsigned)sizeof(T);
       Pack8 hpre[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int id = rlane + it * 64;
         const int rl = id / CPR, cchunk = id - rl * CPR;
-        hpre[it] = gload16(p.resid + (size_t)(m0 + wave * 64 + rl) * p.ldr + n0 + cchunk * 8);
+        hpre[it] = gload16(hbase + (unsigned)rl * hrow + (unsigned)cchunk * 16u);
       }
       __syncthreads();
       const bool gated = p.gate_table != nullptr, modulated = gated && p.gate_mod != nullptr;
@@ -193,9 +202,8 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
         const int id = rlane + it * 64;
         const int rl = id / CPR, cchunk = id - rl * CPR;
         const int ml = wave * 64 + rl;
-        const int m = m0 + ml, n = n0 + cchunk * 8;
         const Pack8 v = lds_read16(ctile + ml * G2_CS + cchunk * 8);
-        if (p.C) gstore16_nt(p.C + (size_t)m * p.ldc + n, v);
+        if (cbase) gstore16_nt(cbase + (unsigned)rl * crow + (unsigned)cchunk * 16u, v);
         float o[8], h[8];
         unpack8<T>(v, o);
         unpack8<T>(hpre[it], h);
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
           for (int e = 0; e < 8; ++e) h[e] += o[e];
         }
         const Pack8 hn = pack8<T>(h);
-        gstore16(p.resid + (size_t)m * p.ldr + n, hn);
+        gstore16(hbase + (unsigned)rl * hrow + (unsigned)cchunk * 16u, hn);
         if (p.stat_out) *reinterpret_cast<u32x4*>(ctile + ml * G2_CS + cchunk * 8) = hn.u;  // the wave's own rows of the C tile now hold the updated hidden states
       }
       if (p.stat_out) {

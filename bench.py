@@ -602,9 +602,15 @@ def main():
             metric = "images/sec at fixed schedule (PixArt-Sigma 1024, 20-step, sigma ours_fast transfer) [secondary]"
             workload = (f"PixArt-Sigma 1024x1024 geometry (N=4096, T=300), 20 steps, {SIGMA1024_SCHEDULE.relative_to(ROOT)} (256 -> 1024 transfer of "
                         f"pixart_sigma_256/ours_fast.json), batch={batch} (CFG batch {2 * batch}), 1xMI355X per rank")
+        one_at_a_time = single_ctx if single_ctx is not None else value
         res = {
             "metric": metric,
             **job,
+            # `value` keeps `batches_in_flight` image batches on the GPU at once (throughput); the reference's own protocol (ecad/benchmark/compute_latency.py:59-83) runs
+            # its batches one after the other: that rate, and its time per batch, on the same engine in the same run
+            "one_batch_at_a_time_images_per_s": one_at_a_time,
+            "one_batch_at_a_time_ms_per_step": 1000.0 * world * batch / one_at_a_time,
+            "batches_in_flight": n_ctx,
             "warmup": args.warmup,
             "dtype": dtype_label,
             "data": "synthetic",

@@ -395,15 +395,28 @@ class EngineContexts:
     ``wait()`` (or reading a result on the host) synchronises; results are ordinary tensors produced on the context's stream, so a consumer on another stream
     must wait for that stream (``torch.cuda.current_stream().wait_stream(ctx_stream)``) -- ``submit`` returns ``(tensor, stream)`` for that purpose."""
 
-    def __init__(self, engine: EcadEngine, n: int):
+    def __init__(self, engine: EcadEngine, n: int, adaptive: bool = False, idle_turns: int = 3):
+        """``adaptive`` (opt-in): a context whose batch finds every other stream idle on ``idle_turns`` consecutive submissions is told it runs alone
+        (``set_batches_in_flight(1)``: full-chip launches instead of half-chip ones that wait for a neighbour) and is told ``n`` again as soon as a peer is
+        busy.  Off by default: the caller built the pool to keep ``n`` batches in flight, every (schedule, context) then has ONE plan set, graph and LayerNorm-fold
+        arena, and the kernel selection does not depend on timing.  With it on, a context may hold two plan sets per schedule (both count against ``ECAD_PLAN_CACHE``);
+        the results are the same bits either way."""
         if n < 1:
             raise ValueError("need at least one context")
+        if idle_turns < 1:
+            raise ValueError("idle_turns must be at least 1")
         self.engines = [engine] + [engine.new_context() for _ in range(n - 1)]
         self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(n)]
         self._turn = 0
+        self.adaptive, self.idle_turns = bool(adaptive), int(idle_turns)
         for e in self.engines:  # the few-rows rule counts all the batches in flight (DESIGN 5f): latency tiles only while the chip would otherwise idle
             e.set_batches_in_flight(n)
-        self._declared = [n] * n  # what each context was last told (submit() lowers it to 1 for a batch that finds the other streams idle)
+        self._declared = [n] * n  # what each context was last told
+        self._idle_seen = [0] * n  # consecutive submissions of a context that found every peer idle (adaptive mode)
+
+    def declared_in_flight(self) -> list[int]:
+        """What each context currently plans for (``n``, or 1 after ``idle_turns`` lonely submissions in adaptive mode)."""
+        return list(self._declared)
 
     def __len__(self) -> int:
         return len(self.engines)
@@ -417,13 +430,16 @@ class EngineContexts:
         k = self._turn % len(self.engines)
         self._turn += 1
         st = self.streams[k]
-        # what this batch will run beside: with another context's batch still on the device the engine may launch half-chip kernels that share the chip with it;
-        # a batch that has the GPU to itself gets the full-chip ones.  Two plan sets (and graphs) per context, both kept; the results are the same bits.
-        busy = sum(1 for j, other in enumerate(self.streams) if j != k and not other.query())
-        want = len(self.engines) if busy else 1
-        if self._declared[k] != want:
-            self.engines[k].set_batches_in_flight(want)
-            self._declared[k] = want
+        if self.adaptive and len(self.engines) > 1:
+            # what this batch will run beside: with another context's batch still on the device the engine may launch half-chip kernels that share the chip with it
+            # (DESIGN 5a); a context that keeps finding the GPU to itself gets the full-chip ones -- after `idle_turns` such submissions in a row, never on the first
+            # turn of a pool (whose peers are idle only because they have not been fed yet), and back to n on the first busy peer
+            busy = any(not other.query() for j, other in enumerate(self.streams) if j != k)
+            self._idle_seen[k] = 0 if busy else self._idle_seen[k] + 1
+            want = 1 if self._idle_seen[k] >= self.idle_turns else len(self.engines)
+            if self._declared[k] != want:
+                self.engines[k].set_batches_in_flight(want)
+                self._declared[k] = want
         st.wait_stream(torch.cuda.current_stream(self.engines[k].device))  # inputs produced on the caller's stream are ready
         for t in (enc, mask, latents):  # and stay allocated until this stream has read them, even if the caller drops them right away
             if isinstance(t, torch.Tensor) and t.is_cuda:

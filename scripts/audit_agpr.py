@@ -5,7 +5,12 @@ accumulator read (`g4_acc`: v_accvgpr_read inside its own small asm statements) 
 fix was to round the accumulators into the C tile inside the statement).  This script compiles the two translation units to assembly and reports, per kernel, compiler-issued
 AGPR accesses (outside ;;#ASMSTART .. ;;#ASMEND) and whether any of them comes before the kernel's last accumulator read.  Exit status 1 on a hazard.
 
-    python scripts/audit_agpr.py            # ~3 minutes of hipcc
+    python scripts/audit_agpr.py                        # compiles both units with the product flags (~4 minutes of hipcc)
+    python scripts/audit_agpr.py --asm build/engine-hip-amdgcn-amd-amdhsa-gfx950.s ...   # audits the assembly the product build kept (-save-temps): what the Makefile runs
+
+The product build runs the second form on the very assembly its objects were made from (ecad_amd/csrc/Makefile), so `make` -- and with it `__graft_entry__.build()` -- fails on
+a hazard.  Order is judged by text line inside a kernel body: right for the straight-line epilogues these kernels have (the tile walk of gemm2w4 is one loop whose body is
+audited as a whole); a kernel that branches around its accumulator reads would need a control-flow walk.
 """
 import re
 import subprocess
@@ -14,8 +19,8 @@ import tempfile
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fno-gpu-rdc -ffast-math -fno-finite-math-only -DECAD_PRODUCT_BUILD -S --cuda-device-only".split()
-KERNELS = ("fgemm4", "fgemm48", "attn_w4a", "gemm2w4")
+FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffast-math -fno-finite-math-only -DECAD_PRODUCT_BUILD -S --cuda-device-only".split()  # BASEFLAGS of the Makefile
+KERNELS = ("fgemm4", "fgemm48", "attn_w4a", "gemm2w4", "gemm3s4")
 
 
 def audit(asm: str, unit: str) -> int:
@@ -52,6 +57,20 @@ def audit(asm: str, unit: str) -> int:
 
 def main() -> int:
     bad = 0
+    if "--asm" in sys.argv:
+        files = [Path(a) for a in sys.argv[sys.argv.index("--asm") + 1:]]
+        if not files:
+            print("--asm needs at least one assembly file", file=sys.stderr)
+            return 2
+        total = 0
+        for f in files:
+            text = f.read_text()
+            if "ASMSTART" not in text:
+                print(f"{f}: no asm-statement markers: not the device assembly of a unit with generated K loops", file=sys.stderr)
+                return 2
+            bad += audit(text, f.name)
+            total += 1
+        return 1 if bad else 0
     with tempfile.TemporaryDirectory() as td:
         for unit in ("flux.hip", "engine.hip"):
             out = Path(td) / (unit + ".s")

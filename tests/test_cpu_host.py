@@ -248,3 +248,89 @@ def test_generated_instruction_streams_are_what_their_generators_write():
     for gen in ("gen_gemm4.py", "gen_attn_w4.py"):
         r = subprocess.run([sys.executable, str(root / "scripts" / gen), "--check"], capture_output=True, text=True)
         assert r.returncode == 0, f"{gen}: {r.stderr[-400:]}"
+
+
+def test_generate_images_skip_rule_is_the_references(tmp_path):
+    """reference generate_images.py:27-43: a schedule's output directory is skipped only when it already holds at least one ``*.png`` directly inside it; an empty
+    directory (what a crashed run leaves) is generated again; with ``--regen-if-not-n-images`` a wrong count removes the PNG files (only those, only at the top
+    level) and regenerates; a schedule directory that holds only directories contributes its own name to the output path (:94-111)."""
+    from PIL import Image
+
+    from ecad_amd.benchmark import generate_images as gi
+
+    made = []
+
+    class FakeGenerator:
+        def __init__(self, start_seed, seed_step, schedule_path, max_batch):
+            self.schedule_path = schedule_path
+
+        def generate_from_saved_prompts(self, input_dir, out, batch_size, images_per_prompt, free_after, include_seed_in_name):
+            made.append(Path(out))
+            for k in range(2):
+                Image.new("RGB", (2, 2)).save(Path(out) / f"img_{k}.png")
+
+    sched = tmp_path / "schedules"
+    (sched / "fam_a").mkdir(parents=True)
+    (sched / "fam_b").mkdir()
+    for f in ("fam_a/s1.json", "fam_a/s2.json", "fam_b/s3.json"):
+        (sched / f).write_text("{}")
+    out = tmp_path / "out"
+    args = (FakeGenerator, sched, tmp_path, out, 4, 1, 0, 1)
+    assert gi.generate_all_schedules(*args) == 3
+    assert sorted(p.relative_to(out).as_posix() for p in made) == ["schedules/s1", "schedules/s2", "schedules/s3"]  # a directory of directories adds ITS name; the leaf directories' files go to <stem>
+    made.clear()
+    assert gi.generate_all_schedules(*args) == 0 and not made  # every directory holds images: skipped
+    # a crashed run: the directory exists, no image in it -> generated again (the round-5 build skipped it)
+    s1 = out / "schedules" / "s1"
+    for p in s1.glob("*.png"):
+        p.unlink()
+    (s1 / "nested").mkdir()
+    Image.new("RGB", (2, 2)).save(s1 / "nested" / "deep.png")  # not counted: the reference's glob is not recursive
+    assert gi.generate_all_schedules(*args) == 1 and made == [s1]
+    assert (s1 / "nested" / "deep.png").exists()
+    made.clear()
+    # wrong count with --regen-if-not-n-images: PNG files removed (the directory and everything else in it stay), regenerated
+    (s1 / "notes.txt").write_text("kept")
+    Image.new("RGB", (2, 2)).save(s1 / "extra.png")
+    assert gi.generate_all_schedules(*args, 2) == 1 and made == [s1]
+    assert (s1 / "notes.txt").exists() and not (s1 / "extra.png").exists() and len(list(s1.glob("*.png"))) == 2
+    made.clear()
+    assert gi.generate_all_schedules(*args, 2) == 0  # right count now
+    # a single schedule file goes to output_dir / stem; a failing constructor surfaces as the reference's ValueError
+    assert gi.generate_all_schedules(FakeGenerator, sched / "fam_b" / "s3.json", tmp_path, tmp_path / "single", 4, 1, 0, 1) == 1
+    assert made[-1] == tmp_path / "single" / "s3"
+
+    class Broken:
+        def __init__(self, **kw):
+            raise RuntimeError("no")
+
+    with pytest.raises(ValueError, match="Error creating image generator"):
+        gi.generate_for_schedule(Broken, sched / "fam_b" / "s3.json", tmp_path, tmp_path / "other", 4, 1, 0, 1)
+
+
+def test_product_build_is_gated_on_the_accumulator_audit():
+    """Round-5 ADVICE: the kernels whose K loops are asm statements hand their accumulators over in AGPRs that hipcc treats as free registers behind the statement; a
+    spill into them is silent.  The Makefile keeps the device assembly each object was made from and fails on a hazard (scripts/audit_agpr.py --asm); here: the rule is
+    in the Makefile, the audit flags a planted hazard, and -- when a build has left its assembly in csrc/build -- that assembly is clean."""
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    mk = (root / "ecad_amd" / "csrc" / "Makefile").read_text()
+    assert "-save-temps" in mk and "audit_agpr.py --asm" in mk and "exit 1" in mk
+    sys.path.insert(0, str(root / "scripts"))
+    try:
+        import audit_agpr
+    finally:
+        sys.path.pop(0)
+    flags = (root / "ecad_amd" / "csrc" / "Makefile").read_text().split("BASEFLAGS := ")[1].split("\n")[0].split()
+    assert "-fPIC" in audit_agpr.FLAGS and all(f in audit_agpr.FLAGS for f in flags if not f.startswith("-W") and f != "--offload-arch=$(ARCH)")
+    body = ["\t;;#ASMSTART", "\tv_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[4:7], a[0:3]", "\t;;#ASMEND", "{planted}", "\t;;#ASMSTART", "\tv_accvgpr_read_b32 v9, a0", "\t;;#ASMEND"]
+    kern = "_ZN4ecad14gemm2w4_kernelIDF16_Li1ELi4EEEvNS_8GemmArgsIT_EE:\n{}\n.Lfunc_end0:\n"
+    clean = kern.format("\n".join(body).format(planted="\tv_add_f32_e32 v1, v2, v3"))
+    spilled = kern.format("\n".join(body).format(planted="\tv_accvgpr_write_b32 a0, v5"))
+    assert audit_agpr.audit(clean, "planted-clean") == 0 and audit_agpr.audit(spilled, "planted-hazard") == 1
+    kept = sorted((root / "ecad_amd" / "csrc" / "build").glob("*-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    if kept:
+        r = subprocess.run([sys.executable, str(root / "scripts" / "audit_agpr.py"), "--asm", *map(str, kept)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-600:]

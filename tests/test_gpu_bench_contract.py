@@ -42,6 +42,9 @@ def test_bench_line_contract():
     # the headline keeps three image batches in flight (execution contexts over one set of weights) and says so, with the one-at-a-time rate beside it
     # (over six timed steps the fill and drain of the three-deep pipeline still show: no ordering between the two rates is asserted here)
     assert d["config"]["batches_in_flight"] == 3 and d["config"]["one_batch_at_a_time_images_per_s"] > 0
+    # the sequential rate (the reference's protocol: one batch after the other) sits at the top level beside the pipelined `value`, with its own time per batch
+    assert d["batches_in_flight"] == 3 and d["one_batch_at_a_time_images_per_s"] == d["config"]["one_batch_at_a_time_images_per_s"]
+    assert abs(d["one_batch_at_a_time_ms_per_step"] * d["one_batch_at_a_time_images_per_s"] - 1000.0 * 16) < 1e-6 * 16000
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["achieved"] > 100.0  # the dominant GEMM really ran on the matrix cores

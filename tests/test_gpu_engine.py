@@ -693,6 +693,47 @@ def test_batches_in_flight_pick_the_tile_shape_not_the_result(monkeypatch):
     eng.close()
 
 
+def test_adaptive_pool_needs_several_lonely_turns_before_it_plans_for_one_batch():
+    """EngineContexts(adaptive=True) (round-5 ADVICE): the downgrade to "this batch runs alone" is opt-in, takes `idle_turns` consecutive submissions that found
+    every peer idle (never the first turn of a pool), and is undone by the first busy peer; by default a pool keeps what it was built for -- one plan set and one
+    graph per (schedule, context), kernel selection independent of timing.  Same bits in every mode."""
+    from ecad_amd.engine import EngineContexts
+
+    layers, steps, B = 2, 4, 2
+    bits = rand_bits(steps, layers, 0.5, seed=5)
+    eng, w, cfg = make_pair(layers, bits, max_batch=2 * B)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    inp, enc, mask = cfg_inputs(B)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    alone = eng.run_schedule(*args).clone()
+    pool = EngineContexts(eng, 2)                      # default: never lowered, however lonely the submissions are
+    for _ in range(5):
+        out = pool.submit(*args)[0]
+        pool.wait()
+        assert torch.equal(out, alone)
+    assert pool.declared_in_flight() == [2, 2]
+    pool.close()
+    pool = EngineContexts(eng, 2, adaptive=True, idle_turns=2)
+    seen = []
+    for _ in range(6):                                 # one batch at a time: contexts 0, 1, 0, 1, ... each find the other idle
+        out = pool.submit(*args)[0]
+        pool.wait()
+        assert torch.equal(out, alone)
+        seen.append(tuple(pool.declared_in_flight()))
+    assert seen[0] == (2, 2) and seen[1] == (2, 2)     # first lonely turn of each context: nothing changes
+    assert seen[2] == (1, 2) and seen[3] == (1, 1)     # second lonely turn in a row: that context plans for one batch
+    a = pool.submit(*args)[0]
+    b = pool.submit(*args)[0]                          # finds context 0 busy: back to two at once
+    pool.wait()
+    assert torch.equal(a, alone) and torch.equal(b, alone)
+    assert pool.declared_in_flight()[1] == 2
+    with pytest.raises(ValueError, match="idle_turns"):
+        EngineContexts(eng, 2, adaptive=True, idle_turns=0)
+    pool.close()
+    eng.close()
+
+
 def test_execution_contexts_share_weights_and_keep_results_bit_identical():
     """ecad_share_weights / EngineContexts: further execution contexts read the first engine's weight arena (no copy), keep their own cache arena,
     plans and hipGraph, and run on their own streams, so several image batches are in flight at once.  Six different batches submitted to three contexts

@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libecad_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ECAD_DTYPE_F16, ECAD_DTYPE_BF16, ECAD_DTYPE_F32 = 0, 1, 2
 ECAD_E_INVALID, ECAD_E_HIP, ECAD_E_NOT_READY, ECAD_E_UNSUPPORTED = -1, -2, -3, -4
@@ -64,6 +64,11 @@ class EcadStats(C.Structure):
         ("fold_arena_bytes", C.c_int64),
         ("fold_refused", C.c_int32),
         ("replays_folded", C.c_int32),
+        ("rmw_launches_wide", C.c_int64),
+        ("rmw_launches_narrow4", C.c_int64),
+        ("rmw_launches_gemm3s", C.c_int64),
+        ("split_k", C.c_int32),
+        ("batches_in_flight", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -124,6 +129,8 @@ SIGNATURES = {
     "ecad_share_weights": (_I, [_P, _P]),
     "ecad_set_ln_fold": (_I, [_P, _I]),
     "ecad_set_batches_in_flight": (_I, [_P, _I]),
+    "ecad_set_split_k": (_I, [_P, _I]),
+    "ecad_set_native_variants": (_I, [_P, C.POINTER(C.c_uint8), _I, _I]),
     "ecad_set_fp8": (_I, [_P, _I]),
     "ecad_set_added_cond": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I]),
     "ecad_set_attention_bias": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -142,6 +142,22 @@ __global__ __launch_bounds__(256) void cache_accumulate_rows_kernel(const FlushA
   }
 }
 
+// ---- ECAD_NATIVE_CFG_MEAN_CACHE: the cache slot of a CFG-doubled batch becomes the mean of its unconditional and its text half, in both halves (what
+// compute_attn_tgate caches at its gate step, cached_transformer_block.py:443-452: `(hidden_uncond + hidden_pred_text) / 2`): fp32 mean, one rounding.
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_mean_halves_kernel(T* slot, size_t half_elems) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= half_elems) return;
+  float a[8], b[8];
+  unpack8<T>(gload16(slot + i), a);
+  unpack8<T>(gload16(slot + half_elems + i), b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.5f * (a[e] + b[e]);
+  const Pack8 m = pack8<T>(a);
+  gstore16(slot + i, m);
+  gstore16(slot + half_elems + i, m);
+}
+
 // ---- LayerNorm (eps, no affine) + modulate, one wave per row, pending cache replays folded in.
 // norm1/norm2 + `x * (1 + scale) + shift` (cached_transformer_block.py:207-215,306-310) and norm_out + modulate
 // (pixart_transformer_2d_edited.py:340-348).  MAXC = 16-byte chunks per lane (D <= 512 * MAXC).

@@ -36,6 +36,7 @@
 #include "final_layer.h"
 #include "gemm2w.h"
 #include "gemm2w4.h"
+#include "gemm3s4.h"
 #include "gemm3s.h"
 #include "gemm3s8.h"
 
@@ -79,6 +80,8 @@ struct EngineBase {
   virtual int set_fp8(int on) = 0;
   virtual int set_ln_fold(int on) = 0;
   virtual int set_batches_in_flight(int n) = 0;
+  virtual int set_split_k(int on) = 0;
+  virtual int set_native(const uint8_t* kinds, int steps, int blocks) = 0;
   virtual int set_added_cond(const float* resolution, const float* aspect_ratio, int Bt) = 0;
   virtual int set_attention_bias(const float* self_bias, const float* enc_bias, int Bt, int N, int T, hipStream_t st) = 0;
   virtual int set_schedule(const uint8_t* bits, int steps, int blocks) = 0;
@@ -112,7 +115,7 @@ struct EngineBase {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Op {
-  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE, COMB, CUSTOM, FINAL } kind;
+  enum Kind { GEMM, GEMM8, QUANT, ATTN, LN, REPLAY, PATCH, SINUS, SILU, MASKBIAS, UNPATCH, SOLVER, DUP, SIZEEMB, ADDSIZE, COMB, CUSTOM, FINAL, CFGMEAN } kind;
   int cls = KC_MISC;
   int epi = 0;
   GemmArgs<T> g{};
@@ -351,6 +354,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_SPLIT_K")) split_k = atoi(l) != 0;
     if (const char* l = getenv("ECAD_GEMM4")) gemm4_wide = atoi(l) != 0;
     if (const char* l = getenv("ECAD_WIDE_RMW")) wide_rmw = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_GEMM3S4")) narrow4 = atoi(l) < 0 ? 0 : atoi(l);
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
     // ---- weight arena
@@ -602,6 +606,33 @@ template <typename T> class EngineT : public EngineBase {
     if (n != in_flight) { stash_current(); in_flight = n; }
     return ECAD_OK;
   }
+  // ECAD_SPLIT_K as a call (round-5 ADVICE): the choice is made where the launch is issued, i.e. it is baked into a captured graph -- plan sets are keyed by it
+  int set_split_k(int on) override {
+    if ((on != 0) != split_k) { stash_current(); split_k = on != 0; }
+    return ECAD_OK;
+  }
+  // Native variants of the compute plug-ins (row a6; cached_transformer_block.py:125-165): per (step, block, component) one of ECAD_NATIVE_* -- gate rules the engine
+  // lowers into its own kernels, so a schedule that names them stays in the whole-loop plan and its hipGraph (a host callback cannot).  NULL: all default.
+  int set_native(const uint8_t* kinds, int nsteps, int nblocks) override {
+    if (!kinds) {
+      if (!native_kind.empty()) { stash_current(); native_kind.clear(); resolve_executed(); plan_valid = false; batch_begun = false; }
+      return ECAD_OK;
+    }
+    if (nblocks != L || nsteps != steps || bits.empty()) return fail(ECAD_E_INVALID, "native variants are given per (step, block, component) of the schedule that is set: %d x %d, got %d x %d", steps, L, nsteps, nblocks);
+    bool any = false;
+    for (size_t i = 0; i < (size_t)nsteps * L * 3; ++i) {
+      if (kinds[i] > ECAD_NATIVE_CFG_MEAN_CACHE) return fail(ECAD_E_INVALID, "native variant %d unknown", (int)kinds[i]);
+      if (kinds[i] == ECAD_NATIVE_CFG_MEAN_CACHE && i % 3 != 1) return fail(ECAD_E_UNSUPPORTED, "the CFG-mean cache rule exists for attn2 (the component TGATE applies it to, cached_transformer_block.py:443-452)");
+      any = any || kinds[i];
+    }
+    stash_current();
+    native_kind.clear();
+    if (any) native_kind.assign(kinds, kinds + (size_t)nsteps * L * 3);
+    resolve_executed();
+    plan_valid = false;
+    batch_begun = false;
+    return ECAD_OK;
+  }
   int set_fp8(int on) override {
     if (on && weights_shared) return fail(ECAD_E_UNSUPPORTED, "fp8 weight copies are per engine: not on a context that borrows its weights");
     if ((on != 0) != fp8) { fp8 = on != 0; finalized = false; drop_all_plans(); }
@@ -779,7 +810,8 @@ template <typename T> class EngineT : public EngineBase {
   std::string make_key() const {
     std::string k((const char*)bits.data(), bits.size());
     k.append((const char*)custom_mask.data(), custom_mask.size());
-    const int geo[10] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, fuse_attn ? 1 : 0, ln_fold ? 1 : 0, in_flight,
+    k.append((const char*)native_kind.data(), native_kind.size());
+    const int geo[10] = {steps, Bt, Hl, Wl, Tt, fp8 ? 1 : 0, fuse_attn ? 1 : 0, (ln_fold ? 1 : 0) | (split_k ? 2 : 0), in_flight,
                          (self_bias_on ? 1 : 0) | (enc_bias_on ? 2 : 0)};
     k.append((const char*)geo, sizeof geo);
     return k;
@@ -839,19 +871,27 @@ template <typename T> class EngineT : public EngineBase {
     stash_current();  // the plans and graph of the outgoing schedule stay reachable by content
     steps = nsteps;
     bits.assign(b, b + (size_t)nsteps * L * 3);
+    native_kind.clear();  // variants belong to the schedule they were given for (ecad_set_native_variants comes after ecad_set_schedule)
+    resolve_executed();
+    plan_valid = false;
+    batch_begun = false;
+    return ECAD_OK;
+  }
+  std::vector<uint8_t> native_kind;  // [steps][L][3] ECAD_NATIVE_* or empty (all default)
+  int native_at(int s, int i) const { return native_kind.empty() ? 0 : native_kind[(size_t)s * L * 3 + i]; }
+  // the gate's flag of (step s, component i of L * 3): the schedule bit, or "always" for a component that names the recompute variant
+  bool flag_at(int s, int i) const { return bits[(size_t)s * L * 3 + i] != 0 || native_at(s, i) == ECAD_NATIVE_RECOMPUTE; }
+  void resolve_executed() {
     executed.assign(bits.size(), 0);
     std::vector<uint8_t> have((size_t)L * 3, 0);
     st.components_executed = st.components_cached = 0;
     for (int s = 0; s < steps; ++s)
       for (int i = 0; i < L * 3; ++i) {
         const size_t k = (size_t)s * L * 3 + i;
-        executed[k] = (bits[k] != 0) || !have[i];  // recompute or cache empty (cached_transformer_block.py:340-347)
+        executed[k] = flag_at(s, i) || !have[i];  // recompute or cache empty (cached_transformer_block.py:340-347)
         have[i] |= executed[k];
         if (executed[k]) st.components_executed++; else st.components_cached++;
       }
-    plan_valid = false;
-    batch_begun = false;
-    return ECAD_OK;
   }
 
   // -------------------------------------------------------------------------------------------
@@ -1078,6 +1118,12 @@ template <typename T> class EngineT : public EngineBase {
         }
         push_rmw(mk_gemm_resid(KC_GEMM_OUT2, attn_o, B.w_o2, B.b_o2, live(b, 1) ? c1 : nullptr, M, D, nullptr, nullptr, 0));
         if (live(b, 1)) st.cache_bytes_written += (int64_t)slot * sizeof(T);
+        if (native_at(s, b * 3 + 1) == ECAD_NATIVE_CFG_MEAN_CACHE && live(b, 1)) {
+          // what is CACHED is the mean of the unconditional and the text half of the batch, in both halves (TGATE's caching rule, cached_transformer_block.py:443-452);
+          // the hidden states took the un-averaged output above.  Its own launch on the slot the GEMM just wrote.
+          Op<T> o; o.kind = Op<T>::CFGMEAN; o.cls = KC_CACHE_REPLAY; o.p2 = c1; o.n = slot / 2; o.bytes = 2.0 * (double)slot * sizeof(T);
+          ops.push_back(o);
+        }
         st.linear_macs_reference += 2ll * M * D * D + 2ll * Mt * D * D; st.linear_macs_executed += 2ll * M * D * D; st.attn_core_macs += 2ll * Bt * N * (int64_t)Tt * D;
       } else {
         pend_push(Pending{c1, nullptr, nullptr});
@@ -1290,6 +1336,14 @@ template <typename T> class EngineT : public EngineBase {
   bool g2w4_attr[4][KC_COUNT] = {};
   bool force_wide_rmw = false;  // ecad_op_gemm_ex(kernel 2) at a read-modify-write site
   bool wide_rmw = true;  // the read-modify-write launches on that tile where it pays (launch_pg; env ECAD_WIDE_RMW=0: always gemm3s.h; bit-identical)
+  // The same launches on gemm3s.h's own 256 x 144 tile, but on four waves with the hand-placed K loop (gemm3s4.h; round 6; bit-identical to gemm3s): where the wide
+  // tile does not apply.  Measured (scripts/probe_gemm3s4.hip, one stream / two streams, us per launch): FF2 77.4 / 72.6 against gemm3s 81.1 / 80.2; the N = K = 1152
+  // out-projections 30.2 / 26.2 against 29.3 / 27.2 (the K loop is 9 % shorter per step, the one-wave-per-SIMD row pass longer); with replayed components the
+  // replay loads have no K loop to hide under: gemm3s.  env ECAD_GEMM3S4: 0 off, 1 (default) FF2, 2 also the out-projections, 3 also launches with replays.
+  int narrow4 = 1;
+  bool force_narrow4 = false;  // ecad_op_gemm_ex(kernel 7)
+  bool g3s4_attr[KC_COUNT] = {};
+  int64_t rmw_launches_wide = 0, rmw_launches_narrow4 = 0, rmw_launches_g3s = 0;  // read-modify-write launches by the kernel that took them (EcadStats)
   // Few rows (batch 1-4): a launch whose 256-row tiles cover less than half the chip is a latency chain (18-72 K-steps of ~0.8 us whatever the tile count);
   // the 64 x 144 latency variant of gemm3s.h (four waves of 16 x 144, two workgroups per CU) has a quarter of the MFMA work per K-step and workgroup.
   // env ECAD_LATENCY_TILES=0: off.  Attention-fused query projections take it too (64 query rows x two heads per workgroup, gemm3s_attn.h).
@@ -1386,9 +1440,25 @@ template <typename T> class EngineT : public EngineBase {
             g2w4_attr[EPI][TAG] = true;
           }
           hipLaunchKernelGGL((gemm2w4_kernel<T, EPI, TAG>), dim3(tiles2 > num_cus ? num_cus : tiles2), dim3(256), G2W4_LDS_BYTES, s, g);
+          ++rmw_launches_wide;
           return ECAD_OK;
         }
       }
+    }
+    if constexpr (EPI == EPI_BIAS_CACHE_RESID && (TAG == KC_GEMM_OUT1 || TAG == KC_GEMM_OUT2 || TAG == KC_GEMM_FF2)) {
+      // ... or on the 256 x 144 tile on four waves (gemm3s4.h): full-chip, bit-identical to gemm3s below
+      const bool want = force_narrow4 || (gemm4_wide && gemm_impl_cls[TAG] == 0 && (TAG == KC_GEMM_FF2 ? narrow4 >= 1 : narrow4 >= 2) && (g.n_xsrc == 0 || narrow4 >= 3));
+      if (want && g3s4_ok(g)) {
+        if (!g3s4_attr[TAG]) {
+          HIPCHK(hipFuncSetAttribute((const void*)gemm3s4_kernel<T, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, G3S4_LDS_BYTES));
+          g3s4_attr[TAG] = true;
+        }
+        hipLaunchKernelGGL((gemm3s4_kernel<T, TAG>), dim3((rows_of(g) / G3_BM) * (g.N / G3_BN)), dim3(256), G3S4_LDS_BYTES, s, g);
+        ++rmw_launches_narrow4;
+        return ECAD_OK;
+      }
+      if (force_narrow4) return fail(ECAD_E_UNSUPPORTED, "gemm3s4 needs whole 256-row tiles inside one sample each, K %% 192 == 0 and at most %d replayed components", G3_XSRC_MAX);
+      ++rmw_launches_g3s;
     }
     if (gemm_impl_cls[TAG] == 0 || (gemm_impl_cls[TAG] == 2 && g.N % G3_BN == 0)) {  // (2: a wide call site whose wide tiles would underfill the chip)
       if (!g3_attr[EPI][TAG]) {
@@ -1626,6 +1696,9 @@ template <typename T> class EngineT : public EngineBase {
         if (rc) return fail(ECAD_E_INVALID, "compute plug-in of block %d component %d failed (callback returned %d)", o.i0, o.i1, rc);
         break;
       }
+      case Op<T>::CFGMEAN:
+        hipLaunchKernelGGL((cfg_mean_halves_kernel<T>), dim3((unsigned)((o.n / 8 + 255) / 256)), dim3(256), 0, s, (T*)o.p2, o.n);
+        break;
       case Op<T>::DUP: {
         const int total = (Bt / 2) * CIN * Hl * Wl;
         hipLaunchKernelGGL((cfg_duplicate_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, lat_buf, model_in, total);
@@ -1707,7 +1780,7 @@ template <typename T> class EngineT : public EngineBase {
     bool as_planned = true;
     for (int i = 0; i < L * 3; ++i) {
       const size_t k = (size_t)step_idx * L * 3 + i;
-      ex[i] = bits[k] || !valid_rt[i];
+      ex[i] = flag_at(step_idx, i) || !valid_rt[i];
       if (!(any_custom && custom_mask[i]) && ex[i] != executed[k]) as_planned = false;
     }
     if (as_planned) {
@@ -1877,6 +1950,8 @@ template <typename T> class EngineT : public EngineBase {
     s->plan_builds = plan_builds; s->graph_captures = graph_captures; s->dynamic_step_plans = dynamic_steps; s->plan_sets_cached = (int32_t)plan_lru.size();
     s->ln_folded = ln_folded; s->fold_preps = fold_preps; s->fold_bytes = (int64_t)fold_used;
     s->fold_arena_bytes = (int64_t)fold_held(); s->fold_refused = fold_refused;
+    s->rmw_launches_wide = rmw_launches_wide; s->rmw_launches_narrow4 = rmw_launches_narrow4; s->rmw_launches_gemm3s = rmw_launches_g3s;
+    s->split_k = split_k ? 1 : 0; s->batches_in_flight = in_flight;
     return ECAD_OK;
   }
   int set_profiling(int on) override {
@@ -1959,6 +2034,12 @@ template <typename T> class EngineT : public EngineBase {
     if (kernel == 5 && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_SILU && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "the latency tiles have no attention tail through this entry");
     if (kernel == 1) return fail(ECAD_E_UNSUPPORTED, "the persistent producer / consumer kernel (pgemm.h) was retired in round 3: no call site used it");
     if (kernel == 6 && epi != EPI_BIAS_CACHE_RESID) return fail(ECAD_E_UNSUPPORTED, "split-K exists for the read-modify-write epilogue only");
+    const bool narrow4_forced = kernel == 7;
+    if (narrow4_forced) {
+      if (epi != EPI_BIAS_CACHE_RESID || (site != KC_GEMM_OUT1 && site != KC_GEMM_OUT2 && site != KC_GEMM_FF2))
+        return fail(ECAD_E_UNSUPPORTED, "gemm3s4 exists for the read-modify-write epilogue at both out-projections and FF2");
+      kernel = 0;
+    }
     if ((kernel < 0 || kernel > 2) && kernel != 5 && kernel != 6) return fail(ECAD_E_INVALID, "kernel %d unknown", kernel);
     if (Nn % G3_BN) return fail(ECAD_E_UNSUPPORTED, "256x144 / 256x288 tiles need N %% 144 == 0, got %d", Nn);
     // kernel 2 at a read-modify-write site = that epilogue on the wide tile (gemm2w4.h), whatever the tile count and the batches in flight say
@@ -1973,15 +2054,23 @@ template <typename T> class EngineT : public EngineBase {
     const int keep = gemm_impl_cls[site];
     const bool keep_lat = latency_tiles, keep_wide = wide_rmw;
     const int keep_force = force_wide_rmw;
+    const int keep_n4 = narrow4;
     gemm_impl_cls[site] = rmw_wide ? 0 : kernel;
     latency_tiles = false;  // the caller named the kernel: no few-rows substitution (kernel 5 IS the latency tile)
     wide_rmw = rmw_wide;    // ... and no wide-tile substitution either
     force_wide_rmw = rmw_wide;
+    force_narrow4 = narrow4_forced;
+    if (!narrow4_forced) narrow4 = 0;  // ... nor the four-wave 256 x 144 kernel unless it was the one named
+    const bool keep_tail = tail_split;
+    if (narrow4_forced) tail_split = false;
     const int rc = launch_gemm(epi, site, g, s);
     gemm_impl_cls[site] = keep;
     latency_tiles = keep_lat;
     wide_rmw = keep_wide;
     force_wide_rmw = keep_force;
+    force_narrow4 = false;
+    narrow4 = keep_n4;
+    tail_split = keep_tail;
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return ECAD_OK;
@@ -2087,6 +2176,8 @@ int ecad_load_weights(EcadEngine* e, const char* name, const void* ptr, int dtyp
 int ecad_finalize_weights(EcadEngine* e) { ENG(e); return E->finalize_weights(); }
 int ecad_set_ln_fold(EcadEngine* e, int on) { ENG(e); return E->set_ln_fold(on); }
 int ecad_set_batches_in_flight(EcadEngine* e, int n) { ENG(e); return E->set_batches_in_flight(n); }
+int ecad_set_split_k(EcadEngine* e, int on) { ENG(e); return E->set_split_k(on); }
+int ecad_set_native_variants(EcadEngine* e, const uint8_t* kinds, int steps, int blocks) { ENG(e); return E->set_native(kinds, steps, blocks); }
 int ecad_share_weights(EcadEngine* e, EcadEngine* donor) {
   ENG(e);
   if (!donor) return E->fail(ECAD_E_INVALID, "NULL donor");

@@ -106,6 +106,23 @@ class EcadEngine:
         counts the other batches' tiles too.  ``EngineContexts`` sets it for its engines."""
         self._chk(self.lib.ecad_set_batches_in_flight(self._h, int(n)))
 
+    def set_split_k(self, on: bool) -> None:
+        """Split-K for the few-rows FF2 (default on; ``ECAD_SPLIT_K``): off restores bit-identity of a sample across batch sizes (``ecad_set_split_k``)."""
+        self._chk(self.lib.ecad_set_split_k(self._h, int(bool(on))))
+
+    NATIVE_DEFAULT, NATIVE_RECOMPUTE, NATIVE_CFG_MEAN_CACHE = 0, 1, 2
+
+    def set_native_variants(self, kinds: np.ndarray | None) -> None:
+        """kinds [steps, blocks, 3] (attn1, attn2, ff) of ``NATIVE_*`` ids: gate rules the engine lowers into its own kernels, so a schedule that names them stays in
+        the whole-loop hipGraph (``ecad_set_native_variants``).  Call after ``set_schedule``; None / all zero: every component uses the default rule."""
+        if kinds is None or not np.asarray(kinds).any():
+            self._chk(self.lib.ecad_set_native_variants(self._h, None, 0, 0))
+            return
+        kinds = np.ascontiguousarray(np.asarray(kinds).astype(np.uint8))
+        if kinds.ndim != 3 or kinds.shape[2] != 3:
+            raise ValueError(f"native variants must have shape (steps, blocks, 3), got {kinds.shape}")
+        self._chk(self.lib.ecad_set_native_variants(self._h, kinds.ctypes.data_as(C.POINTER(C.c_uint8)), kinds.shape[0], kinds.shape[1]))
+
     def new_context(self) -> "EcadEngine":
         """A further execution context on the same GPU: same configuration, the SAME weights (``ecad_share_weights``: no copy, this engine must outlive
         it), the same schedule; its own workspaces, cache arena, plans and hipGraph.  Batches submitted to different contexts on different streams overlap
@@ -329,7 +346,7 @@ class EcadEngine:
         )
         return out
 
-    GEMM_KERNELS = {"tile144": 0, "wide288": 2, "tile128": 3, "latency64": 5, "latency64_splitk": 6}
+    GEMM_KERNELS = {"tile144": 0, "wide288": 2, "tile128": 3, "latency64": 5, "latency64_splitk": 6, "narrow4": 7}
     GEMM_SITES = {"qkv": 0, "attn1_out": 1, "attn2_q": 2, "attn2_out": 3, "ff1": 4, "ff2": 5, "text_kv": 6, "caption": 7, "small": 8, "attn1_kv": 9}
 
     def op_gemm_ex(self, kernel: str, site: str, epi: int, a, w, bias=None, resid=None, gate_table=None, gate_mod=None, gate_mod_stride=0, rows_per_batch=1, out=None,

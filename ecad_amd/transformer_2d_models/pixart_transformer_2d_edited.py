@@ -184,6 +184,10 @@ class PixArtTransformer2DEdited:
         mask = cache_schedule.custom_component_mask()
         # blocks that name a plug-in run as native sub-ops around the registered Python callable, per step; all others stay compiled into the engine
         self.engine.set_custom_components(mask if mask.any() else None, self._run_component)
+        # ... and functions with a native variant (compute_*_recompute, compute_attn_cfg_mean_cache) are lowered by the engine itself: per step and in the whole-loop graph
+        kinds = cache_schedule.native_variant_kinds()
+        self.engine.set_native_variants(kinds if kinds.any() else None)
+        self.uses_native_variants = bool(kinds.any())
         self.uses_plugins = bool(mask.any())
         self._ctx = None
         self._begun_key = None

@@ -110,6 +110,54 @@ def compute_ff_cached(self: CachedTransformerBlock, norm_hidden_states: torch.Te
     return out
 
 
+# -- native variants (ecad_set_native_variants): registered functions with a rule the engine also has as kernels.  In a schedule whose blocks name only native
+#    functions nothing below is ever called -- the engine resolves the rule statically, per-step and inside the whole-loop hipGraph; the callables serve a block
+#    that ALSO names a host-only plug-in (then Python drives all of that block's components) and other plug-ins that want to delegate to them.
+def compute_attn_recompute(self: CachedTransformerBlock, attn: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor | None,
+                           attention_mask: torch.Tensor | None, **cross_attention_kwargs: Any) -> torch.Tensor:
+    """Ignore the schedule's flag: evaluate the sub-layer at this step and cache it ("never reuse here")."""
+    if attn not in ["attn1", "attn2"]:
+        raise ValueError(f"Invalid attention type: {attn}. Must be attn1 or attn2")
+    _require_block(self, "compute_attn_recompute")
+    out = getattr(self, attn)(hidden_states, encoder_hidden_states, attention_mask, **cross_attention_kwargs)
+    setattr(self, f"cached_{attn}_output", out)
+    return out
+
+
+def compute_ff_recompute(self: CachedTransformerBlock, norm_hidden_states: torch.Tensor) -> torch.Tensor:
+    _require_block(self, "compute_ff_recompute")
+    out = self.ff(norm_hidden_states)
+    self.cached_ff_output = out
+    return out
+
+
+def compute_attn_cfg_mean_cache(self: CachedTransformerBlock, attn: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor | None,
+                                attention_mask: torch.Tensor | None, **cross_attention_kwargs: Any) -> torch.Tensor:
+    """attn1: the cached default.  attn2: evaluated per the schedule's flag like the default, but what is CACHED is the mean of the unconditional and the text half
+    of the CFG-doubled batch (in both halves) while the un-averaged output is returned -- the caching rule ``compute_attn_tgate`` applies at its gate step
+    (``cached_transformer_block.py:443-452``), here at every evaluation so that later reuse steps add the CFG-averaged cross-attention."""
+    if attn not in ["attn1", "attn2"]:
+        raise ValueError(f"Invalid attention type: {attn}. Must be attn1 or attn2")
+    _require_block(self, "compute_attn_cfg_mean_cache")
+    if attn == "attn1":
+        return compute_attn_cached(self, attn, hidden_states, encoder_hidden_states, attention_mask, **cross_attention_kwargs)
+    recompute = self.cache_schedule.get_recompute(self.block_num, attn) or self.cached_attn2_output is None
+    if not recompute:
+        return self.cached_attn2_output
+    out = self.attn2(hidden_states, encoder_hidden_states, attention_mask, **cross_attention_kwargs)
+    if out.shape[0] % 2:
+        raise ValueError("compute_attn_cfg_mean_cache needs a CFG-doubled batch (unconditional half, text half)")
+    uncond, text = out.chunk(2)
+    mean = ((uncond.float() + text.float()) * 0.5).to(out.dtype)
+    self.cached_attn2_output = torch.cat([mean, mean])
+    return out
+
+
+compute_attn_recompute.native_variant = 1       # ECAD_NATIVE_RECOMPUTE
+compute_ff_recompute.native_variant = 1
+compute_attn_cfg_mean_cache.native_variant = 2  # ECAD_NATIVE_CFG_MEAN_CACHE (attn2; attn1 runs the default rule)
+
+
 def _require_block(block, name: str) -> None:
     if not isinstance(block, CachedTransformerBlock):
         raise RuntimeError(f"{name} runs on the HIP engine (libecad_hip.so) through a CachedTransformerBlock of PixArtTransformer2DEdited; it has no CPU fallback.")
@@ -120,3 +168,6 @@ def _register_defaults() -> None:
 
     ComputeAttnRegistry.register(compute_attn_cached)
     ComputeFFRegistry.register(compute_ff_cached)
+    ComputeAttnRegistry.register(compute_attn_recompute)
+    ComputeFFRegistry.register(compute_ff_recompute)
+    ComputeAttnRegistry.register(compute_attn_cfg_mean_cache)

@@ -16,6 +16,12 @@ HIP sub-layers on device tensors):
 A schedule that names only the defaults never leaves the device (the gate is compiled into the engine's op lists); a block whose
 schedule names anything else is driven through these Python callables in per-step mode (``ecad_set_custom_components``).
 There is no CPU path: the sub-layers the callables can reach are the engine's.
+
+Native variants (round 6): a registered function may carry ``native_variant = <ECAD_NATIVE_* id>`` -- a gate rule the engine lowers
+into its own kernels (``ecad_set_native_variants``), so a schedule that names it runs in per-step mode AND inside the whole-loop
+hipGraph, where a Python callable cannot be called.  ``compute_attn_recompute`` / ``compute_ff_recompute`` (ignore the flag: always
+evaluate) and ``compute_attn_cfg_mean_cache`` (attn2 caches the mean of the CFG halves -- TGATE's caching rule) ship registered; the
+callables themselves stay real (another plug-in may call them, and a block that also names a host-only function runs them from Python).
 """
 from __future__ import annotations
 
@@ -47,8 +53,17 @@ class ComputeRegistry:
 
     @classmethod
     def is_native(cls, key: str | None) -> bool:
-        """True for the names the engine compiles into its op lists (absent name or the cached default)."""
-        return key is None or key.lower() == getattr(cls, "DEFAULT")
+        """True for the names the engine compiles into its op lists: absent name, the cached default, or a function that declares a native variant."""
+        return cls.native_variant(key) is not None
+
+    @classmethod
+    def native_variant(cls, key: str | None) -> int | None:
+        """The ECAD_NATIVE_* id the engine runs for ``key`` (0 for an absent name / the default), or None for a function only Python can run."""
+        if key is None or key.lower() == getattr(cls, "DEFAULT"):
+            return 0
+        func = cls._registry.get(key.lower())
+        kind = getattr(func, "native_variant", None) if func is not None else None
+        return int(kind) if kind is not None else None
 
 
 class ComputeAttnRegistry(ComputeRegistry):

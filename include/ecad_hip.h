@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ECAD_ABI_VERSION 5
+#define ECAD_ABI_VERSION 6
 
 enum {
   ECAD_OK = 0,
@@ -75,6 +75,14 @@ typedef struct EcadStats {
   int64_t fold_arena_bytes;      /* device memory this engine holds for such copies right now: live + parked plan sets + recycling pool (bounded by ECAD_LN_FOLD_BUDGET_MB, default 24576) */
   int32_t fold_refused;          /* plan sets lowered WITHOUT the fold because their copies did not fit that budget / the device */
   int32_t replays_folded;        /* cached components of the whole-loop plan replayed in the epilogue of the read-modify-write GEMM in front of them (no pending list, no launch) */
+  /* ABI 6: read-modify-write GEMM launches (both out-projections, FF2) issued through the host path since ecad_create, by the kernel that took them -- a captured
+   * hipGraph counts its launches once, when it is captured; replays issue nothing through the host.  Which kernel a launch gets depends on the batches in flight,
+   * the tile count and the replayed components it carries: these say what actually ran. */
+  int64_t rmw_launches_wide;     /* gemm2w4.h, 256 x 288 tiles (whole rounds, or half-chip beside another batch) */
+  int64_t rmw_launches_narrow4;  /* gemm3s4.h, 256 x 144 tiles on four waves */
+  int64_t rmw_launches_gemm3s;   /* gemm3s.h, 256 x 144 tiles on eight waves (and its latency / split-K forms) */
+  int32_t split_k;               /* ecad_set_split_k / ECAD_SPLIT_K as it stands */
+  int32_t batches_in_flight;     /* ecad_set_batches_in_flight as it stands */
 } EcadStats;
 
 typedef struct EcadEngine EcadEngine;
@@ -114,6 +122,11 @@ int ecad_set_ln_fold(EcadEngine* e, int on);
  * stream's kernels: faster per launch pair, slower than the full-chip kernel when nothing else runs -- say 1 when the batches are not really
  * concurrent.  Results do not depend on it (every tile shape is the same arithmetic, bit for bit).  ECAD_E_INVALID outside 1..64. */
 int ecad_set_batches_in_flight(EcadEngine* e, int n);
+/* Split-K for the few-rows FF2 (default on, env ECAD_SPLIT_K sets the default): batch 1-3 run FF2 as K-slices + a reduce launch (-14 % per image at
+ * batch 1); the fp32 sum is then taken in another order than in the sequential-K kernels, so a sample run alone at batch 1-3 equals its row inside a larger batch
+ * to rounding (1.6e-3 on final latents), not bit for bit.  0 restores bit-identity across batch sizes (golden files, cached references, a genetic evaluation whose
+ * last prompt batch has fewer than four samples).  Plan sets and graphs are keyed by it. */
+int ecad_set_split_k(EcadEngine* e, int on);
 /* Opt-in OCP fp8 (e4m3) for the block GEMMs (QKV, attention out-projections, cross-attention Q, FF1, FF2): e4m3 weight copies with
  * per-output-channel scales at finalize, activations quantised per row in front of each GEMM (csrc/gemm3s8.h).  Call before
  * ecad_finalize_weights.  Default off (env ECAD_FP8=1 sets the default): the reference computes in fp16, which stays the precision of
@@ -187,9 +200,22 @@ int ecad_reset_cache(EcadEngine* e);
  * io_in_dev, calls fn on the launch stream's host thread, and then applies gate * out + hidden (:243-246,289,317-320) to what fn left in
  * io_out_dev.  Caching is the plug-in's business, as in the reference (the defaults are plug-ins there too).  io_in_dev / io_out_dev:
  * caller-owned [max_batch * max_tokens, D] buffers of the engine dtype.  fn returns 0 or non-zero to abort the step (ECAD_E_INVALID).
- * ecad_run_schedule (whole-loop hipGraph) refuses with ECAD_E_UNSUPPORTED while any component is routed to a plug-in.  mask NULL / all zero: off. */
+ * ecad_run_schedule (whole-loop hipGraph) refuses with ECAD_E_UNSUPPORTED while any component is routed to a HOST plug-in (native variants,
+ * ecad_set_native_variants below, stay in the graph).  mask NULL / all zero: off. */
 typedef int (*EcadComponentFn)(void* user, int step_idx, int block, int component, const void* in_dev, void* out_dev, int Bt, int N, int D, void* stream);
 int ecad_set_custom_components(EcadEngine* e, const uint8_t* mask, int blocks, EcadComponentFn fn, void* user, void* io_in_dev, void* io_out_dev);
+/* Native variants of the compute plug-ins (ABI 6): gate rules other than the default `out = f(x) if flag or cache is None else cache; cache = out` that the engine
+ * lowers into its own kernels, so that a schedule naming them (`custom_compute_attn` / `custom_compute_ff`, pixart_cache_schedule.py:29-37) runs in ecad_step AND in
+ * the whole-loop plan / hipGraph of ecad_run_schedule -- a host callback cannot be captured.  kinds [steps][blocks][3] (attn1, attn2, ff), one of:
+ *   ECAD_NATIVE_DEFAULT          compute_attn_cached / compute_ff_cached (cached_transformer_block.py:326-391)
+ *   ECAD_NATIVE_RECOMPUTE        the schedule's flag is ignored: the sub-layer is evaluated at this step and cached (the reference idiom "never reuse here")
+ *   ECAD_NATIVE_CFG_MEAN_CACHE   attn2 only: evaluated per the schedule's flag as the default; what is CACHED is the mean of the unconditional and the text half of
+ *                                the CFG-doubled batch, written to both halves, while the hidden states take the un-averaged output -- the caching rule of
+ *                                compute_attn_tgate at its gate step (cached_transformer_block.py:443-452); needs an even batch
+ * Call after ecad_set_schedule (which resets every component to the default), with that schedule's steps and blocks; NULL: all default.  The executed-component
+ * counts and MAC figures of EcadStats follow.  ECAD_E_INVALID for another geometry / an unknown id, ECAD_E_UNSUPPORTED for CFG_MEAN_CACHE on attn1 / ff. */
+enum { ECAD_NATIVE_DEFAULT = 0, ECAD_NATIVE_RECOMPUTE = 1, ECAD_NATIVE_CFG_MEAN_CACHE = 2 };
+int ecad_set_native_variants(EcadEngine* e, const uint8_t* kinds, int steps, int blocks);
 /* The block's native sub-layers for use inside a plug-in = the reference's `self.attn1(h)`, `self.attn2(h, enc, mask)` (which: 1 | 2; attn2 uses the
  * text K/V and mask bias of the batch that has begun) and `self.ff(h)`: x_dev, out_dev [Bt * N, D] engine dtype; bias only, no gate, no cache. */
 int ecad_block_attn(EcadEngine* e, int block, int which, const void* x_dev, void* out_dev, void* stream);
@@ -218,7 +244,8 @@ int ecad_op_gemm(EcadEngine* e, int epi, const void* A, const void* W, const flo
 enum { ECAD_GEMM_K_TILE144 = 0 /* gemm3s.h 256x144 */, ECAD_GEMM_K_WIDE288 = 2 /* gemm2w.h 256x288 */, ECAD_GEMM_K_TILE128 = 3 /* gemm.h 128x128, N % 128 == 0 */,
        /* ids 1 and 4 belonged to kernels that left the tree in round 3 (persistent producer / consumer, 128x144 half tile): ECAD_E_UNSUPPORTED */
        ECAD_GEMM_K_LATENCY64 = 5 /* gemm3s.h 64x144, four waves of 16x144: what the engine launches when a GEMM has few rows (batch 1-4) */,
-       ECAD_GEMM_K_LATENCY64_SPLITK = 6 /* the same tiles with K in four slices + splitk_rmw_kernel: few rows and K >= 2304 (FF2), epilogue 3 only */ };
+       ECAD_GEMM_K_LATENCY64_SPLITK = 6 /* the same tiles with K in four slices + splitk_rmw_kernel: few rows and K >= 2304 (FF2), epilogue 3 only */,
+       ECAD_GEMM_K_NARROW4 = 7 /* gemm3s4.h: the 256x144 tile on four waves with the hand-placed K loop; epilogue 3 at the OUT1 / OUT2 / FF2 sites, whole 256-row tiles, K % 192 == 0 */ };
 enum { ECAD_SITE_QKV = 0, ECAD_SITE_OUT1 = 1, ECAD_SITE_Q2 = 2, ECAD_SITE_OUT2 = 3, ECAD_SITE_FF1 = 4, ECAD_SITE_FF2 = 5, ECAD_SITE_TEXTKV = 6,
        ECAD_SITE_CAPTION = 7, ECAD_SITE_SMALL = 8, ECAD_SITE_KV1 = 9 };
 int ecad_op_gemm_ex(EcadEngine* e, int kernel, int call_site, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,

@@ -27,7 +27,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 import os
 ABLATE = set(filter(None, os.environ.get("G4_ABLATE", "").split(",")))   # timing experiments only (wrong results): mfma, read, dma
-SG = dict(loop=60, ldsw=61, ap=62, ap_hi=63, wp=64, wp_hi=65, m0save=66, tmp0=67, tmp1=68, ldsw2=69)
+SG = dict(loop=60, ldsw=61, ap=62, ap_hi=63, wp=64, wp_hi=65, m0save=66, tmp0=67, tmp1=68, ldsw2=69, wdst=70, rstep=75)   # wdst: s70..s74, rstep: s75 (BN 144 only)
 
 
 def s(n):
@@ -52,21 +52,27 @@ class Gen:
 
     def __init__(self, dtype, bn, stage=False):
         self.dt, self.BN = dtype, bn
-        self.stage = stage                       # BN 288 only: after the K loop the statement itself rounds acc + bias into the row-major C tile in LDS (see stage_c)
+        self.stage = stage                       # BN 288 / 144: after the K loop the statement itself rounds acc + bias into the row-major C tile in LDS (see stage_c)
         self.fp8 = dtype == "fp8"
-        self.FN = bn // 32                       # W fragments per wave (wave tile 128 x BN/2)
-        self.NS = 3 if bn == 128 else 2          # ring slots (BN 288: the PixArt FF1 / K,V tile of gemm2w.h, 2 x 68 KiB)
+        # BN 144 (gemm3s4.h: the N = 1152 read-modify-write GEMMs and FF2 of the PixArt path, gemm3s.h's 256 x 144 tile): the waves are stacked 4 x 1 -- a wave owns
+        # 64 rows x all 144 columns, 4 A + 9 W fragments per 32-deep step for 36 MFMAs (0.36 fragment reads per MFMA against the 8-wave kernel's 0.61), its 144
+        # accumulators in a[0:143]; stages of 50 KiB in a ring of three.  18 W pieces do not divide by four waves: every wave issues five, the last two of wave 3 fetch
+        # pieces 0 and 1 a second time (same bytes to the same place; 4 % more operand traffic, one vmcnt for all waves).
+        self.narrow = bn == 144
+        self.FM = 4 if self.narrow else 8        # A fragments per wave
+        self.FN = 9 if self.narrow else bn // 32  # W fragments per wave (wave tile 128 x BN/2, or 64 x 144)
+        self.NS = 3 if bn in (128, 144) else 2   # ring slots (BN 288: the PixArt FF1 / K,V tile of gemm2w.h, 2 x 68 KiB)
         self.STAGE = (256 + bn) * 128
-        self.WP = bn // 8 // 4                   # W pieces per wave and stage
+        self.WP = 5 if self.narrow else bn // 8 // 4   # W pieces per wave and stage
         self.NP = 8 + self.WP                    # DMA pieces per wave and stage
-        self.NM = 8 * self.FN                    # MFMAs per (sub-)step
+        self.NM = self.FM * self.FN              # MFMAs per (sub-)step
         self.AX = 0
         if self.fp8:
             self.AY, self.WB = 64, 128            # A sets X / Y (8 x 8 registers), W window 4 x 8
             nxt = 160
         else:
-            self.WX, self.AY = 32, 32 + 4 * self.FN
-            self.WY = self.AY + 32
+            self.WX, self.AY = 4 * self.FM, 4 * self.FM + 4 * self.FN
+            self.WY = self.AY + 4 * self.FM
             nxt = self.WY + 4 * self.FN
         self.AADR = nxt                           # [slot][2]: sub-step 0 / 1 (16-bit) or low / high 16-byte half (e4m3)
         self.WADR = self.AADR + 2 * self.NS
@@ -75,12 +81,15 @@ class Gen:
         self.TMP = self.WOFF + self.WP
         self.SC = self.TMP + 8                    # e4m3: the unit block scale
         self.NV = self.SC + 1
-        if stage:
+        if stage and not self.narrow:
             self.C8 = self.NV                     # the ninth accumulator column in registers of the statement (nobody outside reads the accumulators of this variant)
             self.NV += 32
+        if self.narrow:
+            self.ROFF = self.NV                   # byte offsets of this lane's residual chunks (two mappings, see resid_prefetch)
+            self.NV += 2
         self.lines, self.q = [], []
         self.mfma = "v_mfma_scale_f32_16x16x128_f8f6f4" if self.fp8 else f"v_mfma_f32_16x16x32_{dtype}"
-        nreads = 10 if self.fp8 else 8 + self.FN   # read groups behind the barrier
+        nreads = 10 if self.fp8 else self.FM + self.FN   # read groups behind the barrier
         self.barrier_at = self.NM - nreads - 3
         # every piece of a stage is issued BEFORE the barrier of the (sub-)step that carries it: the counted vmcnt there relies on it.  16-bit: sub-step 0 carries the
         # pieces, sub-step 1 the barrier; e4m3: one step carries both
@@ -90,6 +99,8 @@ class Gen:
 
     def acc(self, i, j):
         """accumulator fragment (i, j): AGPRs a[4 (8 i + j) ..] for j < 8; the ninth column of the 288-wide tile lives in eight "+v" operands of the statement"""
+        if self.narrow:
+            return a(4 * (9 * i + j), 4)
         if j < 8:
             return a(4 * (8 * i + j), 4)
         return v(self.C8 + 4 * i, 4) if self.stage else f"%[c8_{i}]"
@@ -122,6 +133,8 @@ class Gen:
         ptr = "ap" if which == "a" else "wp"
         base = "ldsw" if which == "a" else "ldsw2"
         imm = slot * self.STAGE + (0 if which == "a" else 32768) + p * 1024
+        if self.narrow and which == "w":       # LDS address of W piece (5 wave + p) mod 18 of slot 0, in its own SGPR (the wrap is not an affine function of the wave)
+            return [f"s_add_u32 m0, s{SG['wdst'] + p}, {slot * self.STAGE}", "s_nop 0", f"global_load_lds_dwordx4 {v(off)}, {s2(ptr)}"]
         return [f"s_add_u32 m0, {s(base)}, {imm}", "s_nop 0", f"global_load_lds_dwordx4 {v(off)}, {s2(ptr)}"]
 
     def advance(self):
@@ -145,13 +158,13 @@ class Gen:
         self.ds(f"ds_read_b128 {v(base, 4)}, {v(adr)} offset:{f * 2048}", f"{aset}{which}{f}")
 
     def order16(self):
-        return [("w", 0)] + [("a", i) for i in range(8)] + [("w", j) for j in range(1, self.FN)]
+        return [("w", 0)] + [("a", i) for i in range(self.FM)] + [("w", j) for j in range(1, self.FN)]
 
     def substep16(self, aset, wset, naset, nwset, fillers, reads_next, barrier=None, after_barrier_reads=None):
         rd, ab = list(reads_next), list(after_barrier_reads or [])
         n = 0
         for j in range(self.FN):
-            for i in range(8):
+            for i in range(self.FM):
                 if i == 0:
                     self.need(f"{aset}w{j}")
                 if j == 0:
@@ -171,11 +184,13 @@ class Gen:
                 n += 1
         assert not rd and not ab, (len(rd), len(ab))
 
-    def step16(self, slot, dma_slot, vm, last):
+    def step16(self, slot, dma_slot, vm, last, extra=None):
         """one 64-deep stage of ring slot `slot`: sub-step 0 from set X carries the DMA of `dma_slot` (None: nothing left to fetch) and the reads of sub-step 1 into
-        set Y; sub-step 1 from set Y carries the barrier (vmcnt(vm)) and the reads of the next slot's sub-step 0 into set X"""
+        set Y; sub-step 1 from set Y carries the barrier (vmcnt(vm)) and the reads of the next slot's sub-step 0 into set X.  `extra`: more fillers of sub-step 0."""
         nslot = (slot + 1) % self.NS
         fill = self.dma_stage(dma_slot) if dma_slot is not None else {}
+        for n, ts in (extra or {}).items():
+            fill[n] = fill.get(n, []) + ts
         self.substep16(self.AX, self.WX, self.AY, self.WY, fill, [(w, f, slot, 1) for w, f in self.order16()])
         if last:
             self.substep16(self.AY, self.WY, self.AX, self.WX, {}, [])
@@ -239,10 +254,15 @@ class Gen:
         I(f"v_and_b32_e32 {v(T + 1)}, 15, {v(T)}")                  # l15
         I(f"v_lshrrev_b32_e32 {v(T + 2)}, 4, {v(T)}")               # g
         I(f"v_bfe_u32 {v(T + 3)}, {v(T)}, 1, 3")                    # swz = (l15 >> 1) & 7
-        I(f"s_and_b32 {s('tmp0')}, %[wave], 1")                     # wm
-        I(f"s_lshr_b32 {s('tmp1')}, %[wave], 1")                    # wn
-        I(f"s_lshl_b32 {s('tmp0')}, {s('tmp0')}, 14")               # wm * 128 rows * 128 B
-        I(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {self.BN // 2 * 128}")   # wn * BN/2 rows * 128 B
+        b0 = len(self.lines)
+        if self.narrow:
+            I(f"s_lshl_b32 {s('tmp0')}, %[wave], 13")               # wave * 64 rows * 128 B
+            I(f"s_mov_b32 {s('tmp1')}, 0")                          # every wave reads all 144 W rows
+        else:
+            I(f"s_and_b32 {s('tmp0')}, %[wave], 1")                     # wm
+            I(f"s_lshr_b32 {s('tmp1')}, %[wave], 1")                    # wn
+            I(f"s_lshl_b32 {s('tmp0')}, {s('tmp0')}, 14")               # wm * 128 rows * 128 B
+            I(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {self.BN // 2 * 128}")   # wn * BN/2 rows * 128 B
         I(f"v_lshlrev_b32_e32 {v(T + 4)}, 7, {v(T + 1)}")           # l15 * 128
         I(f"v_add_u32_e32 {v(T + 4)}, %[lds], {v(T + 4)}")
         for slot in range(NS):
@@ -259,11 +279,32 @@ class Gen:
                 if slot:
                     I(f"v_add_u32_e32 {v(self.AADR + 2 * slot + h)}, {slot * self.STAGE}, {v(self.AADR + 2 * slot + h)}")
                 I(f"v_add_u32_e32 {v(self.WADR + 2 * slot + h)}, {slot * self.STAGE + 32768}, {v(self.WADR + 2 * slot + h)}")
+        b1 = len(self.lines)
         # DMA lane offsets: piece q of this wave's share covers rows 8 (n wave + q) + (lane >> 3); position lane & 7 holds source piece position ^ ((row >> 1) & 7),
         # (row >> 1) & 7 = (4 (n wave + q) + (lane >> 4)) & 7 = ((q & 1) << 2) | (lane >> 4) because 4 n wave is a multiple of 8 (n = 8 or 4)
         I(f"v_lshrrev_b32_e32 {v(T + 4)}, 3, {v(T)}")               # lane >> 3
         I(f"v_and_b32_e32 {v(T + 5)}, 7, {v(T)}")                   # position
         for which, n, off, rs in (("a", 8, self.AOFF, "%[rsa]"), ("w", self.WP, self.WOFF, "%[rsw]")):
+            if self.narrow and which == "w":
+                for q in range(n):
+                    # W piece (5 wave + q) mod 18: rows 8 piece + (lane >> 3), (row >> 1) & 7 = ((4 piece) & 7) | (lane >> 4); its LDS address in slot 0 -> s[wdst + q]
+                    I(f"s_mul_i32 {s('tmp1')}, %[wave], 5")
+                    I(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, {q}")
+                    I(f"s_sub_u32 {s('tmp0')}, {s('tmp1')}, 18")
+                    I(f"s_cmp_ge_u32 {s('tmp1')}, 18")
+                    I(f"s_cselect_b32 {s('tmp1')}, {s('tmp0')}, {s('tmp1')}")
+                    I(f"s_lshl_b32 {s('tmp0')}, {s('tmp1')}, 10")
+                    I(f"s_add_u32 s{SG['wdst'] + q}, %[lds], {s('tmp0')}")
+                    I(f"s_add_u32 s{SG['wdst'] + q}, s{SG['wdst'] + q}, 32768")
+                    I(f"s_lshl_b32 {s('tmp0')}, {s('tmp1')}, 3")      # first row of the piece
+                    I(f"s_lshl_b32 {s('tmp1')}, {s('tmp1')}, 2")
+                    I(f"s_and_b32 {s('tmp1')}, {s('tmp1')}, 7")
+                    I(f"v_or_b32_e32 {v(T + 6)}, {s('tmp1')}, {v(T + 2)}")
+                    I(f"v_xor_b32_e32 {v(T + 6)}, {v(T + 6)}, {v(T + 5)}")
+                    I(f"v_lshlrev_b32_e32 {v(T + 6)}, 4, {v(T + 6)}")
+                    I(f"v_add_u32_e32 {v(T + 7)}, {s('tmp0')}, {v(T + 4)}")
+                    I(f"v_mad_u32_u24 {v(off + q)}, {v(T + 7)}, {rs}, {v(T + 6)}")
+                continue
             I(f"s_mul_i32 {s('tmp0')}, %[wave], {8 * n}")            # first row of this wave's pieces
             for q in range(n):
                 # (row >> 1) & 7 with row = 8 (n wave + q) + (lane >> 3): ((4 (n wave + q)) & 7) | (lane >> 4) -- n = 9 makes the first term depend on the wave
@@ -282,18 +323,36 @@ class Gen:
         I(f"s_add_u32 {s('ldsw2')}, %[lds], {s('tmp0')}")
         I(f"s_mov_b64 {s2('ap')}, %[ap]")
         I(f"s_mov_b64 {s2('wp')}, %[wp]")
+        b2 = len(self.lines)
         if self.fp8:
             I(f"v_mov_b32_e32 {v(self.SC)}, 0x7f7f7f7f")
         I("s_cmp_eq_u32 %[zero], 0")      # a second K segment (split-A GEMM: another A buffer for the rest of K) goes on accumulating
         I(f"s_cbranch_scc1 {self.lbl('KEEP')}")
-        for i in range(8):
-            for j in range(min(self.FN, 8)):     # (the ninth column's operands are zeroed by the caller)
-                for r in range(4):
-                    I(f"v_accvgpr_write_b32 {a(4 * (8 * i + j) + r)}, 0")
+        if self.narrow:
+            for r in range(4 * self.FM * self.FN):
+                I(f"v_accvgpr_write_b32 {a(r)}, 0")
+        else:
+            for i in range(8):
+                for j in range(min(self.FN, 8)):     # (the ninth column's operands are zeroed by the caller)
+                    for r in range(4):
+                        I(f"v_accvgpr_write_b32 {a(4 * (8 * i + j) + r)}, 0")
         self.L("KEEP")
-        if self.stage:
+        if self.stage and not self.narrow:
             for r in range(32):
                 I(f"v_mov_b32_e32 {v(self.C8 + r)}, 0")
+        if self.narrow:
+            # residual chunks of this lane (resid_prefetch): byte offsets from %[rbase] = &h[m0 + 64 wave][n0]
+            I(f"v_lshrrev_b32_e32 {v(T + 6)}, 4, {v(T)}")                        # lane >> 4
+            I(f"v_and_b32_e32 {v(T + 7)}, 15, {v(T)}")                           # lane & 15
+            I(f"v_lshlrev_b32_e32 {v(T + 7)}, 4, {v(T + 7)}")
+            I(f"v_mad_u32_u24 {v(self.ROFF)}, {v(T + 6)}, %[ldrb], {v(T + 7)}")  # mapping A: row 4 it + (lane >> 4), chunk lane & 15
+            I(f"v_lshrrev_b32_e32 {v(T + 6)}, 1, {v(T)}")                        # lane >> 1
+            I(f"v_and_b32_e32 {v(T + 7)}, 1, {v(T)}")
+            I(f"v_lshlrev_b32_e32 {v(T + 7)}, 4, {v(T + 7)}")
+            I(f"v_add_u32_e32 {v(T + 7)}, 256, {v(T + 7)}")
+            I(f"v_mad_u32_u24 {v(self.ROFF + 1)}, {v(T + 6)}, %[ldrb], {v(T + 7)}")   # mapping B: row 32 (it - 16) + (lane >> 1), chunk 16 + (lane & 1)
+            I(f"s_lshl_b32 s{SG['rstep']}, %[ldrb], 2")                          # four rows
+        b3 = len(self.lines)
         for slot in range(NS - 1):          # the first NS - 1 stages
             for which, n in (("a", 8), ("w", self.WP)):
                 for p in range(n):
@@ -301,6 +360,11 @@ class Gen:
                         I(t)
             for t in self.advance():
                 I(t)
+        if self.narrow:
+            # BN 144: the first two stages are requested as soon as their addresses exist; the fragment addresses, the 144 accumulator zeros and the residual offsets
+            # are computed while they travel (every block below sets the temporaries it uses; a one-round kernel pays this prologue once per launch)
+            L = self.lines
+            self.lines = L[:b0] + L[b1:b2] + L[b3:] + L[b0:b1] + L[b2:b3]
         I(f"s_waitcnt vmcnt({self.NP * (NS - 2)})")
         I("s_barrier")
         if self.fp8:
@@ -318,7 +382,7 @@ class Gen:
         I(f"s_cbranch_scc1 {self.lbl('LAST')}")
         vm = self.NP * (NS - 2)
 
-        def emit(k, dma, vmc, last):
+        def emit(k, dma, vmc, last, extra=None):
             slot = k % NS
             if self.fp8:
                 aset, naset = (self.AX, self.AY) if k % 2 == 0 else (self.AY, self.AX)
@@ -326,7 +390,7 @@ class Gen:
                 self.step8(slot, (slot + NS - 1) % NS if dma else None, vmc, last, aset, naset)
             else:
                 self.q = list(canonical)
-                self.step16(slot, (slot + NS - 1) % NS if dma else None, vmc, last)
+                self.step16(slot, (slot + NS - 1) % NS if dma else None, vmc, last, extra)
 
         self.L("LOOP")
         for k in range(self.period):
@@ -337,13 +401,76 @@ class Gen:
         self.L("LAST")
         for k in range(self.period):
             left = self.period - 1 - k           # stages after this one
+            if self.narrow and self.stage and left == 1:
+                # the second-to-last stage has no DMA left to issue: the NRES residual loads of the read-modify-write epilogue go out here, behind every operand piece,
+                # so this stage's counted wait lets exactly them stay in flight (vmcnt retires in order) -- an HBM round trip that travels under two stages of MFMAs
+                # and the C-tile staging instead of in front of the row pass (gemm3s.h issues its residual loads in the same place)
+                emit(k, False, self.NRES, False, self.resid_prefetch())
+                continue
             emit(k, left >= NS - 1, vm if left >= NS - 1 else 0, left == 0)
         I("s_nop 15")
         I("s_barrier")   # every wave is done with the ring: the epilogue's C tile may overwrite it
         if self.stage:
-            self.stage_c()
+            if self.narrow:
+                self.stage_c144()
+                I("s_waitcnt vmcnt(0)")   # the residual chunks are the statement's outputs: the compiler does not know they are loads in flight
+            else:
+                self.stage_c()
         I(f"s_mov_b32 m0, {s('m0save')}")
         return self.lines
+
+    NRES = 18
+
+    def resid_prefetch(self):
+        """fillers of sub-step 0 (even MFMA slots; the fragment reads sit on the odd ones): this lane's 18 sixteen-byte chunks of the wave's 64 x 144 block of hidden
+        states into the statement's outputs %[h0] .. %[h17].  Mapping A (h0 .. h15): row 4 it + (lane >> 4), chunk lane & 15 -- 256 contiguous bytes of four rows per
+        load; mapping B (h16, h17): row 32 (it - 16) + (lane >> 1), chunk 16 + (lane & 1).  The row pass of gemm3s4.h uses the same mapping."""
+        out = {}
+        for it in range(self.NRES):
+            ts = []
+            if 1 <= it <= 15:
+                ts.append(f"v_add_u32_e32 {v(self.ROFF)}, s{SG['rstep']}, {v(self.ROFF)}")
+            if it == 17:
+                ts.append(f"s_lshl_b32 {s('tmp0')}, %[ldrb], 5")
+                ts.append(f"v_add_u32_e32 {v(self.ROFF + 1)}, {s('tmp0')}, {v(self.ROFF + 1)}")
+            ts.append(f"global_load_dwordx4 %[h{it}], {v(self.ROFF if it < 16 else self.ROFF + 1)}, %[rbase]")
+            out[2 * it] = ts
+        return out
+
+    def stage_c144(self):
+        """BN 144: round(acc + bias) of the wave's 64 x 144 block into the row-major C tile at the start of the LDS (row stride 304 bytes = gemm3s.h's CS), the 144 bias
+        values read from LDS at %[lds] + CST144.  Rows 64 wave .. 64 wave + 63 are written and later read by this wave only: no barrier behind it."""
+        I, T = self.I, self.TMP
+        BV, TT, PK, B0 = 0, 40, 56, 64
+        CS = 304
+        cvt = "v_cvt_pk_bf16_f32" if self.dt == "bf16" else "v_cvt_pk_f16_f32"
+        I(f"v_mbcnt_lo_u32_b32 {v(T)}, -1, 0")
+        I(f"v_mbcnt_hi_u32_b32 {v(T)}, -1, {v(T)}")
+        I(f"v_and_b32_e32 {v(T + 1)}, 15, {v(T)}")                  # l15
+        I(f"v_lshrrev_b32_e32 {v(T + 2)}, 4, {v(T)}")               # g
+        I(f"s_mul_i32 {s('tmp0')}, %[wave], {64 * CS}")
+        I(f"v_mul_u32_u24_e32 {v(B0)}, {CS}, {v(T + 1)}")           # l15 rows
+        I(f"v_add_u32_e32 {v(B0)}, {s('tmp0')}, {v(B0)}")
+        I(f"v_lshl_add_u32 {v(B0)}, {v(T + 2)}, 3, {v(B0)}")        # + 4 g columns x 2 bytes
+        I(f"v_add_u32_e32 {v(B0)}, %[lds], {v(B0)}")
+        I(f"s_add_u32 {s('tmp1')}, %[lds], {CST144}")
+        I(f"v_lshl_add_u32 {v(T + 4)}, {v(T + 2)}, 4, {s('tmp1')}")  # bias of column 16 j + 4 g: 64 j + 16 g bytes
+        for j in range(9):
+            I(f"ds_read_b128 {v(BV + 4 * j, 4)}, {v(T + 4)} offset:{64 * j}")
+        I("s_waitcnt lgkmcnt(0)")
+        n = 0
+        for i in range(4):
+            for j in range(9):
+                t, pk = TT + 4 * (n % 4), PK + 2 * (n % 4)
+                for r in range(4):
+                    I(f"v_accvgpr_read_b32 {v(t + r)}, {a(4 * (9 * i + j) + r)}")
+                I(f"v_pk_add_f32 {v(t, 2)}, {v(t, 2)}, {v(BV + 4 * j, 2)}")
+                I(f"v_pk_add_f32 {v(t + 2, 2)}, {v(t + 2, 2)}, {v(BV + 4 * j + 2, 2)}")
+                I(f"{cvt} {v(pk)}, {v(t)}, {v(t + 1)}")
+                I(f"{cvt} {v(pk + 1)}, {v(t + 2)}, {v(t + 3)}")
+                I(f"ds_write_b64 {v(B0)}, {v(pk, 2)} offset:{i * 16 * CS + 32 * j}")
+                n += 1
+        I("s_waitcnt lgkmcnt(0)")
 
     def stage_c(self):
         """round(acc + bias) of the wave's 128 x 144 block into the row-major C tile at the start of the LDS (row stride 592 bytes = gemm2w.h's G2_CS), the 288 bias
@@ -390,6 +517,9 @@ class Gen:
         I("s_waitcnt lgkmcnt(0)")
 
 
+CST144 = 3 * (256 + 144) * 128      # gemm3s4.h: bias[144] fp32 | gate table[144] fp32 | gate modulation[144] T, behind the three ring slots
+
+
 OPERANDS = """\
       : /* accumulators stay in AGPRs */
       : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
@@ -406,8 +536,13 @@ OPERANDS_288S = """\
 """
 
 
-def clobbers(nv):
-    c = ['"memory"', '"vcc"', '"scc"'] + [f'"v{i}"' for i in range(nv)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(60, 70)]
+OPERANDS_144S = ("      : " + ", ".join(f'[h{i}] "=&v"(h[{i}])' for i in range(18)) + """
+      : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero), [rbase] "s"(rbase), [ldrb] "s"(ldrb)
+""")
+
+
+def clobbers(nv, s_hi=70):
+    c = ['"memory"', '"vcc"', '"scc"'] + [f'"v{i}"' for i in range(nv)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(60, s_hi)]
     return ", ".join(c)
 
 
@@ -432,6 +567,16 @@ def main():
         body = "\n".join('    "' + ln + '\\n"' for ln in lines)
         parts.append(f"#define GEMM4_ASM_{dt.upper()}_288S(ap, wp, rsa, rsw, trips, lds, wave, zero, cst) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
                      + "\n".join(x + " \\" for x in OPERANDS_288S.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV) + ")\n")
+    for dt in ("bf16", "f16"):
+        g = Gen(dt, 144, stage=True)
+        lines = g.build()
+        print(f"{dt} BN 144 (4 x 1 waves) + residual prefetch + C-tile staging: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs, {g.NV} VGPRs, stages per trip {g.period}, "
+              f"barrier at {g.barrier_at}, DMA stride {g.dma_stride}", file=sys.stderr)
+        body = "\n".join('    "' + ln + '\\n"' for ln in lines)
+        parts.append(f"#define GEMM4_CST144 {CST144}  // LDS offset of the epilogue constants of the BN 144 statements\n"
+                     f"#define GEMM4_PERIOD_144 {g.period}\n" if dt == "bf16" else "")
+        parts.append(f"#define GEMM4_ASM_{dt.upper()}_144S(ap, wp, rsa, rsw, trips, lds, wave, zero, rbase, ldrb, h) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
+                     + "\n".join(x + " \\" for x in OPERANDS_144S.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV, 76) + ")\n")
     text = "\n".join(parts)
     if "--check" in sys.argv:   # the committed header is what this generator writes (tests/test_cpu_host.py)
         if ABLATE or out.read_text() != text:

@@ -693,6 +693,42 @@ def test_batches_in_flight_pick_the_tile_shape_not_the_result(monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_read_modify_write_launches_on_the_four_wave_narrow_tile_change_nothing(monkeypatch, dtype, few_rows_tiles):
+    """gemm3s4.h in whole plans (round 6): with ECAD_GEMM3S4=3 every read-modify-write GEMM of the plan that has whole 256-row tiles -- both out-projections and
+    FF2, with and without cached components replayed in their epilogue, publishing the row statistics a folded LayerNorm then consumes -- runs on the 256 x 144 tile
+    on four waves; with 0 none does.  Same arithmetic in the same order: the final latents of a whole cached loop are the same bits, graph and eager, and the engine's
+    launch counters (EcadStats, round-5 ADVICE) say which kernel took the launches."""
+    from ecad_amd.engine import EcadEngine
+
+    if few_rows_tiles == "latency64":
+        pytest.skip("at batch 2 the latency tiles take every GEMM of the plan before the 256-row kernels are considered")
+    layers, steps, B = 4, 6, 2
+    bits = rand_bits(steps, layers, 0.6, seed=77)
+    bits[0] = True
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    inp, enc, mask = cfg_inputs(B)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    outs, counts = {}, {}
+    for level in ("0", "1", "3"):
+        monkeypatch.setenv("ECAD_GEMM3S4", level)
+        eng, w, cfg = make_pair(layers, bits, max_batch=2 * B, dtype=dtype)
+        g = eng.run_schedule(*args, use_graph=True).clone()
+        e = eng.run_schedule(*args, use_graph=False).clone()
+        assert torch.equal(g, e)
+        st = eng.stats()
+        outs[level], counts[level] = g, (st["rmw_launches_narrow4"], st["rmw_launches_gemm3s"], st["rmw_launches_wide"], st["replays_folded"])
+        eng.close()
+    assert torch.equal(outs["0"], outs["3"]) and torch.equal(outs["0"], outs["1"])
+    n4_0, g3_0, _, folded = counts["0"]
+    n4_1, g3_1, _, _ = counts["1"]
+    n4_3, g3_3, _, _ = counts["3"]
+    assert n4_0 == 0 and g3_0 > 0 and folded > 0          # the plan does carry replayed components
+    assert 0 < n4_1 < n4_3 and n4_1 + g3_1 == g3_0        # default: FF2 launches without replays only
+    assert g3_3 == 0 and n4_3 == g3_0                     # 3: all of them
+
+
 def test_adaptive_pool_needs_several_lonely_turns_before_it_plans_for_one_batch():
     """EngineContexts(adaptive=True) (round-5 ADVICE): the downgrade to "this batch runs alone" is opt-in, takes `idle_turns` consecutive submissions that found
     every peer idle (never the first turn of a pool), and is undone by the first busy peer; by default a pool keeps what it was built for -- one plan set and one

@@ -175,6 +175,43 @@ def test_read_modify_write_epilogue_on_the_wide_tile_is_gemm3s_bit_for_bit(dtype
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("site,K,B,Ntok,gated,has_bias", [("attn1_out", 1152, 32, 256, True, True), ("attn2_out", 1152, 8, 256, False, True), ("ff2", 4608, 32, 256, True, True),
+                                                          ("ff2", 4608, 2, 4096, True, True), ("attn1_out", 192, 4, 256, True, False), ("attn2_out", 384, 4, 512, "table", True)])
+def test_narrow_tile_on_four_waves_stores_gemm3s_bytes(dtype_name, site, K, B, Ntok, gated, has_bias):
+    """gemm3s4.h (round 6): gemm3s's 256 x 144 tile with the read-modify-write epilogue -- cache <- out; hidden += gate * out (cached_transformer_block.py:243-246,
+    317-320,355-360) -- on four waves, one per SIMD, the K loop a generated statement that also issues the residual loads and rounds acc + bias into the C tile.  The
+    engine launches it for FF2 of a batch that runs alone, so it must store gemm3s's bytes: cache slot and hidden states bit for bit (K = 192: the single last trip of
+    the loop; K = 384: one full trip + the last; no bias: the statement adds the zeros the kernel put there), and both within tolerance of fp32 torch.  The row
+    statistics and replayed components are compared bit for bit by scripts/probe_gemm3s4.hip and, through whole plans, by the engine tests that run every
+    read-modify-write launch on it (ECAD_GEMM3S4=3)."""
+    eng = small_engine(dtype_name)
+    dt = getattr(torch, dtype_name)
+    D, M = 1152, B * Ntok
+    a, w = _r((M, K), dt, 1.0, 81), _r((D, K), dt, 0.03, 82)
+    bias = _r((D,), torch.float32, 0.1, 83) if has_bias else None
+    h0 = _r((M, D), dt, 1.0, 84)
+    table = _r((D,), torch.float32, 1.0, 85) if gated else None
+    mod = _r((B, 6 * D), dt, 1.0, 86) if gated is True else None
+    res = {}
+    for kernel in ("narrow4", "tile144"):
+        h = h0.clone()
+        cache = torch.zeros((M, D), dtype=dt, device="cuda")
+        eng.op_gemm_ex(kernel, site, 3, a, w, bias, resid=h, gate_table=table, gate_mod=mod[:, 2 * D :] if mod is not None else None, gate_mod_stride=6 * D if mod is not None else 0, rows_per_batch=Ntok,
+                       out=cache)
+        res[kernel] = (cache, h)
+    assert torch.equal(res["narrow4"][0], res["tile144"][0]) and torch.equal(res["narrow4"][1], res["tile144"][1])
+    out_ref = (a.float() @ w.float().t() + (bias if bias is not None else 0.0)).to(dt).float()
+    gate = ((table[None] + mod[:, 2 * D : 3 * D].float()).repeat_interleave(Ntok, 0) if mod is not None else table[None]) if gated else 1.0
+    assert within(tile_rel_l2(res["narrow4"][0], out_ref), TOL[dtype_name])
+    assert within(tile_rel_l2(res["narrow4"][1], h0.float() + gate * out_ref), TOL[dtype_name])
+    # it names its limits instead of substituting another kernel: whole 256-row tiles, K in whole trips of the three-stage loop, the three read-modify-write sites
+    with pytest.raises((RuntimeError, ValueError), match="gemm3s4"):
+        eng.op_gemm_ex("narrow4", site, 3, a[:, :128].contiguous(), w[:, :128].contiguous(), bias, resid=h0.clone(), rows_per_batch=Ntok, out=torch.zeros((M, D), dtype=dt, device="cuda"))
+    with pytest.raises((RuntimeError, ValueError), match="gemm3s4"):
+        eng.op_gemm_ex("narrow4", "ff1", 1, a, w, bias, out=torch.zeros((M, D), dtype=dt, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 def test_gemm_wide_kv_writes_into_fused_qkv_buffer(dtype_name):
     """The split QKV launch of the engine: Q on 256x144 tiles into columns [0, D), K,V on 256x288 tiles into columns [D, 3D) of one [M, 3D] buffer
     (row stride 3D on the output) -- together they must equal one fused projection, and neither may touch the other's columns."""

@@ -18,8 +18,9 @@ from oracle.pipeline_ref import synthetic_inputs  # noqa: E402  (checker only)
 from oracle.pixart_ref import PixArtConfig, PixArtOracle, make_weights  # noqa: E402
 
 
-def _model(layers, steps, bits, custom):
-    """Facade + schedule whose rows name plug-ins: custom = {(step, block): {"custom_compute_ff": {...}, ...}}."""
+def _model(layers, steps, bits, custom, unit_gates=False):
+    """Facade + schedule whose rows name plug-ins: custom = {(step, block): {"custom_compute_ff": {...}, ...}}.  unit_gates: scale_shift_table ~ N(0, 1) as in
+    test_gpu_engine.unit_gate_weights (gates of O(1): a sub-layer's output reaches the prediction at full size)."""
     from ecad_amd.schedulers.cache_scheduler.pixart_cache_schedule import PixArtCacheSchedule
     from ecad_amd.schedulers.dit_scheduler.dit_scheduler import DiTScheduler, PixArtDiTSchedule
     from ecad_amd.transformer_2d_models.pixart_transformer_2d_edited import PixArtTransformer2DEdited
@@ -29,6 +30,11 @@ def _model(layers, steps, bits, custom):
         sched.schedule[s][str(b)].update(extra)
     cfg = PixArtConfig(num_layers=layers)
     w = make_weights(cfg, seed=3)
+    if unit_gates:
+        g = torch.Generator().manual_seed(103)
+        for k in w:
+            if k.endswith("scale_shift_table"):
+                w[k] = torch.randn(w[k].shape, generator=g)
     tr = PixArtTransformer2DEdited(num_layers=layers, sample_size=32, max_batch=4)
     tr.load_state_dict(w)
     tr._post_init(DiTScheduler(PixArtDiTSchedule(layers, steps, "default")), sched)
@@ -302,3 +308,108 @@ def test_blocks_run_in_the_order_of_the_references_default_fx_graph(golden_dir):
         tr(x.cuda(), encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=torch.full((2,), 900.0 - 100 * s).cuda(), return_dict=False)
         sched.per_step_callback(s, 0)
     assert seen == order * steps
+
+
+def test_native_variants_run_per_step_and_inside_the_whole_loop_graph():
+    """Round 6 (row a6): a registered compute function may declare a native variant -- a gate rule the engine lowers into its own kernels
+    (``ecad_set_native_variants``) -- so a schedule that names it stays on the device: per step through ``ecad_step`` and inside the whole-loop plan and its hipGraph
+    (``ecad_run_schedule``), which a host callback cannot enter.  ``compute_attn_recompute`` / ``compute_ff_recompute`` ignore the schedule's flag;
+    ``compute_attn_cfg_mean_cache`` caches the mean of the CFG halves of attn2 while the hidden states take the un-averaged output (the caching rule of
+    ``compute_attn_tgate``, cached_transformer_block.py:443-452).  Checked against the oracle with the same rules as hooks: per step (2e-3, as every per-step
+    comparison here), on the final latents of the whole loop (6e-3, test_gpu_engine's bound for final latents), graph == eager bit for bit, and the executed-component
+    count of EcadStats follows the variants."""
+    from oracle.dpm_solver_ref import DPMSolverPP2M
+    from oracle.pipeline_ref import denoise
+
+    layers, steps = 3, 5
+    bits = np.random.default_rng(14).random((steps, layers, 3)) < 0.5
+    bits[0] = True
+    custom = {}
+    for s in range(steps):
+        if s >= 1:
+            custom[(s, 0)] = {"custom_compute_attn": {"name": "compute_attn_recompute"}}         # block 0: attn1 and attn2 always evaluated from step 1 on
+        if s >= 2:
+            custom.setdefault((s, 1), {})["custom_compute_ff"] = {"name": "compute_ff_recompute"}    # block 1: ff always evaluated from step 2 on
+        custom.setdefault((s, 2), {})["custom_compute_attn"] = {"name": "compute_attn_cfg_mean_cache", "kwargs": {}}   # block 2: attn2 caches the CFG mean at every step
+    tr, sched, cfg, w = _model(layers, steps, bits, custom, unit_gates=True)
+    assert not tr.uses_plugins and tr.uses_native_variants and sched.uses_only_native_compute() and not sched.custom_component_mask().any()
+    kinds = sched.native_variant_kinds()
+    assert kinds[0, 0].tolist() == [0, 0, 0] and kinds[1, 0].tolist() == [1, 1, 0] and kinds[1, 1].tolist() == [0, 0, 0] and kinds[2, 1].tolist() == [0, 0, 1]
+    assert all(kinds[s, 2].tolist() == [0, 2, 0] for s in range(steps))   # attn1 of the CFG-mean function is the default rule
+    forced = int(((kinds == 1) & ~bits).sum())
+    ex = np.ones((layers, 3), bool)
+    expected_executed = 0
+    have = np.zeros((layers, 3), bool)
+    for s in range(steps):
+        ex = bits[s] | (kinds[s] == 1) | ~have
+        have |= ex
+        expected_executed += int(ex.sum())
+    assert tr.engine.stats()["components_executed"] == expected_executed and forced > 0
+
+    def make_ref():
+        ref = PixArtOracle(cfg, w)
+        cell = {"s": 0}
+
+        def fresh_and_cache(block, comp, first):
+            def hook(cached, fresh):
+                if cell["s"] < first:
+                    return cached()
+                out = fresh()
+                ref.cache.entries[(block, comp)] = out
+                return out
+            return hook
+
+        def cfg_mean(cached, fresh):
+            n0 = len(ref.cache.executed_log)
+            out = cached()
+            if len(ref.cache.executed_log) > n0:   # evaluated at this step: the cache keeps the CFG mean, the block adds the un-averaged output
+                u, t = out.chunk(2)
+                m = ref.q(0.5 * (u + t))
+                ref.cache.entries[(2, "attn2")] = torch.cat([m, m])
+            return out
+
+        ref.plugins = {(0, "attn1"): fresh_and_cache(0, "attn1", 1), (0, "attn2"): fresh_and_cache(0, "attn2", 1), (1, "ff"): fresh_and_cache(1, "ff", 2), (2, "attn2"): cfg_mean}
+        orig = ref.forward
+
+        def fwd(*a, **k):
+            cell["s"] = a[4]
+            return orig(*a, **k)
+
+        ref.forward = fwd
+        return ref
+
+    worst = _run(tr, sched, make_ref(), bits, steps)
+    print(f"native-variant schedule, per step: worst rel-L2 {worst:.3e}")
+    assert within(worst, 2e-3)
+    # the whole loop: one hipGraph, no host round trips -- and the same values as launching its ops eagerly
+    B = 2
+    inp = synthetic_inputs(B)
+    enc = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]], 0).cuda()
+    mask = torch.cat([inp["negative_prompt_attention_mask"], inp["prompt_attention_mask"]], 0).cuda()
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    graph = tr.engine.run_schedule(enc, mask, inp["latents"].cuda(), solver.timesteps, coefs, 4.5, use_graph=True).clone()
+    assert tr.engine.stats()["graph_nodes"] > 0
+    eager = tr.engine.run_schedule(enc, mask, inp["latents"].cuda(), solver.timesteps, coefs, 4.5, use_graph=False)
+    assert torch.equal(graph, eager)
+    q = {k: (v.half().float() if v.is_floating_point() else v) for k, v in inp.items()}
+    exp = denoise(make_ref(), bits, q)
+    err = rel_l2(graph, exp)
+    print(f"native-variant schedule, whole loop in one hipGraph: final-latent rel-L2 {err:.3e}")
+    assert within(err, 6e-3)
+    # the rule is part of the result: the same bits without the variants give other latents (the net would notice a variant that is silently dropped)
+    tr.engine.set_native_variants(None)
+    plain = tr.engine.run_schedule(enc, mask, inp["latents"].cuda(), solver.timesteps, coefs, 4.5, use_graph=True)
+    moved = rel_l2(plain, exp)
+    print(f"the same schedule bits without the variants: {moved:.3e} from the oracle that applies them")
+    assert moved > 3 * err
+    # limits are named: the CFG-mean rule exists for attn2, ids are checked, the geometry must be the schedule's
+    bad = np.zeros((steps, layers, 3), np.uint8)
+    bad[0, 0, 0] = 2
+    with pytest.raises((RuntimeError, ValueError), match="attn2"):
+        tr.engine.set_native_variants(bad)
+    bad[0, 0, 0] = 9
+    with pytest.raises(ValueError, match="unknown"):
+        tr.engine.set_native_variants(bad)
+    with pytest.raises(ValueError, match="schedule"):
+        tr.engine.set_native_variants(np.ones((steps + 1, layers, 3), np.uint8))

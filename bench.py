@@ -261,6 +261,12 @@ def main_flux(args, world, rank, device, dist):
 
     B, grid, T = 2, 64, 512
     sched_path = "schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json"
+    small = args.workload == "flux256"
+    if small:
+        # the geometry the paper's FLUX schedules were searched on (schedules_in_paper/flux_256/ours_fast.json: 256 x 256 -> N = 256 image + T = 512 text tokens),
+        # at the batch its own latency record uses (metrics.latency: batch_size 18, 1016.6 ms per image on an A6000)
+        B, grid = args.batch or 18, 16
+        sched_path = "schedules/schedules_in_paper/flux_256/ours_fast.json"
     sched = FluxCacheSchedule.from_json(ROOT / sched_path)
     model = FluxTransformer2DEdited(guidance_embeds=True, max_batch=B, max_image_tokens=grid * grid, max_text_tokens=T, torch_dtype=torch.bfloat16, device=device.index)
     eng = model.engine
@@ -291,10 +297,11 @@ def main_flux(args, world, rank, device, dist):
         value = job["value"]
         flop_per_image = 2.0 * (st["linear_macs_reference"] + st["attn_core_macs"])
         res = {
-            "metric": "images/sec at fixed schedule (FLUX.1-dev 1024, 20-step, fast_256_to_1024) [secondary]", **job, "warmup": args.warmup,
+            "metric": ("images/sec at fixed schedule (FLUX.1-dev 256, 20-step, flux_256/ours_fast) [secondary]" if small
+                       else "images/sec at fixed schedule (FLUX.1-dev 1024, 20-step, fast_256_to_1024) [secondary]"), **job, "warmup": args.warmup,
             "dtype": "fp8-e4m3 block GEMMs, bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
             "config": {
-                "workload": f"FLUX.1-dev geometry 1024x1024 (N=4096 + T=512 tokens, D=3072, 19+38 blocks), 20 steps, {sched_path}, batch=2 (no CFG; guidance 5 embedded), 1xMI355X per rank",
+                "workload": f"FLUX.1-dev geometry {16 * grid}x{16 * grid} (N={grid * grid} + T=512 tokens, D=3072, 19+38 blocks), 20 steps, {sched_path}, batch={B} (no CFG; guidance 5 embedded), 1xMI355X per rank",
                 "batch_per_gpu": B, "timed_region": "context/pooled embedding hoist, all-step adaLN GEMM, 20 transformer steps with cache gate, flow-match Euler; packed latents out (no VAE/PIL)",
                 "weights": "random-init FLUX.1-dev shapes, 11.9 B parameters (no checkpoint available offline)", "hipgraph": bool(use_graph and st["graph_nodes"] > 0),
                 "kernel_launches_per_batch": st["launches_per_batch"], "ms_per_image": 1000.0 * elapsed / (args.steps * B),
@@ -303,7 +310,7 @@ def main_flux(args, world, rank, device, dist):
                 "whole_job_mfma_fraction_pricing": ("linear flops at the 5 PFLOP/s fp8 peak, attention core at the 2.5 PFLOP/s bf16 peak" if args.fp8
                                                     else "all flops at the 2.5 PFLOP/s bf16 peak"),
                 "components_executed_cached_dead": [st["components_executed"], st["components_cached"], st["components_dead"]],
-                "published_reference_a6000_images_per_s": 0.144,
+                "published_reference_a6000_images_per_s": (1000.0 / 1016.588 if small else 0.144),
             },
         }
         if not args.no_roofline:
@@ -319,7 +326,7 @@ def main_flux(args, world, rank, device, dist):
             gem = [v for k, v in mf.items() if k.startswith("gemm")]
             # HBM bytes per launch by PMC: only from a committed profile stamped with this workload, dtype and kernel sources (scripts/pmc_traffic.py; the
             # joint attention out-projection and FF2 share a kernel symbol and grid, so their traffic is one merged class)
-            pmc, pmc_file, stamp = stamped_traffic(f"flux1024_b{B}", "fp8" if args.fp8 else "bf16")
+            pmc, pmc_file, stamp = stamped_traffic(f"{args.workload}_b{B}", "fp8" if args.fp8 else "bf16")
 
             def traffic_of(cls):
                 e = pmc.get(cls) or (pmc.get("gemm_joint_attn_out+ff2") if cls in ("gemm_joint_attn_out", "gemm_joint_ff2") else None)
@@ -331,7 +338,7 @@ def main_flux(args, world, rank, device, dist):
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "flops_per_launch": d["flops"] / d["launches"],
                                "avg_launch_ms": d["ms"] / d["launches"], "launches_measured": d["launches"],
                                "all_gemm_tflops": sum(v["flops"] for v in gem) / (sum(v["ms"] for v in gem) * 1e-3) / 1e12}
-            sq, sq_file = stamped_sq(f"flux1024_b{B}", "fp8" if args.fp8 else "bf16")
+            sq, sq_file = stamped_sq(f"{args.workload}_b{B}", "fp8" if args.fp8 else "bf16")
             res["roofline"].update(sq_fields(sq, sq_file, "gemm_joint_attn_out+ff2" if dom in ("gemm_joint_attn_out", "gemm_joint_ff2") else dom))
             at = mf.get("attn_joint")
             if at:
@@ -427,6 +434,8 @@ SECONDARY = {
     "sigma1024_batch4": ["--workload", "sigma1024", "--steps", "4", "--warmup", "1", "--streams", "2", "--roofline"],  # two batches in flight: +1.7 % (9.13 -> 9.29 same box; three: +0.6 %)
     "flux1024_batch2_bf16": ["--workload", "flux1024", "--steps", "2", "--warmup", "1", "--roofline"],
     "flux1024_batch2_fp8": ["--workload", "flux1024", "--fp8", "--steps", "2", "--warmup", "1", "--roofline"],  # BASELINE config 5 names fp8 MFMA
+    # FLUX at the geometry its paper schedules were searched on (256 x 256: N = 256 + T = 512), the batch of that file's own latency record (18)
+    "flux256_batch18_bf16": ["--workload", "flux256", "--steps", "3", "--warmup", "1", "--roofline"],
     # BASELINE config 4, one rank's share: 9 of the 72 seed candidates x 100 prompts at batch 16 through the in-process evaluator (a new schedule every 7 batches)
     "ga_config4_shard": ["--workload", "ga_shard", "--steps", "1", "--warmup", "0"],
 }
@@ -482,7 +491,7 @@ def main():
     ap.add_argument("--secondary", default="all", help="comma-separated subset of: " + ", ".join(SECONDARY))
     ap.add_argument("--fp8", action="store_true", help="opt-in OCP e4m3 block GEMMs (north_star / BASELINE config 5 name fp8 MFMA); secondary: dtype then reads fp8, the headline stays f16 / bf16")
     ap.add_argument("--bf16", action="store_true", help="PixArt workloads in bf16 instead of the reference's fp16 (secondary line; `value` of the default run stays fp16)")
-    ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024", "flux1024", "ga_shard"],
+    ap.add_argument("--workload", default="alpha256", choices=["alpha256", "sigma1024", "flux1024", "flux256", "ga_shard"],
                     help="alpha256 = BASELINE metric config (default); sigma1024 / flux1024 = BASELINE configs 3 / 5 (secondary, not the headline)")
     ap.add_argument("--streams", type=int, default=None,
                     help="image batches in flight per GPU: S engine contexts (own cache arena, workspaces and hipGraph; same weights values), batch i runs on context i %% S and its "
@@ -522,7 +531,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
         log(f"process group: nccl (RCCL), world {dist.get_world_size()}" + (" [ECAD_FORCE_DIST]" if forced else ""))
 
-    if args.workload == "flux1024":
+    if args.workload in ("flux1024", "flux256"):
         return main_flux(args, world, rank, device, dist)
     if args.workload == "ga_shard":
         return main_ga_shard(args, world, rank, device, dist)

@@ -38,6 +38,10 @@ struct AttnArgs {
   float scale_log2e;  // (1/sqrt(dh)) * log2(e)
   int seg_t, seg_bt;  // 0, 0: plain [B, N] rows; else the joint [text | image] layout (same for q, k, v, out)
   int q_off, q_cnt;   // attention_dma.h: this launch covers query rows [q_off, q_off + q_cnt) of every (sample, head); q_cnt 0 = all Nq rows
+  // The two conventions of the Q columns of a qkv buffer (flux.hip): 0 = plain Q, the kernel multiplies the scores by scale_log2e; 1 = whoever produced Q (RoPE
+  // epilogue / kernel, FGemmArgs::q_scale) already multiplied it by scale * log2(e) and scale_log2e must be 1.  Launchers check the pairing: a debug dump, a parity
+  // hook on the post-RoPE q or a cached-Q path that reads the buffer has to know which one it holds.
+  int q_prescaled;
 };
 
 template <int DHC> struct AttCfg;

@@ -56,6 +56,21 @@ template <typename T> ECAD_DEV void float_to_elem4(Pack4& p, int i, float v);
 template <> ECAD_DEV void float_to_elem4<f16_t>(Pack4& p, int i, float v) { p.he[i] = (f16_t)v; }
 template <> ECAD_DEV void float_to_elem4<bf16_t>(Pack4& p, int i, float v) { p.be[i] = (bf16_t)v; }
 
+// two floats -> one register of two storage elements, as ONE v_cvt_pk_{f16,bf16}_f32 (round to nearest even, what the scalar conversions do): written as a vector
+// conversion because element-wise stores into a Pack4 came out as v_cvt + v_cvt (SDWA) + v_or per pair in the register-resident epilogues (FF1: 288 values per lane)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+template <typename T> ECAD_DEV unsigned pack2(float a, float b);
+template <> ECAD_DEV unsigned pack2<f16_t>(float a, float b) {
+  const f16x2_t h = __builtin_convertvector((f32x2_t){a, b}, f16x2_t);
+  return __builtin_bit_cast(unsigned, h);
+}
+template <> ECAD_DEV unsigned pack2<bf16_t>(float a, float b) {
+  const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+  return __builtin_bit_cast(unsigned, h);
+}
+
 template <typename T> ECAD_DEV void unpack8(const Pack8& p, float (&f)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) f[i] = elem_to_float<T>(p, i);

@@ -675,6 +675,7 @@ template <typename T> class FluxT : public FluxBase {
     a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.out = out; a.bias = nullptr; a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
     a.B = B; a.H = NH; a.Nq = a.Nk = Tt + N; a.dh = DH;
     a.scale_log2e = attn_w4 ? 1.0f : (float)(1.4426950408889634 / sqrt((double)DH));  // attn_w4: already in Q (q_fold)
+    a.q_prescaled = q_fold() != 0.f ? 1 : 0;  // the producers of this plan's Q (set_rope / the ROPE op) were given the same q_fold()
     a.seg_t = Tt; a.seg_bt = B * Tt;
     const double S = Tt + N;
     ao.flops = 4.0 * B * S * S * D;
@@ -974,6 +975,8 @@ template <typename T> class FluxT : public FluxBase {
     return bn == 256 ? launch_gemm_bn<256>(epi, g, s) : launch_gemm_bn<128>(epi, g, s);
   }
   int launch_attn(const AttnArgs& a, hipStream_t s) {
+    // one qkv buffer, two conventions (AttnArgs::q_prescaled): a pre-scaled Q goes with scale 1 and only with it (round-5 ADVICE)
+    if ((a.q_prescaled != 0) != (a.scale_log2e == 1.0f)) return fail(ECAD_E_INVALID, "attention launch: q_prescaled %d with score scale %g", a.q_prescaled, (double)a.scale_log2e);
     constexpr int lds = attn_lds_bytes<128, 128>();
     const int items = a.B * a.H * ((a.Nq + ATT_QB - 1) / ATT_QB);
     const int grid = items < num_cus ? items : num_cus;

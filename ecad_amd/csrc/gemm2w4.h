@@ -165,14 +165,15 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
       if constexpr (EPI == EPI_BIAS_GELU) {
         const f32x2 v01 = gelu_tanh2((f32x2){av[0] + bv[0], av[1] + bv[1]});
         const f32x2 v23 = gelu_tanh2((f32x2){av[2] + bv[2], av[3] + bv[3]});
-        float_to_elem4<T>(o, 0, v01[0]); float_to_elem4<T>(o, 1, v01[1]); float_to_elem4<T>(o, 2, v23[0]); float_to_elem4<T>(o, 3, v23[1]);
+        o.u[0] = pack2<T>(v01[0], v01[1]); o.u[1] = pack2<T>(v23[0], v23[1]);  // one v_cvt_pk per pair (same rounding as the scalar conversions)
       } else {
+        float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = av[r] + bv[r];
-          if (EPI == EPI_BIAS_SILU) v = silu(v);
-          float_to_elem4<T>(o, r, v);
+          v[r] = av[r] + bv[r];
+          if (EPI == EPI_BIAS_SILU) v[r] = silu(v[r]);
         }
+        o.u[0] = pack2<T>(v[0], v[1]); o.u[1] = pack2<T>(v[2], v[3]);
       }
       return o;
     };

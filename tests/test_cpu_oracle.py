@@ -286,3 +286,63 @@ def test_dpm_solver_solves_the_probability_flow_ode():
     # 8x the steps: a first-order method gains 8x, a second-order one 64x (measured: 4.6e-2 -> 3.0e-4, i.e. 156x; the integer timestep grid
     # and the first-order first / last steps make individual doublings uneven, so only the overall rate is asserted)
     assert e20 < 6e-2 and e160 < e20 / 30
+
+
+def test_oracle_attention_is_torch_scaled_dot_product_attention(tiny):
+    """The layer arithmetic of the reference lives in diffusers 0.30.3 (absent here: "restated, not verified against diffusers").  What can be pinned without it: the
+    one non-trivial primitive its `AttnProcessor2_0` calls is torch's own `F.scaled_dot_product_attention(q, k, v, attn_mask=<additive bias>, dropout_p=0,
+    is_causal=False)` on `[B, heads, tokens, head_dim]` views -- installed here.  The oracle spells the attention out (`softmax(q k^T / sqrt(d_h) + bias) v`); this
+    test holds that spelling to torch's SDPA on the same projections, for the self-attention (no mask) and for the cross-attention with the reference's
+    `(1 - mask) * -10000` bias broadcast over heads and queries (pixart_transformer_2d_edited.py:271-291), and the FLUX oracle's joint attention likewise."""
+    import torch.nn.functional as F
+
+    cfg, w = tiny
+    m = PixArtOracle(cfg, w)
+    g = torch.Generator().manual_seed(5)
+    B, N, T, D, H, dh = 2, 12, 7, cfg.dim, cfg.num_attention_heads, cfg.attention_head_dim
+    x = torch.randn(B, N, D, generator=g)
+    ctx = torch.randn(B, T, D, generator=g)
+    mask = torch.ones(B, T, dtype=torch.int64)
+    mask[1, 3:] = 0
+    bias = m._mask_to_bias(mask)  # [B, 1, T]: 0 keep / -10000 discard
+
+    def sdpa(prefix, x_q, x_kv, attn_bias):
+        heads = lambda t: t.view(B, -1, H, dh).transpose(1, 2)
+        q, k, v = (heads(F.linear(s, w[f"{prefix}.{n}.weight"].float(), w[f"{prefix}.{n}.bias"].float())) for n, s in (("to_q", x_q), ("to_k", x_kv), ("to_v", x_kv)))
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=None if attn_bias is None else attn_bias[:, None], dropout_p=0.0, is_causal=False)
+        o = o.transpose(1, 2).reshape(B, -1, H * dh)
+        return F.linear(o, w[prefix + ".to_out.0.weight"].float(), w[prefix + ".to_out.0.bias"].float())
+
+    p = "transformer_blocks.0"
+    assert torch.allclose(m.attention(p + ".attn1", x, x, None), sdpa(p + ".attn1", x, x, None), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(m.attention(p + ".attn2", x, ctx, bias), sdpa(p + ".attn2", x, ctx, bias), atol=2e-6, rtol=1e-5)
+    # a discarded key really is out: -10000 in front of the softmax leaves exp(-10000 + ...) == 0 in fp32
+    ctx2 = ctx.clone()
+    ctx2[1, 3:] += 5.0
+    assert torch.allclose(m.attention(p + ".attn2", x, ctx2, bias)[1], m.attention(p + ".attn2", x, ctx, bias)[1], atol=1e-6)
+
+    from oracle import flux_ref
+
+    fm = flux_ref.FluxOracle(flux_ref.FluxConfig(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=32, pooled_projection_dim=16),
+                             flux_ref.make_weights(flux_ref.FluxConfig(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=32, pooled_projection_dim=16), seed=2))
+    dhf = fm.cfg.attention_head_dim
+    qh, kh, vh = (torch.randn(2, 2, 9, dhf, generator=g) for _ in range(3))
+    want = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=0.0, is_causal=False).transpose(1, 2).reshape(2, 9, 2 * dhf)
+    assert torch.allclose(fm.sdpa(qh, kh, vh), want, atol=2e-6, rtol=1e-5)
+
+
+def test_oracle_feed_forward_and_layer_norm_are_torch_modules(tiny):
+    """Same idea for the other two layer kinds: `FeedForward(activation_fn="gelu-approximate")` of diffusers is Linear -> torch.nn.GELU(approximate="tanh") -> Linear,
+    and `norm1 / norm2` are torch.nn.LayerNorm(D, elementwise_affine=False, eps=1e-6): both torch modules, instantiated here with the oracle's weights."""
+    cfg, w = tiny
+    m = PixArtOracle(cfg, w)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 12, cfg.dim, generator=g)
+    p = "transformer_blocks.1.ff"
+    l1, l2 = torch.nn.Linear(cfg.dim, 4 * cfg.dim), torch.nn.Linear(4 * cfg.dim, cfg.dim)
+    with torch.no_grad():
+        l1.weight.copy_(w[p + ".net.0.proj.weight"]); l1.bias.copy_(w[p + ".net.0.proj.bias"]); l2.weight.copy_(w[p + ".net.2.weight"]); l2.bias.copy_(w[p + ".net.2.bias"])
+        want = l2(torch.nn.GELU(approximate="tanh")(l1(x)))
+        ln = torch.nn.LayerNorm(cfg.dim, elementwise_affine=False, eps=1e-6)
+        assert torch.allclose(m.feed_forward(p, x), want, atol=2e-6, rtol=1e-5)
+        assert torch.allclose(m.layer_norm(x), ln(x), atol=1e-6, rtol=1e-6)

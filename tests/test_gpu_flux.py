@@ -365,13 +365,16 @@ def test_forced_recompute_and_all_cached_steps_are_exact_replays():
 
 
 @pytest.mark.parametrize("fp8", [False, True])
-def test_flux_1024_full_size_properties(fp8):
+@pytest.mark.parametrize("geometry", ["1024", "256"])
+def test_flux_1024_full_size_properties(fp8, geometry):
     """BASELINE config 5 at its full size -- FLUX.1-dev geometry, 19 joint + 38 single blocks, 1024 x 1024 (N = 4096 + T = 512), batch 2, bf16 and the fp8
     block GEMMs the config names (e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4; final latents within 1.2e-1 of the bf16 engine's, measured 6.1e-2), the
     paper's schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json -- cannot be checked against the fp32 CPU oracle in seconds (the reduced-depth
     full-width test below covers the arithmetic), so the size-independent properties: determinism, hipGraph == eager bit for bit, sample 1 of the
     batch == that sample run alone (rows of a batch never see each other), and the engine's Linear MAC count == the closed form that reproduces the
-    reference's own `metrics.total_macs` of this file (batch 2 there too: 376.6 TMACs)."""
+    reference's own `metrics.total_macs` of this file (batch 2 there too: 376.6 TMACs).
+    geometry "256": the same at the geometry the paper's FLUX schedules were searched on -- schedules_in_paper/flux_256/ours_fast.json, 256 x 256 = 256 image + 512
+    text tokens (S = 768: three 256-row query blocks per sample in the joint attention), its `metrics.total_macs` 63.02 TMACs."""
     import json
     from pathlib import Path
 
@@ -380,8 +383,9 @@ def test_flux_1024_full_size_properties(fp8):
     from ecad_amd.transformer_2d_models.flux_transformer_2d_edited import FluxTransformer2DEdited, synthetic_state_dict
     from oracle.schedule_ref import flux_bits_from_schedule_json, flux_mac_model
 
-    path = Path(__file__).resolve().parents[1] / "schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json"
-    B, grid, T = 2, 64, 512
+    root = Path(__file__).resolve().parents[1]
+    path = root / ("schedules/schedules_in_paper/flux_256_to_1024/fast_256_to_1024.json" if geometry == "1024" else "schedules/schedules_in_paper/flux_256/ours_fast.json")
+    B, grid, T = 2, (64 if geometry == "1024" else 16), 512
     sched = FluxCacheSchedule.from_json(path)
     model = FluxTransformer2DEdited(guidance_embeds=True, max_batch=B, max_image_tokens=grid * grid, max_text_tokens=T, torch_dtype=torch.bfloat16, device=0)
     eng = model.engine
@@ -413,7 +417,7 @@ def test_flux_1024_full_size_properties(fp8):
     assert 2 * st["linear_macs_reference"] == want == json.loads(path.read_text())["metrics"]["total_macs"]  # the engine's figure is per sample
     one = run(slice(1, 2), False)
     assert torch.equal(one, a[1:2])
-    key = "_flux_1024_bf16_latents"
+    key = f"_flux_{geometry}_bf16_latents"
     if not fp8:
         globals()[key] = a.float().cpu()  # the fp8 case (collected right after this one) is held to these
     elif key in globals():

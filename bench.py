@@ -428,7 +428,8 @@ SECONDARY = {
     "alpha256_batch1_latency_no_split_k": ["ENV:ECAD_SPLIT_K=0", "--batch", "1", "--steps", "20", "--warmup", "3", "--streams", "1"],
     "alpha256_batch4_x4_contexts": ["--batch", "4", "--streams", "4", "--steps", "24", "--warmup", "2"],  # small-batch serving: four batches of 4 in flight
     "alpha256_batch100_paper_latency_config": ["--batch", "100", "--steps", "3", "--warmup", "1"],
-    "alpha256_fp8_block_gemms": ["--fp8", "--steps", "5", "--warmup", "1"],
+    # three batches in flight like the headline (round 6: execution contexts multiply the donor's e4m3 weight copies), so that the two lines compare like for like
+    "alpha256_fp8_block_gemms": ["--fp8", "--streams", "3", "--steps", "9", "--warmup", "1"],
     # the same kernels with bf16 storage / MFMAs (north_star names bf16): fewer mantissa bits toggle in the multipliers, and the power-limited K loops run at a higher clock
     "alpha256_bf16": ["--bf16", "--streams", "3", "--steps", "9", "--warmup", "1"],
     "sigma1024_batch4": ["--workload", "sigma1024", "--steps", "4", "--warmup", "1", "--streams", "2", "--roofline"],  # two batches in flight: +1.7 % (9.13 -> 9.29 same box; three: +0.6 %)

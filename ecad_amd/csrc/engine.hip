@@ -151,7 +151,10 @@ template <typename T> class EngineT : public EngineBase {
   // Shared by an owner and its borrowers (share_weights).  refs / gen / finalized are plain fields: ecad_create / ecad_share_weights / ecad_load_weights /
   // ecad_finalize_weights / ecad_destroy of engines that share an arena must be serialized by the caller (include/ecad_hip.h says so at ecad_share_weights);
   // the per-batch calls only read them.
-  struct SharedArena { char* base; int refs; uint64_t gen; bool finalized; };
+  struct W8 { uint8_t* w; float* s; };
+  // (fp8 / w8 / w8allocs: the e4m3 weight copies of the owner's fp8 mode, keyed by the 16-bit weight they mirror; they live and die with the arena, so that the
+  // contexts that borrow it multiply the same copies and outlive the engine that made them, as they outlive it for the 16-bit weights)
+  struct SharedArena { char* base; int refs; uint64_t gen; bool finalized; bool fp8; std::map<const void*, W8> w8; std::vector<void*> w8allocs; };
   SharedArena* sarena = nullptr;
   uint64_t seen_gen = 0;
   struct Dest { void* ptr; bool f32; int64_t rows, cols, ld; bool loaded; };
@@ -176,9 +179,7 @@ template <typename T> class EngineT : public EngineBase {
   int pos_grid = 0;
   // ---- opt-in fp8 (e4m3) block GEMMs: gemm3s8.h; env ECAD_FP8=1 or ecad_set_fp8
   bool fp8 = false;
-  struct W8 { uint8_t* w; float* s; };
-  std::map<const void*, W8> w8map;
-  std::vector<void*> w8allocs;
+  std::map<const void*, W8> w8map;  // this engine's view of sarena->w8
   uint8_t* a8 = nullptr;  // [M][4D] activation rows quantised in front of each fp8 GEMM
   float* sa8 = nullptr;
   const void* a8_src = nullptr;  // plan construction: which tensor a8 currently holds (Q and K/V launches share one pass)
@@ -304,11 +305,10 @@ template <typename T> class EngineT : public EngineBase {
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (sarena) {
-      if (--sarena->refs == 0) { (void)hipFree(sarena->base); delete sarena; }
+      if (--sarena->refs == 0) { (void)hipFree(sarena->base); for (void* q : sarena->w8allocs) (void)hipFree(q); delete sarena; }
     } else if (warena) (void)hipFree(warena);
     if (pos) (void)hipFree(pos);
     if (ws) (void)hipFree(ws);
-    for (void* q : w8allocs) (void)hipFree(q);
     if (a8) (void)hipFree(a8);
     if (sa8) (void)hipFree(sa8);
     if (desc_dev) (void)hipFree(desc_dev);
@@ -368,7 +368,7 @@ template <typename T> class EngineT : public EngineBase {
     warena_bytes = (per_blk_T * L + glob_T) * sizeof(T) + (per_blk_f * L + glob_f) * sizeof(float) + (size_t)(L * 16 + 64) * 256;
     HIPCHK(hipMalloc((void**)&warena, warena_bytes));
     HIPCHK(hipMemset(warena, 0, warena_bytes));
-    sarena = new SharedArena{warena, 1, 0, false};
+    sarena = new SharedArena{warena, 1, 0, false, false, {}, {}};
     blk.resize(L);
     w_kv2_all = walloc<T>((size_t)L * 2 * d * d);
     b_kv2_all = walloc<float>((size_t)L * 2 * d);
@@ -542,9 +542,10 @@ template <typename T> class EngineT : public EngineBase {
     for (auto& kv : dests)
       if (!kv.second.loaded) return fail(ECAD_E_NOT_READY, "weight '%s' was never loaded", kv.first.c_str());
     finalized = true;
-    sarena->finalized = true; seen_gen = ++sarena->gen;
     drop_all_plans();
-    if (fp8) return build_fp8_weights();
+    sarena->fp8 = false;
+    if (fp8) { int rc = build_fp8_weights(); if (rc) return rc; }  // (publishes the copies in the arena)
+    sarena->finalized = true; seen_gen = ++sarena->gen;
     return ECAD_OK;
   }
   // a context that borrows its weights: has the owner changed them since this context last lowered its plans?
@@ -559,6 +560,9 @@ template <typename T> class EngineT : public EngineBase {
       batch_begun = false;
       std::fill(valid_rt.begin(), valid_rt.end(), 0);  // cache slots computed with the donor's previous weights are not usable (a keep_caches rebind must not keep them)
       seen_gen = sarena->gen;
+      fp8 = sarena->fp8;  // the owner's mode and its (re-made) e4m3 copies
+      w8map.clear();
+      if (fp8) { w8map = sarena->w8; int rc = fp8_workspaces(); if (rc) return rc; }
     }
     return ECAD_OK;
   }
@@ -571,7 +575,7 @@ template <typename T> class EngineT : public EngineBase {
     if (src->dev != dev || src->L != L || src->D != D || src->CAP != CAP || src->CIN != CIN || src->COUT != COUT || src->P != P ||
         src->cfg.use_additional_conditions != cfg.use_additional_conditions || src->warena_bytes != warena_bytes || src->warena_used != warena_used)
       return fail(ECAD_E_INVALID, "share_weights: the two engines were created with different model configurations (or on different devices)");
-    if (fp8 || src->fp8) return fail(ECAD_E_UNSUPPORTED, "share_weights: fp8 weight copies are per engine; load the weights into each context instead");
+    if (fp8 && !src->fp8) return fail(ECAD_E_UNSUPPORTED, "share_weights: this engine is in fp8 mode and the donor is not; the e4m3 weight copies are the donor's");
     if (weights_shared) return fail(ECAD_E_INVALID, "share_weights: this engine already borrows its weights");
     HIPCHK(hipSetDevice(dev));
     drop_all_plans();
@@ -583,6 +587,7 @@ template <typename T> class EngineT : public EngineBase {
     for (int k = 0; k < 2; ++k) { rb(w_sz1[k]); rb(w_sz2[k]); rb(b_sz1[k]); rb(b_sz2[k]); }
     for (auto& kv : dests) { kv.second.ptr = reinterpret_cast<char*>(kv.second.ptr) + delta; kv.second.loaded = true; }
     (void)hipFree(warena);
+    for (void* q : sarena->w8allocs) (void)hipFree(q);  // e4m3 copies this engine made of its own weights before it became a context
     delete sarena;
     warena = src->warena;
     sarena = src->sarena;
@@ -590,6 +595,13 @@ template <typename T> class EngineT : public EngineBase {
     seen_gen = sarena->gen;
     weights_shared = true;
     finalized = true;
+    // fp8 mode travels with the weights: the context multiplies the donor's e4m3 copies (the keys of its map are the 16-bit weight pointers, now this engine's too)
+    w8map.clear();
+    fp8 = sarena->fp8;
+    if (fp8) {
+      w8map = sarena->w8;
+      return fp8_workspaces();
+    }
     return ECAD_OK;
   }
   // LayerNorm fold on / off at run time: a caller that runs every schedule for ONE batch (the NSGA-II evaluation) cannot amortise the
@@ -678,15 +690,16 @@ template <typename T> class EngineT : public EngineBase {
     W8 e{};
     HIPCHK(hipMalloc((void**)&e.w, rows * K));
     HIPCHK(hipMalloc((void**)&e.s, rows * sizeof(float)));
-    w8allocs.push_back(e.w); w8allocs.push_back(e.s);
-    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, 0, w, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, e.w, (int64_t)K, e.s, (int)rows);
+    sarena->w8allocs.push_back(e.w); sarena->w8allocs.push_back(e.s);
+    launch_quant_rows_fp8<T>(w, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, e.w, (int64_t)K, e.s, (int)rows, (hipStream_t)0);
     w8map[w] = e;
     return ECAD_OK;
   }
   int build_fp8_weights() {
     if (D % 128) return fail(ECAD_E_UNSUPPORTED, "fp8 mode needs D %% 128 == 0");
-    for (void* q : w8allocs) (void)hipFree(q);
-    w8allocs.clear(); w8map.clear();
+    if (!sarena->w8allocs.empty()) (void)hipDeviceSynchronize();  // a borrower's graph may still multiply the copies that are about to go
+    for (void* q : sarena->w8allocs) (void)hipFree(q);
+    sarena->w8allocs.clear(); sarena->w8.clear(); w8map.clear();
     const size_t d = D;
     int rc;
     for (auto& b : blk) {
@@ -697,6 +710,12 @@ template <typename T> class EngineT : public EngineBase {
       w8map[b.w_qkv + d * d] = W8{e.w + d * d, e.s + d};  // the K,V rows of the fused weight (split QKV launch)
     }
     HIPCHK(hipDeviceSynchronize());
+    sarena->w8 = w8map; sarena->fp8 = true;  // contexts that borrow this arena run their fp8 GEMMs on these copies (share_weights / weights_current)
+    return fp8_workspaces();
+  }
+  // a8 / sa8 (the quantised A rows of the GEMM in flight) and the kernel attributes: per engine, also for a context that borrows the e4m3 weight copies
+  int fp8_workspaces() {
+    const size_t d = D;
     if (!a8) {
       const size_t Mmax = (size_t)cfg.max_batch * cfg.max_tokens;
       HIPCHK(hipMalloc((void**)&a8, Mmax * 4 * d));
@@ -1619,8 +1638,8 @@ template <typename T> class EngineT : public EngineBase {
     switch (o.kind) {
       case Op<T>::GEMM: return launch_gemm(o.epi, o.cls, o.g, s);
       case Op<T>::QUANT:
-        hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((o.g.M + 3) / 4), dim3(256), 0, s, (const T*)o.p0, (int64_t)o.i0, o.g.K, (const T*)nullptr, (int64_t)0, 0, a8, (int64_t)o.g.K,
-                           sa8, o.g.M);
+        launch_quant_rows_fp8<T>((const T*)o.p0, (int64_t)o.i0, o.g.K, (const T*)nullptr, (int64_t)0, 0, a8, (int64_t)o.g.K,
+                           sa8, o.g.M, s);
         break;
       case Op<T>::GEMM8: {
         Gemm8Args<T> q{};

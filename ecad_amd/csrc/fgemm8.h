@@ -52,7 +52,10 @@ ECAD_DEV uint32_t pack_fp8x4(float a, float b, float c, float d) {
 // dst8[r][:] = e4m3(cat(src1[r], src2[r]) / s), s = max|row| / 448 (1 for an all-zero row); one wave per row, 16-byte loads.
 // Weights at load; activations right before each fp8 GEMM (src2: the single-stream proj_out reads [attn | gelu(mlp)] from two cache
 // slots -- the concatenation materialises only in fp8, inside this pass).  K1, K2 multiples of 8.
-template <typename TS>
+// NR = 16-byte chunks a lane keeps between the maximum and the conversion (rows of up to 512 NR elements): the buffer is what bounds the waves per SIMD, and with
+// them the bytes in flight of a pass that is nothing but latency -- launch_quant_rows_fp8 picks the smallest instantiation that holds the row (round 6: the
+// 1152- and 4608-wide rows of the PixArt path ran on the 32-chunk buffer sized for FLUX's 15360, three waves per SIMD).  Same arithmetic for every NR.
+template <typename TS, int NR_ = 32>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const TS* __restrict__ src1, int64_t ld1, int K1, const TS* __restrict__ src2, int64_t ld2, int K2,
                                                             uint8_t* __restrict__ dst, int64_t ldd, float* __restrict__ scale, int rows) {
   const int lane = threadIdx.x & 63;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const TS* __restric
   // Rows of up to 16384 elements (every row of both models: K <= 5 D = 15360) stay in the wave's registers between the maximum and the conversion -- 32 chunks of
   // 16 bytes per lane -- so the row is read once.  The two-pass form below re-read it "from L2", but with every CU holding 32 rows of 30 KB in flight the second
   // pass came from the Infinity Cache / HBM: 5 bytes of traffic per element instead of 3 (round 5: fp8_quant_rows 48 -> 33 ms per FLUX batch).
-  constexpr int NR = 32;
+  constexpr int NR = NR_;
   if (ctot <= 64 * NR) {
     Pack8 buf[NR];
 #pragma unroll
@@ -119,6 +122,17 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const TS* __restric
     unpack8<TS>(gload16(c < c1 ? s1 + c * 8 : s2 + (c - c1) * 8), v);
     d[c] = (u32x2){pack_fp8x4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv), pack_fp8x4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv)};
   }
+}
+
+template <typename TS>
+inline void launch_quant_rows_fp8(const TS* src1, int64_t ld1, int K1, const TS* src2, int64_t ld2, int K2, uint8_t* dst, int64_t ldd, float* scale, int rows, hipStream_t s) {
+  const int per_lane = (((K1 + K2) >> 3) + 63) / 64;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (per_lane <= 3) hipLaunchKernelGGL((quant_rows_fp8_kernel<TS, 3>), grid, block, 0, s, src1, ld1, K1, src2, ld2, K2, dst, ldd, scale, rows);
+  else if (per_lane <= 6) hipLaunchKernelGGL((quant_rows_fp8_kernel<TS, 6>), grid, block, 0, s, src1, ld1, K1, src2, ld2, K2, dst, ldd, scale, rows);
+  else if (per_lane <= 9) hipLaunchKernelGGL((quant_rows_fp8_kernel<TS, 9>), grid, block, 0, s, src1, ld1, K1, src2, ld2, K2, dst, ldd, scale, rows);
+  else if (per_lane <= 16) hipLaunchKernelGGL((quant_rows_fp8_kernel<TS, 16>), grid, block, 0, s, src1, ld1, K1, src2, ld2, K2, dst, ldd, scale, rows);
+  else hipLaunchKernelGGL((quant_rows_fp8_kernel<TS, 32>), grid, block, 0, s, src1, ld1, K1, src2, ld2, K2, dst, ldd, scale, rows);
 }
 
 template <typename T, int BN, int EPI>

@@ -461,7 +461,7 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipMalloc((void**)&e.w, rows * K));
     FHIPCHK(hipMalloc((void**)&e.s, rows * sizeof(float)));
     w8allocs.push_back(e.w); w8allocs.push_back(e.s);
-    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, 0, w, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, e.w, (int64_t)K, e.s, (int)rows);
+    launch_quant_rows_fp8<T>(w, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, e.w, (int64_t)K, e.s, (int)rows, (hipStream_t)0);
     w8map[w] = e;
     return ECAD_OK;
   }
@@ -1068,8 +1068,8 @@ template <typename T> class FluxT : public FluxBase {
       case FOp<T>::FORK:
       case FOp<T>::JOIN: break;
       case FOp<T>::QUANT:
-        hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((o.g.M + 3) / 4), dim3(256), 0, s, (const T*)o.p0, (int64_t)o.i0, o.i1, (const T*)o.p1, (int64_t)o.i2, (int)o.n,
-                           o.lane ? a8_side : a8, (int64_t)o.g.K, o.lane ? sa8_side : sa8, o.g.M);
+        launch_quant_rows_fp8<T>((const T*)o.p0, (int64_t)o.i0, o.i1, (const T*)o.p1, (int64_t)o.i2, (int)o.n,
+                           o.lane ? a8_side : a8, (int64_t)o.g.K, o.lane ? sa8_side : sa8, o.g.M, s);
         break;
       case FOp<T>::GEMM8: {
         FGemm8Args<T> q{};
@@ -1298,8 +1298,8 @@ template <typename T> class FluxT : public FluxBase {
     FHIPCHK(hipMalloc((void**)&w8, (size_t)Nn * K));
     FHIPCHK(hipMalloc((void**)&sa, (size_t)M * sizeof(float)));
     FHIPCHK(hipMalloc((void**)&sw, (size_t)Nn * sizeof(float)));
-    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)A, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, a8, (int64_t)K, sa, M);
-    hipLaunchKernelGGL((quant_rows_fp8_kernel<T>), dim3((Nn + 3) / 4), dim3(256), 0, s, (const T*)W, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, w8, (int64_t)K, sw, Nn);
+    launch_quant_rows_fp8<T>((const T*)A, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, a8, (int64_t)K, sa, M, s);
+    launch_quant_rows_fp8<T>((const T*)W, (int64_t)K, K, (const T*)nullptr, (int64_t)0, 0, w8, (int64_t)K, sw, Nn, s);
     FGemm8Args<T> q{};
     q.A8 = a8; q.W8 = w8; q.sa = sa; q.sw = sw; q.lda8 = K;
     q.e.bias = bias; q.e.C = (T*)out; q.e.M = M; q.e.N = Nn; q.e.K = K; q.e.ldc = Nn; q.e.k_split = K;

@@ -127,9 +127,8 @@ class EcadEngine:
         """A further execution context on the same GPU: same configuration, the SAME weights (``ecad_share_weights``: no copy, this engine must outlive
         it), the same schedule; its own workspaces, cache arena, plans and hipGraph.  Batches submitted to different contexts on different streams overlap
         on the device (``EngineContexts``)."""
-        if self.fp8:
-            raise ValueError("fp8 weight copies are per engine: create the second engine and load the weights into it")
-        ctx = EcadEngine(**self._ctor)
+        ctx = EcadEngine(**{**self._ctor, "fp8": None})  # fp8 mode travels with the weights: a context multiplies the donor's e4m3 copies (ecad_share_weights)
+        ctx.fp8 = self.fp8
         ctx._chk(self.lib.ecad_share_weights(ctx._h, self._h))
         ctx._donor = self  # (the weight arena itself is owned jointly on the C side: closing this engine first leaves the context usable)
         if self._bits is not None:

@@ -107,7 +107,8 @@ int ecad_finalize_weights(EcadEngine* e);
  * submitted to different contexts on different HIP streams overlap on the device (one batch's kernel boundaries and HBM-bound kernels hide behind the other's
  * GEMMs), which is how a caller keeps several batches in flight -- the reference has one pipeline object per process and runs batches back to back
  * (image_generator.py:161-186, `generate_from_saved_prompts`).  The donor must outlive `e`.  ECAD_E_INVALID for mismatched configurations,
- * ECAD_E_UNSUPPORTED in fp8 mode (the e4m3 weight copies are per engine).  Thread safety: the per-batch calls of different contexts may run on different host
+ * fp8 mode travels with the weights (ABI 6): a donor whose weights were finalized in fp8 mode hands its e4m3 copies on as well (they live with the arena), and
+ * ecad_set_fp8 stays refused on the context itself (ECAD_E_UNSUPPORTED).  Thread safety: the per-batch calls of different contexts may run on different host
  * threads; ecad_create / ecad_share_weights / ecad_load_weights / ecad_finalize_weights / ecad_destroy of engines that share an arena must be serialized by the
  * caller (the arena's reference count and weight generation are plain fields). */
 int ecad_share_weights(EcadEngine* e, EcadEngine* donor);

@@ -59,6 +59,9 @@ def classify_flux(name: str, tiles: int) -> str | None:
 
 
 def classify(name: str) -> str | None:
+    m4 = re.search(r"gemm3s4_kernel.*?Li(\d+)E", name) or re.search(r"gemm3s4_kernel<[^,]+, *(\d+)>", name)  # gemm3s4.h: <T, TAG>
+    if m4:
+        return GEMM_TAGS.get(int(m4.group(1)))
     m = re.search(r"(gemm2w4|gemm2w|gemm3s|pgemm)_kernel.*?Li(\d+)ELi(\d+)E", name) or re.search(r"(gemm2w4|gemm2w|gemm3s|pgemm)_kernel<[^,]+, *(\d+), *(\d+)>", name)
     if m:
         return GEMM_TAGS.get(int(m.group(3)))

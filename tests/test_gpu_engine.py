@@ -729,6 +729,49 @@ def test_read_modify_write_launches_on_the_four_wave_narrow_tile_change_nothing(
     assert g3_3 == 0 and n4_3 == g3_0                     # 3: all of them
 
 
+def test_fp8_mode_travels_with_shared_weights():
+    """Execution contexts of an engine in fp8 mode (round 6): ecad_share_weights hands the donor's e4m3 weight copies on with the 16-bit arena (they live and die with
+    it), so several fp8 batches can be in flight -- round 5 refused.  Every batch == the same batch on the donor alone, bit for bit; the context outlives the donor;
+    ecad_set_fp8 on a context stays refused."""
+    from ecad_amd.engine import EcadEngine, EngineContexts
+
+    layers, steps, B = 3, 5, 2
+    bits = rand_bits(steps, layers, 0.5, seed=19)
+    cfg = PixArtConfig(num_layers=layers)
+    w = make_weights(cfg, seed=0)
+    eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16, fp8=True)
+    eng.load_state_dict(w)
+    eng.set_schedule(bits)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    batches = []
+    for k in range(4):
+        inp = synthetic_inputs(B, start_seed=300 + k)
+        enc = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]], 0).cuda()
+        mask = torch.cat([inp["negative_prompt_attention_mask"], inp["prompt_attention_mask"]], 0).cuda()
+        batches.append((enc, mask, inp["latents"].cuda()))
+    alone = [eng.run_schedule(e, m, x, solver.timesteps, coefs, 4.5).clone() for e, m, x in batches]
+    pool = EngineContexts(eng, 2)
+    outs = [pool.submit(e, m, x, solver.timesteps, coefs, 4.5)[0] for e, m, x in batches]
+    pool.wait()
+    for a, b in zip(alone, outs):
+        assert torch.equal(a, b)
+    ctx = pool.engines[1]
+    with pytest.raises(ValueError, match="borrows"):
+        ctx._chk(ctx.lib.ecad_set_fp8(ctx._h, 1))
+    # the fp8 GEMMs really ran in the context: the same batch on a 16-bit engine differs by the fp8 quantisation, not by nothing
+    ref16, _, _ = make_pair(layers, bits, max_batch=2 * B)
+    plain = ref16.run_schedule(*batches[0], solver.timesteps, coefs, 4.5)
+    d = rel_l2(outs[0], plain)
+    print(f"fp8 context against the fp16 engine: {d:.3e}")
+    assert 1e-4 < d < 2e-2
+    pool.wait()
+    eng.close()  # the donor goes first: the arena (and the e4m3 copies in it) stays with the context
+    again = ctx.run_schedule(*batches[1], solver.timesteps, coefs, 4.5)
+    assert torch.equal(again, alone[1])
+    ctx.close()
+
+
 def test_adaptive_pool_needs_several_lonely_turns_before_it_plans_for_one_batch():
     """EngineContexts(adaptive=True) (round-5 ADVICE): the downgrade to "this batch runs alone" is opt-in, takes `idle_turns` consecutive submissions that found
     every peer idle (never the first turn of a pool), and is undone by the first busy peer; by default a pool keeps what it was built for -- one plan set and one

@@ -183,6 +183,12 @@ template <typename T> class EngineT : public EngineBase {
   uint8_t* a8 = nullptr;  // [M][4D] activation rows quantised in front of each fp8 GEMM
   float* sa8 = nullptr;
   const void* a8_src = nullptr;  // plan construction: which tensor a8 currently holds (Q and K/V launches share one pass)
+  // FF1 -> FF2 without the row quantiser (round 6, gemm3s8.h): FF1's epilogue leaves gelu(.) as e4m3 rows + one E8M0 byte per (row, 288-column tile) in a8b / e8buf,
+  // FF2's MFMAs take the bytes as block scales.  env ECAD_FP8_SEG=0: the 16-bit ffmid + the row quantiser, as in round 5.
+  bool fp8_seg = true;
+  uint8_t* a8b = nullptr;    // [M][4D] e4m3
+  uint8_t* e8buf = nullptr;  // [M][16]
+  const void* a8b_src = nullptr;  // plan construction: the tensor a8b / e8buf mirror (ffmid right after an emitting FF1)
   bool f8_attr = false;
   // ---- workspaces
   char* ws = nullptr;
@@ -310,6 +316,8 @@ template <typename T> class EngineT : public EngineBase {
     if (pos) (void)hipFree(pos);
     if (ws) (void)hipFree(ws);
     if (a8) (void)hipFree(a8);
+    if (a8b) (void)hipFree(a8b);
+    if (e8buf) (void)hipFree(e8buf);
     if (sa8) (void)hipFree(sa8);
     if (desc_dev) (void)hipFree(desc_dev);
   }
@@ -355,6 +363,7 @@ template <typename T> class EngineT : public EngineBase {
     if (const char* l = getenv("ECAD_GEMM4")) gemm4_wide = atoi(l) != 0;
     if (const char* l = getenv("ECAD_WIDE_RMW")) wide_rmw = atoi(l) != 0;
     if (const char* l = getenv("ECAD_GEMM3S4")) narrow4 = atoi(l) < 0 ? 0 : atoi(l);
+    if (const char* l = getenv("ECAD_FP8_SEG")) fp8_seg = atoi(l) != 0;
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, dev)); num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
 
     // ---- weight arena
@@ -720,6 +729,8 @@ template <typename T> class EngineT : public EngineBase {
       const size_t Mmax = (size_t)cfg.max_batch * cfg.max_tokens;
       HIPCHK(hipMalloc((void**)&a8, Mmax * 4 * d));
       HIPCHK(hipMalloc((void**)&sa8, Mmax * sizeof(float)));
+      HIPCHK(hipMalloc((void**)&a8b, Mmax * 4 * d));
+      HIPCHK(hipMalloc((void**)&e8buf, Mmax * 16));
     }
     if (!f8_attr) {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
@@ -727,6 +738,8 @@ template <typename T> class EngineT : public EngineBase {
       HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS_CACHE_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
       HIPCHK(hipFuncSetAttribute((const void*)gemm2w8_kernel<T, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
       HIPCHK(hipFuncSetAttribute((const void*)gemm2w8_kernel<T, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm2w8_kernel<T, EPI_BIAS_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3s8_kernel<T, EPI_BIAS_CACHE_RESID, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES + G3S8_TAB_BYTES));
       f8_attr = true;
     }
     st.weight_bytes = (int64_t)warena_used + (int64_t)blk.size() * 14 * (int64_t)d * d;
@@ -738,15 +751,27 @@ template <typename T> class EngineT : public EngineBase {
     if (it == w8map.end() || o.g.K % GEMM8_BK || o.g.N % G3_BN || (o.epi != EPI_BIAS && o.epi != EPI_BIAS_GELU && o.epi != EPI_BIAS_CACHE_RESID)) {
       ops.push_back(o);
       a8_src = nullptr;  // a bf16 GEMM may have rewritten the tensor a8 mirrors (e.g. the residual stream)
+      a8b_src = nullptr;
       return;
     }
-    if (!(share_prev && a8_src == o.g.A)) {  // share_prev: the previous push quantised the same, untouched tensor (Q then K,V of one LN output)
+    // FF2 right behind an FF1 that left its output as e4m3 + per-tile block scales (below): no quantiser pass, the MFMAs take the scale bytes
+    const bool block_scaled = a8b_src && a8b_src == o.g.A && o.cls == KC_GEMM_FF2 && o.epi == EPI_BIAS_CACHE_RESID && o.g.lda == o.g.K;
+    if (!block_scaled && !(share_prev && a8_src == o.g.A)) {  // share_prev: the previous push quantised the same, untouched tensor (Q then K,V of one LN output)
       Op<T> qo;
       qo.kind = Op<T>::QUANT; qo.cls = KC_QUANT; qo.p0 = o.g.A; qo.i0 = o.g.lda; qo.g.M = o.g.M; qo.g.K = o.g.K;
       qo.bytes = (double)o.g.M * o.g.K * (2 * sizeof(T) + 1);
       ops.push_back(qo);
     }
-    a8_src = o.epi == EPI_BIAS_CACHE_RESID ? nullptr : o.g.A;  // the residual epilogue rewrites h, which a8 may mirror
+    if (!block_scaled) a8_src = o.epi == EPI_BIAS_CACHE_RESID ? nullptr : o.g.A;  // the residual epilogue rewrites h, which a8 may mirror
+    a8b_src = nullptr;
+    o.i0 = o.i1 = 0;
+    if (block_scaled) o.i1 = 1;
+    // FF1 + GELU on whole rounds of 256 x 288 tiles (what launch_op gives gemm2w8_kernel): its only reader is FF2 -- emit e4m3 + one E8M0 byte per (row, tile)
+    if (fp8_seg && o.cls == KC_GEMM_FF1 && o.epi == EPI_BIAS_GELU && o.g.C == ffmid && o.g.ldc == o.g.N && o.g.M % G2_BM == 0 && o.g.N % G2_BN == 0 && o.g.N / G2_BN == 16 &&
+        (o.g.M / G2_BM) * (o.g.N / G2_BN) >= num_cus) {
+      o.i0 = 1;
+      a8b_src = o.g.C;
+    }
     o.kind = Op<T>::GEMM8;
     o.w8 = it->second.w; o.sw8 = it->second.s;
     o.bytes = ((double)o.g.M * o.g.K + (double)o.g.N * o.g.K) + (double)o.g.M * o.g.N * sizeof(T);
@@ -1644,6 +1669,16 @@ template <typename T> class EngineT : public EngineBase {
       case Op<T>::GEMM8: {
         Gemm8Args<T> q{};
         q.A8 = a8; q.W8 = o.w8; q.sa = sa8; q.sw = o.sw8; q.lda8 = o.g.K; q.e = o.g;
+        if (o.i0) {  // FF1 emitting e4m3 + block scales for FF2 (push_gemm checked the shape: whole rounds of wide tiles)
+          q.q8_out = a8b; q.e8_out = e8buf; q.ldq8 = o.g.N;
+          hipLaunchKernelGGL((gemm2w8_kernel<T, EPI_BIAS_GELU, true>), dim3((o.g.M / G2_BM) * (o.g.N / G2_BN)), dim3(G2_NW * 64), G2_LDS_BYTES, s, q);
+          break;
+        }
+        if (o.i1) {  // FF2 reading them
+          q.A8 = a8b; q.e8_in = e8buf; q.e8_ld = o.g.K / G2_BN;
+          hipLaunchKernelGGL((gemm3s8_kernel<T, EPI_BIAS_CACHE_RESID, true>), dim3(((o.g.M + G3_BM - 1) / G3_BM) * (o.g.N / G3_BN)), dim3(G3_NW * 64), G3_LDS_BYTES + G3S8_TAB_BYTES, s, q);
+          break;
+        }
         if (o.epi != EPI_BIAS_CACHE_RESID && o.g.N % G2_BN == 0 && ((o.g.M + G2_BM - 1) / G2_BM) * (o.g.N / G2_BN) >= num_cus) {  // 256 x 288 tiles, 4 x 2 waves
           const int tiles2 = ((o.g.M + G2_BM - 1) / G2_BM) * (o.g.N / G2_BN);
           if (o.epi == EPI_BIAS) hipLaunchKernelGGL((gemm2w8_kernel<T, EPI_BIAS>), dim3(tiles2), dim3(G2_NW * 64), G2_LDS_BYTES, s, q);

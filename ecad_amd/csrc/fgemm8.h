@@ -8,11 +8,12 @@
 // (v_mfma_scale_f32_16x16x128_f8f6f4, 32 fp8 per lane per operand); it is issued with every block scale = 2^0 and the two fp32
 // scales are applied to the accumulators before the shared epilogue, so no E8M0 scale tensors exist and the operand / scale lane
 // maps of the instruction beyond "lane l owns row (col) l & 15 and K-group l >> 4" never matter (A and B use the same K order).
-// Probed on the hardware (scripts/probe_mfma_scale.hip): the scale operands ARE per lane -- the selected byte (opsel) of lane l's scale
-// VGPR, an E8M0 exponent, multiplies that lane's own 32 elements (row / column l & 15, K-block l >> 4), for both operands.  So a
-// producer that only sees 128 columns of a row (attention per head, a GEMM epilogue per 128-column group) could emit e4m3 + one
-// power-of-two scale byte per (row, K-step) and the consumer would need no row-wide maximum; that fusion would remove the row
-// quantiser passes in front of attn-out / FF2 / proj_out (49 ms of a 712 ms FLUX-1024 batch) and is the next step for this mode.
+// Probed on the hardware (scripts/probe_mfma_scale.hip, probe_mfma_scale2.hip): the scale operands ARE per lane -- the selected byte (opsel) of lane l's scale
+// VGPR, an E8M0 exponent -- but the 32 elements it multiplies are the instruction's LOGICAL K-block (l >> 4) of row / column l & 15, and the hardware counts K
+// as (register half, lane group): a lane's low 16 bytes are K-chunk g, its high 16 bytes K-chunk 4 + g.  (Round 5 read the first probe as "the lane's own 32
+// elements"; with ones everywhere it could not tell.)  A kernel that uses block scales therefore loads pieces g and 4 + g of the 128-byte K-step per lane group,
+// not 2g and 2g + 1 -- gemm3s8_kernel<.., BS> does, for the FF1 -> FF2 hand-over of the PixArt path (round 6: e4m3 + one E8M0 byte per (row, 288-column tile)
+// from FF1's epilogue, no row quantiser in between).  The same fusion in front of FLUX's FF2 / proj_out is the next step for this mode.
 // Same 256 x BN tile, wave layout, LDS image (128-byte rows = 128 fp8, 16-byte chunks XOR-swizzled by (row >> 1) & 7), LDS-DMA ring
 // and epilogue as fgemm.h; a K-step is 128 elements, so a step moves the same bytes as a bf16 step but carries twice the flops.
 #pragma once

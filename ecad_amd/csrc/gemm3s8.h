@@ -21,9 +21,29 @@ template <typename T> struct Gemm8Args {
   const float* sw;    // [N]
   int lda8;
   GemmArgs<T> e;      // M, N, K, bias, C, resid, gate fields ... (A / W / lda / ldw unused)
+  // Round 6: the FF1 -> FF2 hand-over without the row quantiser.  The producer (gemm2w8_kernel<.., EMIT = true>) leaves its epilogue's output as e4m3 rows plus ONE
+  // E8M0 scale byte per (row, 288-column tile) -- a power of two >= max|tile row| / 448, which a tile knows without seeing the rest of the row -- and the consumer
+  // (gemm3s8_kernel<.., BS = true>) hands that byte to v_mfma_scale_f32_16x16x128_f8f6f4 as the block scale of the lane's 32 K-elements (scripts/probe_mfma_scale.hip:
+  // the scale operand is per lane; 288 = 9 x 32, so a lane's block never straddles two tiles).  No row-wide maximum, no pass between the two GEMMs.
+  uint8_t* q8_out;       // EMIT: [M][ldq8] e4m3 (instead of the 16-bit C)
+  uint8_t* e8_out;       // EMIT: [M][N / 288] E8M0
+  int ldq8;
+  const uint8_t* e8_in;  // BS: [M][e8_ld] E8M0 scale bytes of A8, one per G2_BN (288) K-elements; sa is not read
+  int e8_ld;
 };
 
-template <typename T, int EPI>
+constexpr int G3S8_TAB_BYTES = G3_BM * 16;  // BS: the tile's rows x 16 scale bytes behind the operand ring
+// E8M0 exponent byte of the smallest power of two >= amax / 448 (127 = 2^0 for an all-zero segment), and the reciprocal of that power of two
+ECAD_DEV unsigned e8m0_for(float amax) {
+  const unsigned b = __builtin_bit_cast(unsigned, amax * (1.0f / 448.0f));
+  unsigned e = (b >> 23) & 0xffu;
+  e += (b & 0x7fffffu) ? 1u : 0u;
+  e = amax > 0.f ? e : 127u;
+  return e < 1u ? 1u : (e > 254u ? 254u : e);
+}
+ECAD_DEV float e8m0_inverse(unsigned e) { return __builtin_bit_cast(float, (254u - e) << 23); }
+
+template <typename T, int EPI, bool BS = false>
 __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> q) {
   constexpr int BM = G3_BM, BN = G3_BN, NWAVES = G3_NW;
   constexpr int WTM = BM / NWAVES;
@@ -54,10 +74,17 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
 
   const uint8_t* a_src[A_INST];
   const uint8_t* b_src[B_INST_MAX];
+  // Which 16-byte piece of the 128-byte K-step lands in LDS position (lane & 7) of its row.  Plain: piece = position ^ swizzle (any K order works as long as both
+  // operands share it).  BS: the instruction's own K order matters -- the block scale of lane group b is applied to ITS logical K-block b, and the hardware counts K
+  // as (register half, lane group): a lane's low 16 bytes are K-chunk g, its high 16 bytes K-chunk 4 + g (scripts/probe_mfma_scale2.hip: ones in (group 0, high
+  // half) were scaled by group 2's byte, (group 2, low half) by group 1's).  The fragment reads below keep their conflict-free pattern (positions 2g and 2g + 1);
+  // the DMA source side deals the pieces instead: position q receives piece (q >> 1) + 4 (q & 1), so that lane group g reads pieces g and 4 + g and its scale byte
+  // covers exactly bytes [32 g, 32 g + 32) of the step -- how the producer's tiles are cut.  (Reading positions g and 4 + g directly cost 6 us of 58: bank conflicts.)
+  auto piece_of = [](int q_) { return BS ? (q_ >> 1) + 4 * (q_ & 1) : q_; };
 #pragma unroll
   for (int i = 0; i < A_INST; ++i) {
     const int r = (wave * A_INST + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int c = piece_of((lane & 7) ^ ((r >> 1) & 7));
     int row = m0 + r;
     row = row < p.M ? row : p.M - 1;
     a_src[i] = q.A8 + (size_t)row * q.lda8 + c * 16;
@@ -67,7 +94,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
     int inst = wave + i * NWAVES;
     inst = inst < B_INST_TOTAL ? inst : B_INST_TOTAL - 1;
     const int r = inst * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int c = piece_of((lane & 7) ^ ((r >> 1) & 7));
     b_src[i] = q.W8 + (size_t)(n0 + r) * p.K + c * 16;
   }
   auto issue = [&](int stage) {
@@ -96,8 +123,23 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
   const int b_row_off = l15 * 128;
   const int c0 = ((2 * g) ^ swz) * 16, c1 = ((2 * g + 1) ^ swz) * 16;
   const int nk = p.K / GEMM8_BK;
+  // BS: the 16 scale bytes of each of the tile's 256 rows, requested first (older than every operand piece) and parked behind the ring
+  u32x4 tabv = (u32x4){0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu};
+  if constexpr (BS) {
+    if (tid < BM) {
+      const int m = m0 + tid < p.M ? m0 + tid : p.M - 1;
+      tabv = *reinterpret_cast<const u32x4*>(q.e8_in + (size_t)m * q.e8_ld);
+    }
+  }
   issue(0);
   if (nk > 1) issue(1);
+  if constexpr (BS) {
+    if (tid < BM) *reinterpret_cast<u32x4*>(smem + G3_LDS_BYTES + tid * 16) = tabv;  // (the wait for tabv also waits for nothing younger: it was the first request)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in place before the first K-step's barrier
+  }
+  const char* tab_row[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) tab_row[i] = smem + G3_LDS_BYTES + (wave * WTM + 16 * i + l15) * 16;
   // EPI_BIAS_CACHE_RESID: fetch the hidden-state chunks of the epilogue now (see gemm3s.h)
   constexpr int CPR = BN / 8;
   constexpr int CHUNKS = WTM * CPR;
@@ -114,6 +156,9 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
     }
   }
   int stage = 0;
+  int asc_next[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) asc_next[i] = 0x7F7F7F7F;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -136,11 +181,29 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
       const Pack8 lo = lds_read16(bbase + b_row_off + j * 2048 + c0), hi = lds_read16(bbase + b_row_off + j * 2048 + c1);
       wf[j] = (i32x8){(int)lo.u[0], (int)lo.u[1], (int)lo.u[2], (int)lo.u[3], (int)hi.u[0], (int)hi.u[1], (int)hi.u[2], (int)hi.u[3]};
     }
+    int asc[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) asc[i] = 0x7F7F7F7F;
+    if constexpr (BS) {
+      // this lane group's scale byte is applied to K-block 4 kt + g of the row (see piece_of); blocks come nine to a 288-column producer tile: segment = block / 9 =
+      // (block * 57) >> 9 (exact below 512).  Fetched one step ahead: an LDS read right in front of the MFMAs that take it stalls them for its latency.
+      if (kt == 0) {  // (the table became visible with this step's barrier; blocks 0 .. 3 lie in segment 0)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) asc_next[i] = *reinterpret_cast<const unsigned char*>(tab_row[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asc[i] = asc_next[i];
+      const int seg = ((4 * (kt + 1) + g) * 57) >> 9;
+      if (kt + 1 < nk) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) asc_next[i] = *reinterpret_cast<const unsigned char*>(tab_row[i] + seg);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, asc[i]);
     stage = stage + 1 >= G3_STAGES ? 0 : stage + 1;
   }
   // weight scales, biases and row scales of this lane in ONE batch (gemm3s.h: hipcc otherwise serializes a load -> wait -> use round trip per vector)
@@ -155,7 +218,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int mi = m0 + wave * WTM + 16 * i + l15;
-    sams[i] = q.sa[mi < p.M ? mi : p.M - 1];
+    sams[i] = BS ? 1.0f : q.sa[mi < p.M ? mi : p.M - 1];  // BS: the activation scales went in as block scales of the MFMAs
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
@@ -223,7 +286,7 @@ __global__ __launch_bounds__(G3_NW * 64) void gemm3s8_kernel(const Gemm8Args<T> 
 // ---- wide tile for the plain-store GEMMs with N % 288 == 0 (FF1, K/V, fused QKV): gemm2w.h's 256 x 288 tile, 8 waves laid out 4 (M) x 2 (N)
 // with 64 x 144 each.  With 32 x 144 per wave (above) a wave reads 22 fragments from LDS per 18 fp8 MFMAs and the tile is LDS-read-bound
 // (FF1 gained only 1.19x over fp16); here it is 26 reads per 36 MFMAs.  2-stage ring (2 x 69.6 KiB).
-template <typename T, int EPI>
+template <typename T, int EPI, bool EMIT = false>
 __global__ __launch_bounds__(G2_NW * 64) void gemm2w8_kernel(const Gemm8Args<T> q) {
   static_assert(EPI != EPI_BIAS_CACHE_RESID, "plain-store epilogues only");
   constexpr int FM = 4, FN = 9;
@@ -351,6 +414,43 @@ __global__ __launch_bounds__(G2_NW * 64) void gemm2w8_kernel(const Gemm8Args<T> 
     }
   }
   __syncthreads();
+  if constexpr (EMIT) {
+    // The tile's rows leave as e4m3 with one power-of-two scale per (row, this 288-column tile): two lanes per row (144 columns each) read the rounded 16-bit values
+    // back from the C tile -- what the row quantiser would have read from HBM -- take the row segment's maximum, and convert with the smallest power of two that keeps
+    // it within e4m3's 448.  The consumer's MFMAs apply the byte as the block scale of the 32-element K-blocks it covers.
+    const int rl = lane >> 1, half = lane & 1;
+    const int ml = wave * 32 + rl, m = m0 + ml;
+    const T* src = ctile + ml * G2_CS + half * 144;
+    Pack8 cv[18];
+#pragma unroll
+    for (int c = 0; c < 18; ++c) cv[c] = lds_read16(src + 8 * c);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 18; ++c) {
+      float v[8];
+      unpack8<T>(cv[c], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    const unsigned eb = e8m0_for(amax);
+    const float inv = e8m0_inverse(eb);
+    if (m < p.M) {
+      uint8_t* dst = q.q8_out + (size_t)m * q.ldq8 + n0 + half * 144;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        float a[8], b[8];
+        unpack8<T>(cv[2 * c], a);
+        unpack8<T>(cv[2 * c + 1], b);
+        u32x4 o;
+        o[0] = pack_fp8x4(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv); o[1] = pack_fp8x4(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
+        o[2] = pack_fp8x4(b[0] * inv, b[1] * inv, b[2] * inv, b[3] * inv); o[3] = pack_fp8x4(b[4] * inv, b[5] * inv, b[6] * inv, b[7] * inv);
+        *reinterpret_cast<u32x4*>(dst + 16 * c) = o;
+      }
+      if (half == 0) q.e8_out[(size_t)m * (p.N / G2_BN) + n0 / G2_BN] = (uint8_t)eb;
+    }
+    return;
+  }
   constexpr int CPR = G2_BN / 8;
   constexpr int CHUNKS = 32 * CPR;
   for (int id = lane; id < CHUNKS; id += 64) {

@@ -1,5 +1,6 @@
 // Probe of v_mfma_scale_f32_16x16x128_f8f6f4 block-scale semantics on gfx950: hipcc --offload-arch=gfx950 scripts/probe_mfma_scale.hip -o /tmp/p && /tmp/p
-// Result (MI355X): lane l`s scale byte (opsel selects which of the 4) scales that lane`s own 32 elements, i.e. row/col l & 15, K-block l >> 4, for both operands.
+// Result (MI355X): lane l`s scale byte (opsel selects which of the 4) scales row/col l & 15, LOGICAL K-block l >> 4, for both operands -- which registers of which
+// lanes make up that block is settled by scripts/probe_mfma_scale2.hip (low 16 bytes of lane group g = K-chunk g, high 16 bytes = chunk 4 + g; block b = chunks 2b, 2b+1).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef int v8i __attribute__((ext_vector_type(8)));

@@ -729,6 +729,44 @@ def test_read_modify_write_launches_on_the_four_wave_narrow_tile_change_nothing(
     assert g3_3 == 0 and n4_3 == g3_0                     # 3: all of them
 
 
+def test_fp8_ff1_hands_e4m3_rows_and_block_scales_to_ff2(monkeypatch, few_rows_tiles):
+    """Round 6 (north_star: fp8 MFMA GEMMs; row n2): in fp8 mode FF1's GELU epilogue leaves its output as e4m3 rows plus one E8M0 scale byte per (row, 288-column
+    tile) -- a power of two the tile knows without the rest of the row -- and FF2's v_mfma_scale_f32_16x16x128_f8f6f4 takes the byte as the block scale of the lane's
+    32 K-elements: the row-quantiser pass between the two GEMMs (and the 16-bit round trip of the 4608-wide activations) is gone.  Taken from a CFG batch of 16 on
+    (M = 4096: one round of wide tiles).  Against ECAD_FP8_SEG=0 (16-bit ffmid + per-row quantiser): one launch less per executed feed-forward, final latents within
+    the fp8 quantisation of each other, and both within the fp8 mode's distance of the fp16 engine; graph == eager bit for bit."""
+    from ecad_amd.engine import EcadEngine
+
+    if few_rows_tiles == "latency64":
+        pytest.skip("one tile mode is enough: the fp8 GEMMs do not take latency tiles")
+    layers, steps, B = 2, 4, 8
+    bits = rand_bits(steps, layers, 0.6, seed=41)
+    bits[0] = True
+    cfg = PixArtConfig(num_layers=layers)
+    w = make_weights(cfg, seed=0)
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    inp, enc, mask = cfg_inputs(B)
+    args = (enc.cuda(), mask.cuda(), inp["latents"].cuda(), solver.timesteps, coefs, 4.5)
+    outs, launches = {}, {}
+    for seg in ("1", "0"):
+        monkeypatch.setenv("ECAD_FP8_SEG", seg)
+        eng = EcadEngine(num_layers=layers, max_batch=2 * B, max_tokens=256, max_text_tokens=120, dtype=torch.float16, fp8=True)
+        eng.load_state_dict(w)
+        eng.set_schedule(bits)
+        g = eng.run_schedule(*args, use_graph=True).clone()
+        assert torch.isfinite(g).all() and torch.equal(g, eng.run_schedule(*args, use_graph=False))
+        outs[seg], launches[seg] = g, eng.stats()["launches_per_batch"]
+        eng.close()
+    n_ff = int(resolve_executed(bits)[:, :, 2].sum())
+    assert launches["0"] - launches["1"] == n_ff                      # one quantiser launch per executed feed-forward
+    ref16, _, _ = make_pair(layers, bits, max_batch=2 * B)
+    plain = ref16.run_schedule(*args)
+    d_seg, d_row, d_between = rel_l2(outs["1"], plain), rel_l2(outs["0"], plain), rel_l2(outs["1"], outs["0"])
+    print(f"fp8 against the fp16 engine: block-scaled hand-over {d_seg:.3e}, row quantiser {d_row:.3e}; between the two {d_between:.3e}")
+    assert within(d_seg, 2e-2) and within(d_row, 2e-2) and d_between < 1.5 * max(d_seg, d_row)
+
+
 def test_fp8_mode_travels_with_shared_weights():
     """Execution contexts of an engine in fp8 mode (round 6): ecad_share_weights hands the donor's e4m3 weight copies on with the 16-bit arena (they live and die with
     it), so several fp8 batches can be in flight -- round 5 refused.  Every batch == the same batch on the donor alone, bit for bit; the context outlives the donor;

@@ -67,6 +67,57 @@ def engine_score_fn(engine, enc, mask, latents, timesteps, coefs, guidance: floa
     return score
 
 
+def engine_score_fn_batches(engine, batches, timesteps, coefs, guidance: float = 4.5, contexts: int = 3):
+    """score_fn over SEVERAL fixed prompt batches (config 4: 100 prompts per candidate = 6 batches of 16 + one of 4), the batches of a candidate kept in flight on
+    ``contexts`` execution contexts over this rank's weights (``EngineContexts``: batch i + 1 .. i + contexts - 1 run while batch i is being scored; every batch's
+    latents are bit-identical to running it alone).  Score = mean over the batches of the stand-in fidelity to the uncached run of the same batch.  ``score.restore()``
+    as in ``engine_score_fn``; ``score.close()`` releases the extra contexts."""
+    import torch
+
+    from ecad_amd.engine import EngineContexts
+
+    steps = len(timesteps)
+    fold_before = getattr(engine, "ln_fold", True)
+    engine.set_ln_fold(False)
+    engine.set_schedule(np.ones((steps, engine.cfg.num_layers, 3), dtype=np.uint8))
+    refs = [engine.run_schedule(e, m, l, timesteps, coefs, guidance).clone() for e, m, l in batches]
+    pool = EngineContexts(engine, max(1, int(contexts))) if contexts > 1 else None
+    if pool is not None:
+        for ctx in pool.engines[1:]:
+            ctx.set_ln_fold(False)
+
+    def score(_idx: int, bits: np.ndarray) -> float:
+        if pool is None:
+            engine.set_schedule(bits)
+            return float(np.mean([latent_fidelity_score(engine.run_schedule(e, m, l, timesteps, coefs, guidance), r) for (e, m, l), r in zip(batches, refs)]))
+        pool.set_schedule(bits)
+        pending, scores = [], []
+
+        def finish():
+            i, out, st = pending.pop(0)
+            torch.cuda.current_stream(engine.device).wait_stream(st)
+            scores.append(latent_fidelity_score(out, refs[i]))  # .norm() -> float: waits for that batch only
+
+        for i, (e, m, l) in enumerate(batches):
+            out, st = pool.submit(e, m, l, timesteps, coefs, guidance)
+            pending.append((i, out, st))
+            if len(pending) >= len(pool):
+                finish()
+        while pending:
+            finish()
+        return float(np.mean(scores))
+
+    def restore():
+        engine.set_ln_fold(fold_before)
+
+    def close():
+        if pool is not None:
+            pool.close()
+
+    score.restore, score.close, score.references = restore, close, refs
+    return score
+
+
 def flux_engine_score_fn(engine, enc, pooled, latents, grid_h: int, grid_w: int, timesteps_x1000, guidance_x1000: float, sigmas, num_blocks: int, num_single_blocks: int):
     """score_fn for FLUX candidates (flat ``FluxCacheSchedule.to_numpy`` vectors) on this rank's ``EcadFluxEngine``."""
     steps = len(timesteps_x1000)

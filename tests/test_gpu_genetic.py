@@ -118,3 +118,39 @@ def test_config4_population_72_one_generation_and_resume(tmp_path, monkeypatch, 
     monkeypatch.setattr(sys, "argv", base + ["--load-from", str(tmp_path / "p/c4/gen_002/manager_config.json"), "--generations", "1"])
     M.main()
     assert "generation 2: 72 candidates" in capsys.readouterr().out and (tmp_path / "p/c4/gen_003/checkpoint.pkl").exists()
+
+
+def test_candidate_scoring_with_its_prompt_batches_in_flight_gives_the_same_scores():
+    """engine_score_fn_batches (round 6; BASELINE config 4: 100 prompts per candidate = several batches): a candidate's prompt batches are kept in flight on execution
+    contexts over the rank's weights; every batch's latents are bit-identical to running it alone, so the candidate's score is the same number with one, two or
+    three batches in flight."""
+    import numpy as np
+    import torch
+
+    from ecad_amd.engine import EcadEngine
+    from ecad_amd.genetic.evaluate import engine_score_fn_batches
+    from oracle.dpm_solver_ref import DPMSolverPP2M
+    from oracle.pipeline_ref import synthetic_inputs
+    from oracle.pixart_ref import PixArtConfig, make_weights
+
+    layers, steps = 2, 4
+    eng = EcadEngine(num_layers=layers, max_batch=8, max_tokens=256, max_text_tokens=120, dtype=torch.float16)
+    eng.load_state_dict(make_weights(PixArtConfig(num_layers=layers), seed=0))
+    solver = DPMSolverPP2M(steps)
+    coefs = np.array([solver.coefficients(i, solver.order_for_step(i)) for i in range(steps)], dtype=np.float32)
+    batches = []
+    for k, B in enumerate((4, 4, 2, 4, 1)):  # the last batch of a prompt set is the short one
+        inp = synthetic_inputs(B, start_seed=50 + k)
+        batches.append((torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]], 0).cuda(), torch.cat([inp["negative_prompt_attention_mask"], inp["prompt_attention_mask"]], 0).cuda(),
+                        inp["latents"].cuda()))
+    rng = np.random.default_rng(3)
+    cands = [rng.random((steps, layers, 3)) < p for p in (0.3, 0.6, 0.9)]
+    got = {}
+    for n in (1, 2, 3):
+        score = engine_score_fn_batches(eng, batches, solver.timesteps, coefs, 4.5, contexts=n)
+        got[n] = [score(i, c) for i, c in enumerate(cands)]
+        score.restore()
+        score.close()
+    assert got[1] == got[2] == got[3]
+    assert got[1][0] < got[1][1] < got[1][2] <= 0.0  # more recomputation = closer to the uncached run
+    eng.close()

@@ -30,7 +30,9 @@ python3 scripts/pmc_sq.py gpurun_out/${PFX}_pmc_SQ gpurun_out/${PFX}_pmc_GRBM gp
 cp gpurun_out/${PFX}_pmc_sq.json profiles/${PFX}_pmc_sq.json
 rm -rf gpurun_out/${PFX}_prof gpurun_out/${PFX}_pmc_FETCH_SIZE gpurun_out/${PFX}_pmc_WRITE_SIZE gpurun_out/${PFX}_pmc_SQ gpurun_out/${PFX}_pmc_GRBM
 cp gpurun_out/${PFX}_pmc_traffic.json profiles/${PFX}_pmc_traffic.json   # so that the bench run below finds the stamped profile
-if [ "$WL" = alpha256 ]; then
+if [ "$WL" = alpha256 ] && [ -n "$FP8" ]; then
+  python3 bench.py --fp8 --streams 3 --steps 12 --warmup 2 --no-cpu-baseline --no-secondary --no-decode-tail > gpurun_out/${PFX}_bench.json 2> gpurun_out/${PFX}_bench.err
+elif [ "$WL" = alpha256 ]; then
   python3 bench.py > gpurun_out/${PFX}_bench.json 2> gpurun_out/${PFX}_bench.err
 else
   python3 bench.py $WARGS --no-cpu-baseline --no-secondary --no-decode-tail > gpurun_out/${PFX}_bench.json 2> gpurun_out/${PFX}_bench.err

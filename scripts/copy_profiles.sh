@@ -6,7 +6,7 @@ set -u
 TAG=${1:?tag}
 cd "$(dirname "$0")/.."
 n=0
-for w in "" _sigma1024 _flux1024 _flux1024_fp8; do
+for w in "" _fp8 _sigma1024 _flux1024 _flux1024_fp8; do
   for k in bench.json bench_under_rocprof.json kernel_stats.csv pmc_traffic.json pmc_sq.json; do
     f=gpurun_out/${TAG}${w}_$k
     [ -f "$f" ] && cp "$f" profiles/ && n=$((n + 1))

@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256) void gemm2w4_kernel(const GemmArgs<T> p) {
     // (the lane id is re-derived by v_mbcnt behind the statement rather than kept: threadIdx.x carried across it was a scratch spill + reload with a full vmcnt(0))
     int lane_fresh;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_fresh));
-    const int tid = wave * 64 + lane_fresh;
     const int lane = lane_fresh, l15 = lane & 15, g = lane >> 4;
     const char* cst = smem + G2W4_CST;
     auto raw = [&](auto ic, auto jc) -> f32x4 {

@@ -80,7 +80,7 @@ typedef struct EcadStats {
    * the tile count and the replayed components it carries: these say what actually ran. */
   int64_t rmw_launches_wide;     /* gemm2w4.h, 256 x 288 tiles (whole rounds, or half-chip beside another batch) */
   int64_t rmw_launches_narrow4;  /* gemm3s4.h, 256 x 144 tiles on four waves */
-  int64_t rmw_launches_gemm3s;   /* gemm3s.h, 256 x 144 tiles on eight waves (and its latency / split-K forms) */
+  int64_t rmw_launches_gemm3s;   /* gemm3s.h, 256 x 144 tiles on eight waves (launches that took the few-rows forms -- latency tiles, split-K -- are in none of the three) */
   int32_t split_k;               /* ecad_set_split_k / ECAD_SPLIT_K as it stands */
   int32_t batches_in_flight;     /* ecad_set_batches_in_flight as it stands */
 } EcadStats;

@@ -800,7 +800,7 @@ def main():
             dec_ms = ev0.elapsed_time(ev1) / 5
             vs = vae.decode_stats()
             res["decode_tail"] = {
-                "device_ms_per_batch": dec_ms, "conv_launches": vs["conv_launches"], "conv3s_launches": vs["conv3s_launches"], "conv_flops_per_batch": vs["conv_flops"],
+                "device_ms_per_batch": dec_ms, "conv_launches": vs["conv_launches"], "conv3s_launches": vs["conv3s_launches"], "conv4_launches": vs["conv4_launches"], "conv_flops_per_batch": vs["conv_flops"],
                 "roofline": {"bound": "mfma", "kernel": "conv3s_kernel + conv_gemm_kernel (implicit-GEMM convolutions of the AutoencoderKL decoder; GroupNorm / SiLU / upsample time included in the denominator)",
                              "achieved": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
             }

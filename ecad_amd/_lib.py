@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libecad_hip.so"
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ECAD_DTYPE_F16, ECAD_DTYPE_BF16, ECAD_DTYPE_F32 = 0, 1, 2
 ECAD_E_INVALID, ECAD_E_HIP, ECAD_E_NOT_READY, ECAD_E_UNSUPPORTED = -1, -2, -3, -4
@@ -163,6 +163,7 @@ SIGNATURES = {
     "ecad_vae_create_ex": (_I, [_I, _I, _I, _I, C.POINTER(_P)]),
     "ecad_vae_decode_ex": (_I, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P]),
     "ecad_vae_decode_stats": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I), C.POINTER(_I)]),
+    "ecad_vae_decode_stats_ex": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     # include/ecad_flux.h
     "ecad_flux_create": (_I, [C.POINTER(EcadFluxCfg), _I, C.POINTER(_P)]),
     "ecad_flux_destroy": (None, [_P]),

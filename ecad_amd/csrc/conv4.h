@@ -1,0 +1,170 @@
+// conv4.h -- the decoder's convolutions on the one-wave-per-SIMD K loops of gemm4_asm.h (round 6; SURVEY 8f-1, reference: `self.vae.decode` inside the timed region of
+// ecad/pipelines/pass_through.py:382-396).  conv3s_kernel (vae_kernels.h) gathers its A rows per tap with a per-lane address and a zero page for the padding, which a
+// generated loop with one uniform A pointer cannot do.  Here the INPUT of a 3 x 3 convolution is laid out with a zero border -- [B][H + 2][W + 2][C], written by the
+// GroupNorm apply pass or the upsample pass that produces it anyway -- so that
+//   * the three taps of one kernel row are 3 C contiguous channels starting at pixel (y + dy, x - 1): a K segment of 3 C elements, no padding test;
+//   * from one kernel row to the next every lane's source moves by the same (W + 2) C elements: a uniform jump of the A pointer every 3 C / 64 stages.
+// The M index still runs over the B H W real pixels (whole 256-row tiles, the same tile counts as conv3s), so a lane's eight DMA pieces have gathered byte offsets
+// (operands %[ao0..7] of the GEMM4_ASM_*G statements); outputs, residuals and 1 x 1 inputs stay plain [B H W][C].  K order per accumulator (row of taps, tap, channel,
+// fp32) and the epilogue arithmetic (bias in fp32, round, C tile through LDS, residual added to the rounded value, round) are conv3s_kernel's: the outputs are its bytes.
+#pragma once
+#include "common.h"
+#include "gemm4.h"
+#include "vae_kernels.h"
+
+namespace ecad {
+
+template <typename T, int BN> ECAD_DEV void conv4_statement(const char* ap, const char* wp, unsigned rsw, unsigned trips, unsigned lds, unsigned wave, unsigned seg,
+                                                            unsigned jump, const unsigned (&ao)[8]) {
+  const unsigned zero = 1u;
+  if constexpr (std::is_same<T, bf16_t>::value && BN == 256) { GEMM4_ASM_BF16_256G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
+  else if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_128G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
+  else if constexpr (BN == 256) { GEMM4_ASM_F16_256G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
+  else { GEMM4_ASM_F16_128G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
+}
+
+// p.in: [B][H + 2][W + 2][Cin] with a zero border when p.taps == 9, plain [B H W][Cin] when p.taps == 1; B H W % 256 == 0, Cout % BN == 0, taps Cin / 64 a whole
+// number of trips of the loop (vae.hip: conv4_bn)
+// RES: out = round(round(conv + bias) + resid).  The tile's residual chunks are requested right behind the K loop, all at once (16 or 32 sixteen-byte loads per lane), so
+// that they travel while the accumulators are staged: the row pass of conv3s_kernel asks for four at a time, which at one workgroup per CU is a latency-bound stream
+// (the conv2 launches took 75-120 us longer than their conv1 twins, 268 MB of residual at ~2 TB/s).
+template <typename T, int BN, bool RES>
+__global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
+  constexpr int FM = 8, FN = BN / 32, CS = BN + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = p.B * p.H * p.W;
+  int tm, tn;
+  {  // workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles: neighbours share their halo rows (and, along n, all their A rows) in that XCD's L2
+    const int tiles_n = p.Cout / BN, nwg = (M / 256) * tiles_n;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tm = bid / tiles_n;
+    tn = bid - tm * tiles_n;
+  }
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int K = p.taps * p.Cin;
+  unsigned ao[8];
+  {
+    const int HW = p.H * p.W, Wp = p.W + 2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = 8 * (8 * wave + q) + (lane >> 3);
+      const int m = m0 + r;
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      unsigned pix = (unsigned)m;
+      if (p.taps == 9) {
+        const int b = m / HW, rem = m - b * HW;
+        const int y = rem / p.W, x = rem - y * p.W;
+        pix = (unsigned)((b * (p.H + 2) + y) * Wp + x);   // the pixel above-left of (y, x) in the bordered image: first tap of the first kernel row
+      }
+      ao[q] = pix * (unsigned)(p.Cin * 2) + (unsigned)(c * 16);
+    }
+  }
+  const unsigned seg = p.taps == 9 ? (unsigned)(3 * p.Cin / 64) : 0x7fffffffu;
+  const unsigned jump = p.taps == 9 ? (unsigned)((p.W + 2 - 3) * p.Cin * 2 + 128) : 128u;
+  constexpr int period = G4Period<T, BN>::value;
+  conv4_statement<T, BN>(reinterpret_cast<const char*>(p.in), reinterpret_cast<const char*>(p.w) + (size_t)n0 * K * sizeof(T), (unsigned)(K * sizeof(T)),
+                         (unsigned)(K / 64 / period - 1), __builtin_amdgcn_readfirstlane(lds_offset(smem)), (unsigned)wave, seg, jump, ao);
+
+  // epilogue of conv3s_kernel on this wave geometry (2 x 2 waves of 128 x BN/2): the statement ends behind a barrier, the ring is free
+  const int wm = wave & 1, wn = wave >> 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  constexpr int CPR = BN / 8, RPP = 256 / CPR, NPASS = 256 / RPP;   // 16-byte chunks per tile row, rows per pass of the 256 threads, passes
+  const int cchunk = tid % CPR, crow0 = tid / CPR;
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* res = reinterpret_cast<const T*>(p.resid);
+  const size_t off0 = (size_t)(m0 + crow0) * p.Cout + n0 + cchunk * 8;
+  const size_t pstep = (size_t)RPP * p.Cout;
+  Pack8 rv[RES ? NPASS : 1];
+  if constexpr (RES) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) rv[pass] = gload16(res + off0 + pass * pstep);
+  }
+  T* ctile = reinterpret_cast<T*>(smem);
+  static_for<FN>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int nl = wn * (BN / 2) + 16 * j + 4 * g;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+    static_for<FM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int ml = wm * 128 + 16 * i + l15;
+      const f32x4 av = g4_acc<i, j>();
+      Pack4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) float_to_elem4<T>(o, r, av[r] + bv[r]);
+      *reinterpret_cast<u32x2*>(ctile + ml * CS + nl) = o.u;
+    });
+  });
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int ml = pass * RPP + crow0;
+    Pack8 v = lds_read16(ctile + ml * CS + cchunk * 8);
+    if constexpr (RES) {
+      float a[8], b[8];
+      unpack8<T>(v, a);
+      unpack8<T>(rv[pass], b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+      v = pack8<T>(a);
+    }
+    gstore16(out + off0 + pass * pstep, v);
+  }
+}
+
+// GroupNorm apply (+ SiLU) from plain [B H W][C] into the zero-bordered layout [B][H + 2][W + 2][C] a conv4_kernel reads; the border chunks are written as zeros here,
+// every time, so that the buffer carries no state from the geometry it held before
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_pad_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           size_t total_chunks, int H, int W, int C) {
+  const int cpr = C >> 3, Wp = W + 2, HWp = (H + 2) * Wp;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_chunks; idx += (size_t)gridDim.x * 256) {
+    const size_t pp = idx / cpr;
+    const int c = (int)(idx - pp * cpr) * 8;
+    const int b = (int)(pp / HWp);
+    const int rem = (int)(pp - (size_t)b * HWp);
+    const int yy = rem / Wp, xx = rem - yy * Wp;
+    Pack8 o;
+    o.u = (u32x4){0u, 0u, 0u, 0u};
+    if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
+      float v[8];
+      unpack8<T>(gload16(x + (((size_t)b * H + (yy - 1)) * W + (xx - 1)) * C + c), v);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c), s1 = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + (size_t)b * C + c), h1 = *reinterpret_cast<const f32x4*>(shift + (size_t)b * C + c + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = v[e] * s0[e] + h0[e];
+        v[4 + e] = v[4 + e] * s1[e] + h1[e];
+      }
+      if (SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+      }
+      o = pack8<T>(v);
+    }
+    gstore16(y + idx * 8, o);
+  }
+}
+
+// nearest-2x upsample of plain [B][H/2][W/2][C] into the zero-bordered [B][H + 2][W + 2][C] (H, W: the upsampled size) in front of an upsampler's conv4_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_pad_kernel(const T* __restrict__ x, T* __restrict__ y, size_t total_chunks, int H, int W, int C) {
+  const int cpr = C >> 3, Wp = W + 2, HWp = (H + 2) * Wp, Hin = H >> 1, Win = W >> 1;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_chunks; idx += (size_t)gridDim.x * 256) {
+    const size_t pp = idx / cpr;
+    const int c = (int)(idx - pp * cpr) * 8;
+    const int b = (int)(pp / HWp);
+    const int rem = (int)(pp - (size_t)b * HWp);
+    const int yy = rem / Wp, xx = rem - yy * Wp;
+    Pack8 o;
+    o.u = (u32x4){0u, 0u, 0u, 0u};
+    if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) o = gload16(x + (((size_t)b * Hin + ((yy - 1) >> 1)) * Win + ((xx - 1) >> 1)) * C + c);
+    gstore16(y + idx * 8, o);
+  }
+}
+
+}  // namespace ecad

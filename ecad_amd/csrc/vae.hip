@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "vae_kernels.h"
+#include "conv4.h"
 
 namespace ecad {
 
@@ -61,7 +62,7 @@ struct VaeBase {
   virtual int decode(const float* lat, int B, int h, int w, float scaling, float shift, uint8_t* out, hipStream_t s) = 0;
   // roofline accounting of the last decode: flops of its convolution GEMMs (2 M Cout taps Cin each) and how many of them ran on the 256 x 128 / 3-stage kernel
   double conv_flops = 0;
-  int conv_launches = 0, conv3s_launches = 0;
+  int conv_launches = 0, conv3s_launches = 0, conv4_launches = 0;
 };
 
 template <typename T> struct VaeT : VaeBase {
@@ -72,13 +73,15 @@ template <typename T> struct VaeT : VaeBase {
   void* zero_page = nullptr;
   // activation buffers
   T *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr;
+  T* bufP = nullptr;  // zero-bordered input of the conv4_kernel launches: [B][H + 2][W + 2][C] (conv4.h)
   float *gn_sums = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
-  size_t act_elems = 0;
+  size_t act_elems = 0, bufD_elems = 0;
   int cap_B = 0, cap_h = 0, cap_w = 0;
   bool finalized = false;
   bool async_failed = false;  // an asynchronous call inside a void helper failed: decode() turns it into ECAD_E_HIP
   int gn_blocks_cap = 0;  // per-block partial sums the GroupNorm statistics may write: sized by ensure_acts for the largest stage of the geometry it was given
   bool conv_tile128 = false;  // env ECAD_VAE_CONV=tile128: every convolution on the 128 x 128 kernel (A/B against conv3s_kernel)
+  bool conv_gather = false;   // env ECAD_VAE_CONV=conv3s: no conv4_kernel launches (the round-3 path: per-tap gathered A on eight waves; A/B and the byte-identity test)
   int num_cus = 256;
 
   ~VaeT() override {
@@ -87,9 +90,9 @@ template <typename T> struct VaeT : VaeBase {
     free_acts();
   }
   void free_acts() {
-    for (void* p : {(void*)bufA, (void*)bufB, (void*)bufC, (void*)bufD, (void*)gn_sums, (void*)gn_scale, (void*)gn_shift})
+    for (void* p : {(void*)bufA, (void*)bufB, (void*)bufC, (void*)bufD, (void*)bufP, (void*)gn_sums, (void*)gn_scale, (void*)gn_shift})
       if (p) (void)hipFree(p);
-    bufA = bufB = bufC = bufD = nullptr;
+    bufA = bufB = bufC = bufD = bufP = nullptr;
     gn_sums = gn_scale = gn_shift = nullptr;
   }
   int reg(const std::string& name, Kind kind, int cout, int cin) {
@@ -138,7 +141,11 @@ template <typename T> struct VaeT : VaeBase {
     REG("decoder.conv_out.weight", CONVOUT, 3, 128) REG("decoder.conv_out.bias", F32, 3, 0)
     VHIPCHK(hipFuncSetAttribute((const void*)conv_gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     VHIPCHK(hipFuncSetAttribute((const void*)conv3s_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES));
-    if (const char* e = getenv("ECAD_VAE_CONV")) conv_tile128 = strcmp(e, "tile128") == 0;
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<256>()));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<128>()));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<256>()));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<128>()));
+    if (const char* e = getenv("ECAD_VAE_CONV")) { conv_tile128 = strcmp(e, "tile128") == 0; conv_gather = strcmp(e, "conv3s") == 0; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount;
     return ECAD_OK;
@@ -196,7 +203,9 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipMalloc((void**)&bufA, act_elems * sizeof(T)));
     VHIPCHK(hipMalloc((void**)&bufB, act_elems * sizeof(T)));
     VHIPCHK(hipMalloc((void**)&bufC, act_elems * sizeof(T)));
-    VHIPCHK(hipMalloc((void**)&bufD, (attn_elems > act_elems ? attn_elems : act_elems) * sizeof(T)));
+    bufD_elems = attn_elems > act_elems ? attn_elems : act_elems;
+    VHIPCHK(hipMalloc((void**)&bufD, bufD_elems * sizeof(T)));
+    VHIPCHK(hipMalloc((void**)&bufP, (size_t)B * (8 * h + 2) * (8 * w + 2) * 256 * sizeof(T)));
     // per-block partial (sum, sum of squares) of the 32 groups: the largest stage has 64 h w pixels at 512 per block (group_norm_stats), the small ones at most 64 blocks
     const size_t blocks_max = (64 * tokens + 511) / 512;
     gn_blocks_cap = (int)(blocks_max > 64 ? blocks_max : 64);
@@ -208,8 +217,17 @@ template <typename T> struct VaeT : VaeBase {
   }
 
   // ---- layer launchers
+  // which conv4_kernel tile a convolution takes (0: none -- conv3s_kernel / conv_gemm_kernel): whole 256-row tiles, whole trips of the generated K loop, and enough
+  // tiles for the chip.  A 3 x 3 convolution on conv4_kernel reads the zero-bordered layout: its producer (GroupNorm apply or the upsample pass) asks here first.
+  int conv4_bn(int M, int cin, int cout, int taps) const {
+    if (conv_tile128 || conv_gather || M % 256 || cin % 64) return 0;
+    const int stages = taps * cin / 64, tiles_m = M / 256;
+    if (cout % 256 == 0 && stages % G4Period<T, 256>::value == 0 && tiles_m * (cout / 256) >= num_cus) return 256;
+    if (cout % 128 == 0 && stages % G4Period<T, 128>::value == 0 && tiles_m * (cout / 128) >= num_cus) return 128;
+    return 0;
+  }
   int conv(const T* in, const std::string& name, T* out, const T* resid, int B, int H, int W, int cin, int cout, int taps, int up, hipStream_t s,
-           const T* w_override = nullptr, const float* b_override = nullptr, bool no_bias = false) {
+           const T* w_override = nullptr, const float* b_override = nullptr, bool no_bias = false, bool bordered = false) {
     if (cin % 64 || cout % 128) return fail(ECAD_E_UNSUPPORTED, "conv %s: Cin %% 64 / Cout %% 128 required (%d, %d)", name.c_str(), cin, cout);
     ConvArgs a{};
     a.in = in; a.w = w_override ? w_override : W_<T>(name + ".weight"); a.bias = no_bias ? nullptr : (b_override ? b_override : W_<float>(name + ".bias"));
@@ -217,6 +235,16 @@ template <typename T> struct VaeT : VaeBase {
     const int M = B * H * W;
     conv_flops += 2.0 * M * (double)cout * taps * cin;
     ++conv_launches;
+    if (const int bn = (up || (taps == 9) != bordered) ? 0 : conv4_bn(M, cin, cout, taps)) {
+      const dim3 grid((M / 256) * (cout / bn));
+      if (bn == 256 && resid) hipLaunchKernelGGL((conv4_kernel<T, 256, true>), grid, dim3(256), g4_lds_bytes<256>(), s, a);
+      else if (bn == 256) hipLaunchKernelGGL((conv4_kernel<T, 256, false>), grid, dim3(256), g4_lds_bytes<256>(), s, a);
+      else if (resid) hipLaunchKernelGGL((conv4_kernel<T, 128, true>), grid, dim3(256), g4_lds_bytes<128>(), s, a);
+      else hipLaunchKernelGGL((conv4_kernel<T, 128, false>), grid, dim3(256), g4_lds_bytes<128>(), s, a);
+      ++conv4_launches;
+      return ECAD_OK;
+    }
+    if (bordered) return fail(ECAD_E_INVALID, "internal: conv %s was handed the bordered layout but does not run on conv4_kernel", name.c_str());
     // 256 x 128 tiles with the 3-stage K loop (conv3s_kernel) once they fill the chip; the 128 x 128 kernel for the small launches (mid-block attention, 8 x 8 latents)
     if (!conv_tile128 && ((M + C3_BM - 1) / C3_BM) * (cout / C3_BN) >= num_cus && (taps * cin) / 64 >= 4) {
       hipLaunchKernelGGL((conv3s_kernel<T>), dim3(((M + C3_BM - 1) / C3_BM) * (cout / C3_BN)), dim3(C3_NW * 64), C3_LDS_BYTES, s, a);
@@ -227,6 +255,17 @@ template <typename T> struct VaeT : VaeBase {
     hipLaunchKernelGGL((conv_gemm_kernel<T>), dim3(tiles), dim3(256), 65536, s, a);
     return ECAD_OK;
   }
+  // out[i] = in[i] w[i]^T for nb images (grid.y): the mid-block attention's score and value GEMMs on the 128 x 128 kernel
+  int gemm_batched(const T* in, const T* w, T* out, int nb, int M, int K, int N, size_t bs_in, size_t bs_w, size_t bs_out, hipStream_t s) {
+    if (K % 64 || N % 128) return fail(ECAD_E_UNSUPPORTED, "attention GEMM: K %% 64 / N %% 128 required (%d, %d)", K, N);
+    ConvArgs a{};
+    a.in = in; a.w = w; a.out = out; a.zero_page = zero_page; a.B = 1; a.H = M; a.W = 1; a.Cin = K; a.Cout = N; a.taps = 1;
+    a.bs_in = bs_in; a.bs_w = bs_w; a.bs_out = bs_out;
+    conv_flops += 2.0 * nb * M * (double)N * K;
+    ++conv_launches;
+    hipLaunchKernelGGL((conv_gemm_kernel<T>), dim3(((M + 127) / 128) * (N / 128), nb), dim3(256), 65536, s, a);
+    return ECAD_OK;
+  }
   // statistics -> per-(image, channel) scale/shift in gn_scale / gn_shift
   void group_norm_stats(const T* x, const std::string& name, int B, int HW, int C, hipStream_t s) {
     const int ppb = HW >= 16384 ? 512 : HW >= 4096 ? 256 : 64;
@@ -234,6 +273,13 @@ template <typename T> struct VaeT : VaeBase {
     if (nblk > gn_blocks_cap) { async_failed = true; return; }  // cannot happen for a geometry ensure_acts has sized the buffers for; decode() reports it
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nblk, B), dim3(256), 0, s, x, gn_sums, HW, C, 32, ppb);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, gn_sums, nblk, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
+  }
+  // GroupNorm + SiLU into the zero-bordered layout (conv4.h)
+  void group_norm_bordered(const T* x, T* y, const std::string& name, int B, int H, int W, int C, hipStream_t s) {
+    group_norm_stats(x, name, B, H * W, C, s);
+    const size_t chunks = (size_t)B * (H + 2) * (W + 2) * (C / 8);
+    const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+    hipLaunchKernelGGL((gn_apply_pad_kernel<T, true>), dim3(grid), dim3(256), 0, s, x, y, gn_scale, gn_shift, chunks, H, W, C);
   }
   void group_norm(const T* x, T* y, const std::string& name, int B, int HW, int C, bool act, hipStream_t s) {
     group_norm_stats(x, name, B, HW, C, s);
@@ -245,15 +291,18 @@ template <typename T> struct VaeT : VaeBase {
   // x (in `x`) -> resnet -> result in `out`; t1, t2 scratch
   int resnet(const std::string& p, const T* x, T* out, T* t1, T* t2, int B, int H, int W, int cin, int cout, hipStream_t s) {
     int rc;
-    group_norm(x, t1, p + "norm1", B, H * W, cin, true, s);
-    if ((rc = conv(t1, p + "conv1", t2, nullptr, B, H, W, cin, cout, 9, 0, s))) return rc;
-    group_norm(t2, t2, p + "norm2", B, H * W, cout, true, s);
+    const bool b1 = conv4_bn(B * H * W, cin, cout, 9) != 0, b2 = conv4_bn(B * H * W, cout, cout, 9) != 0;
+    if (b1) group_norm_bordered(x, bufP, p + "norm1", B, H, W, cin, s);
+    else group_norm(x, t1, p + "norm1", B, H * W, cin, true, s);
+    if ((rc = conv(b1 ? bufP : t1, p + "conv1", t2, nullptr, B, H, W, cin, cout, 9, 0, s, nullptr, nullptr, false, b1))) return rc;
+    if (b2) group_norm_bordered(t2, bufP, p + "norm2", B, H, W, cout, s);
+    else group_norm(t2, t2, p + "norm2", B, H * W, cout, true, s);
     const T* res = x;
     if (cin != cout) {
       if ((rc = conv(x, p + "conv_shortcut", t1, nullptr, B, H, W, cin, cout, 1, 0, s))) return rc;
       res = t1;
     }
-    return conv(t2, p + "conv2", out, res, B, H, W, cout, cout, 9, 0, s);
+    return conv(b2 ? bufP : t2, p + "conv2", out, res, B, H, W, cout, cout, 9, 0, s, nullptr, nullptr, false, b2);
   }
 
   int decode(const float* lat, int B, int h, int w, float scaling, float shift, uint8_t* out, hipStream_t s) override {
@@ -262,7 +311,7 @@ template <typename T> struct VaeT : VaeBase {
     if (B < 1 || h < 4 || w < 4 || (h * w) % 128 || (w & 1)) return fail(ECAD_E_INVALID, "latent %dx%dx%d unsupported (h*w must be a multiple of 128, w even)", B, h, w);
     int rc = ensure_acts(B, h, w);
     if (rc) return rc;
-    conv_flops = 0; conv_launches = conv3s_launches = 0;
+    conv_flops = 0; conv_launches = conv3s_launches = conv4_launches = 0;
     T *x = bufA, *y = bufB, *t = bufC;
     int H = h, Wd = w;
     {
@@ -289,11 +338,16 @@ template <typename T> struct VaeT : VaeBase {
       if ((rc = conv(t, a + "to_v", v, nullptr, B, HW, 1, C, C, 1, 0, s))) return rc;
       hipLaunchKernelGGL((transpose_kernel<T>), dim3((C + 31) / 32, (HW + 31) / 32, B), dim3(32, 8), 0, s, v, vt, HW, C);
       T* o = t;  // attention output [B*HW, C] (group-normed input no longer needed once q,k,v exist)
-      for (int b = 0; b < B; ++b) {
-        T* S = bufD;  // [HW, HW]
-        if ((rc = conv(q + (size_t)b * HW * C, "", S, nullptr, 1, HW, 1, C, HW, 1, 0, s, k + (size_t)b * HW * C, nullptr, true))) return rc;
-        hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3(HW), dim3(256), 0, s, S, HW, 1.0f / sqrtf((float)C));
-        if ((rc = conv(S, "", o + (size_t)b * HW * C, nullptr, 1, HW, 1, HW, C, 1, 0, s, vt + (size_t)b * HW * C, nullptr, true))) return rc;
+      // score matrices of as many images at once as bufD holds ([nb][HW][HW]; all 16 of the bench geometry): the three launches per image of rounds 1-5 were 0.6 ms
+      // of launch-bound work per decode
+      const size_t cap_imgs = bufD_elems / ((size_t)HW * HW);
+      for (int b = 0; b < B;) {
+        const int nb = (int)((size_t)(B - b) < cap_imgs ? (size_t)(B - b) : cap_imgs);
+        T* S = bufD;
+        if ((rc = gemm_batched(q + (size_t)b * HW * C, k + (size_t)b * HW * C, S, nb, HW, C, HW, (size_t)HW * C, (size_t)HW * C, (size_t)HW * HW, s))) return rc;
+        hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3(HW * nb), dim3(256), 0, s, S, HW, 1.0f / sqrtf((float)C));
+        if ((rc = gemm_batched(S, vt + (size_t)b * HW * C, o + (size_t)b * HW * C, nb, HW, HW, C, (size_t)HW * HW, (size_t)HW * C, (size_t)HW * C, s))) return rc;
+        b += nb;
       }
       if ((rc = conv(o, a + "to_out.0", x, y, B, HW, 1, C, C, 1, 0, s))) return rc;  // + residual (input of the attention)
     }
@@ -311,7 +365,13 @@ template <typename T> struct VaeT : VaeBase {
       }
       if (i < 3) {
         H *= 2; Wd *= 2;
-        if ((rc = conv(cur, "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", oth, nullptr, B, H, Wd, chans[i], chans[i], 9, 1, s))) return rc;
+        const std::string un = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
+        if (conv4_bn(B * H * Wd, chans[i], chans[i], 9)) {  // the upsampled image is written out (bordered) and the convolution runs on conv4_kernel
+          const size_t chunks = (size_t)B * (H + 2) * (Wd + 2) * (chans[i] / 8);
+          const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+          hipLaunchKernelGGL((upsample_pad_kernel<T>), dim3(grid), dim3(256), 0, s, cur, bufP, chunks, H, Wd, chans[i]);
+          if ((rc = conv(bufP, un, oth, nullptr, B, H, Wd, chans[i], chans[i], 9, 0, s, nullptr, nullptr, false, true))) return rc;
+        } else if ((rc = conv(cur, un, oth, nullptr, B, H, Wd, chans[i], chans[i], 9, 1, s))) return rc;
         std::swap(cur, oth);
       }
       prev = chans[i];
@@ -367,6 +427,11 @@ int ecad_vae_decode_stats(const EcadVae* v, double* conv_flops, int* conv_launch
   if (conv_launches) *conv_launches = v->impl->conv_launches;
   if (conv3s_launches) *conv3s_launches = v->impl->conv3s_launches;
   return ECAD_OK;
+}
+int ecad_vae_decode_stats_ex(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches, int* conv4_launches) {
+  if (!v) return ECAD_E_INVALID;
+  if (conv4_launches) *conv4_launches = v->impl->conv4_launches;
+  return ecad_vae_decode_stats(v, conv_flops, conv_launches, conv3s_launches);
 }
 int ecad_vae_decode_ex(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, float shift_factor, uint8_t* out_u8_dev, void* stream) {
   if (!v || !latents_dev || !out_u8_dev) return ECAD_E_INVALID;

@@ -20,6 +20,7 @@ struct ConvArgs {
   int B, H, W;        // OUTPUT spatial size
   int Cin, Cout, taps;  // taps = 9 (3x3, pad 1) or 1 (1x1 / linear)
   int up;             // 1: input is [B, H/2, W/2, Cin], nearest-upsampled on the fly
+  size_t bs_in, bs_w, bs_out;  // conv_gemm_kernel only: element strides of in / w / out per blockIdx.y (batched GEMMs of the mid-block attention; 0 elsewhere)
 };
 
 // 128 x 128 x 64 tile, 4 waves (2 x 2, 64 x 64 each), 2-stage LDS ring; same LDS image / swizzle / epilogue as gemm.h.
@@ -38,8 +39,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int K = p.taps * p.Cin;
   const int Hin = p.up ? p.H >> 1 : p.H, Win = p.up ? p.W >> 1 : p.W;
-  const T* in = reinterpret_cast<const T*>(p.in);
-  const T* wgt = reinterpret_cast<const T*>(p.w);
+  const T* in = reinterpret_cast<const T*>(p.in) + blockIdx.y * p.bs_in;
+  const T* wgt = reinterpret_cast<const T*>(p.w) + blockIdx.y * p.bs_w;
 
   // this lane's A rows (output pixels) and its 16-byte chunk inside the 64-channel K-step
   int pb[A_INST], py[A_INST], px[A_INST], pc[A_INST];
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
     }
   }
   __syncthreads();
-  T* out = reinterpret_cast<T*>(p.out);
+  T* out = reinterpret_cast<T*>(p.out) + blockIdx.y * p.bs_out;
   const T* res = reinterpret_cast<const T*>(p.resid);
   const int cchunk = tid & 15, crow0 = tid >> 4;
 #pragma unroll 4

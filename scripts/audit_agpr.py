@@ -20,7 +20,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffast-math -fno-finite-math-only -DECAD_PRODUCT_BUILD -S --cuda-device-only".split()  # BASEFLAGS of the Makefile
-KERNELS = ("fgemm4", "fgemm48", "attn_w4a", "gemm2w4", "gemm3s4")
+KERNELS = ("fgemm4", "fgemm48", "attn_w4a", "gemm2w4", "gemm3s4", "conv4")
 
 
 def audit(asm: str, unit: str) -> int:
@@ -72,7 +72,7 @@ def main() -> int:
             total += 1
         return 1 if bad else 0
     with tempfile.TemporaryDirectory() as td:
-        for unit in ("flux.hip", "engine.hip"):
+        for unit in ("flux.hip", "engine.hip", "vae.hip"):
             out = Path(td) / (unit + ".s")
             subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, str(ROOT / "ecad_amd" / "csrc" / unit), "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
             bad += audit(out.read_text(), unit)

@@ -27,7 +27,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 import os
 ABLATE = set(filter(None, os.environ.get("G4_ABLATE", "").split(",")))   # timing experiments only (wrong results): mfma, read, dma
-SG = dict(loop=60, ldsw=61, ap=62, ap_hi=63, wp=64, wp_hi=65, m0save=66, tmp0=67, tmp1=68, ldsw2=69, wdst=70, rstep=75)   # wdst: s70..s74, rstep: s75 (BN 144 only)
+SG = dict(loop=60, ldsw=61, ap=62, ap_hi=63, wp=64, wp_hi=65, m0save=66, tmp0=67, tmp1=68, ldsw2=69, wdst=70, rstep=75, segc=70)   # wdst: s70..s74, rstep: s75 (BN 144 only); segc: s70 (gathered A only)
 
 
 def s(n):
@@ -50,8 +50,12 @@ class Gen:
     """dtype bf16 | f16: two 32-deep sub-steps per 64-element stage, fragments of 4 registers, two whole fragment sets alternate.
     dtype fp8: one 128-deep step per stage, fragments of 8 registers (two 16-byte reads), A in two alternating sets, W in a rolling window of four."""
 
-    def __init__(self, dtype, bn, stage=False):
+    def __init__(self, dtype, bn, stage=False, gather=False):
         self.dt, self.BN = dtype, bn
+        # gathered A (conv4_kernel of vae_kernels.h: a 3 x 3 convolution over zero-bordered NHWC activations as an implicit GEMM): the byte offsets of the lane's eight A
+        # pieces come in as operands %[ao0] .. %[ao7] instead of row * stride, and the A pointer jumps by %[jump] instead of 128 bytes after every %[seg] stages (from the
+        # three pixels of one image row to the three of the next: the K order is row of taps, tap, channel)
+        self.gather = gather
         self.stage = stage                       # BN 288 / 144: after the K loop the statement itself rounds acc + bias into the row-major C tile in LDS (see stage_c)
         self.fp8 = dtype == "fp8"
         # BN 144 (gemm3s4.h: the N = 1152 read-modify-write GEMMs and FF2 of the PixArt path, gemm3s.h's 256 x 144 tile): the waves are stacked 4 x 1 -- a wave owns
@@ -130,6 +134,9 @@ class Gen:
 
     def dma_piece(self, which, p, slot):
         off = (self.AOFF if which == "a" else self.WOFF) + p
+        if self.gather and which == "a":
+            ptr, base, imm = "ap", "ldsw", slot * self.STAGE + p * 1024
+            return [f"s_add_u32 m0, {s(base)}, {imm}", "s_nop 0", f"global_load_lds_dwordx4 %[ao{p}], {s2(ptr)}"]
         ptr = "ap" if which == "a" else "wp"
         base = "ldsw" if which == "a" else "ldsw2"
         imm = slot * self.STAGE + (0 if which == "a" else 32768) + p * 1024
@@ -138,6 +145,10 @@ class Gen:
         return [f"s_add_u32 m0, {s(base)}, {imm}", "s_nop 0", f"global_load_lds_dwordx4 {v(off)}, {s2(ptr)}"]
 
     def advance(self):
+        if self.gather:
+            return [f"s_sub_u32 {s('segc')}, {s('segc')}, 1", f"s_cmp_eq_u32 {s('segc')}, 0", f"s_cselect_b32 {s('tmp0')}, %[jump], 128",
+                    f"s_cselect_b32 {s('segc')}, %[seg], {s('segc')}", f"s_add_u32 {s('ap')}, {s('ap')}, {s('tmp0')}", f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, 0",
+                    f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"]
         return [f"s_add_u32 {s('ap')}, {s('ap')}, 128", f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, 0", f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"]
 
     def dma_stage(self, slot):
@@ -285,6 +296,8 @@ class Gen:
         I(f"v_lshrrev_b32_e32 {v(T + 4)}, 3, {v(T)}")               # lane >> 3
         I(f"v_and_b32_e32 {v(T + 5)}, 7, {v(T)}")                   # position
         for which, n, off, rs in (("a", 8, self.AOFF, "%[rsa]"), ("w", self.WP, self.WOFF, "%[rsw]")):
+            if self.gather and which == "a":
+                continue
             if self.narrow and which == "w":
                 for q in range(n):
                     # W piece (5 wave + q) mod 18: rows 8 piece + (lane >> 3), (row >> 1) & 7 = ((4 piece) & 7) | (lane >> 4); its LDS address in slot 0 -> s[wdst + q]
@@ -323,6 +336,8 @@ class Gen:
         I(f"s_add_u32 {s('ldsw2')}, %[lds], {s('tmp0')}")
         I(f"s_mov_b64 {s2('ap')}, %[ap]")
         I(f"s_mov_b64 {s2('wp')}, %[wp]")
+        if self.gather:
+            I(f"s_mov_b32 {s('segc')}, %[seg]")
         b2 = len(self.lines)
         if self.fp8:
             I(f"v_mov_b32_e32 {v(self.SC)}, 0x7f7f7f7f")
@@ -524,6 +539,10 @@ OPERANDS = """\
       : /* accumulators stay in AGPRs */
       : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
 """
+OPERANDS_G = ("""\
+      : /* accumulators stay in AGPRs */
+      : [ap] "s"(ap), [wp] "s"(wp), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero), [seg] "s"(seg), [jump] "s"(jump), """
+              + ", ".join(f'[ao{i}] "v"(ao[{i}])' for i in range(8)) + "\n")
 OPERANDS_288 = """\
       : [c8_0] "+v"(c8[0]), [c8_1] "+v"(c8[1]), [c8_2] "+v"(c8[2]), [c8_3] "+v"(c8[3]), [c8_4] "+v"(c8[4]), [c8_5] "+v"(c8[5]), [c8_6] "+v"(c8[6]), [c8_7] "+v"(c8[7])
       : [ap] "s"(ap), [wp] "s"(wp), [rsa] "s"(rsa), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero)
@@ -577,6 +596,14 @@ def main():
                      f"#define GEMM4_PERIOD_144 {g.period}\n" if dt == "bf16" else "")
         parts.append(f"#define GEMM4_ASM_{dt.upper()}_144S(ap, wp, rsa, rsw, trips, lds, wave, zero, rbase, ldrb, h) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
                      + "\n".join(x + " \\" for x in OPERANDS_144S.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV, 76) + ")\n")
+    for dt in ("bf16", "f16"):
+        for bn in (256, 128):
+            g = Gen(dt, bn, gather=True)
+            lines = g.build()
+            print(f"{dt} BN {bn}, gathered A: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs, {g.NV} VGPRs", file=sys.stderr)
+            body = "\n".join('    "' + ln + '\\n"' for ln in lines)
+            parts.append(f"#define GEMM4_ASM_{dt.upper()}_{bn}G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
+                         + "\n".join(x + " \\" for x in OPERANDS_G.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV, 71) + ")\n")
     text = "\n".join(parts)
     if "--check" in sys.argv:   # the committed header is what this generator writes (tests/test_cpu_host.py)
         if ABLATE or out.read_text() != text:

@@ -61,6 +61,33 @@ def test_conv3s_tiles_give_the_bytes_of_the_128_tile_kernel_and_decodes_repeat(m
         assert torch.equal(out["tile128"], out["conv3s"])
 
 
+@pytest.mark.parametrize("B", [16, 4, 3])
+def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B):
+    """conv4.h (round 6): the convolutions whose tiles fill the chip run the generated one-wave-per-SIMD K loop over a zero-bordered copy of their input (written by the
+    GroupNorm apply / upsample pass), K order and epilogue arithmetic of conv3s_kernel -- the decoded image must be conv3s's byte for byte.  B 16 is the bench geometry
+    (every 3 x 3 convolution and the 512 -> 256 shortcut on conv4); B 4 / B 3 mix conv4 stages with conv3s / conv_gemm ones."""
+    from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
+
+    lat = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(11)) * 0.36
+    out, stats = {}, {}
+    for mode in ("conv3s", "default"):
+        if mode == "default":
+            monkeypatch.delenv("ECAD_VAE_CONV", raising=False)
+        else:
+            monkeypatch.setenv("ECAD_VAE_CONV", mode)
+        vae = HipVaeDecoder.random_init(3, device=0)
+        out[mode] = vae.decode_to_uint8(lat.cuda()).cpu()
+        stats[mode] = vae.decode_stats()
+        del vae
+    print(stats)
+    assert stats["conv3s"]["conv4_launches"] == 0 and stats["default"]["conv4_launches"] > 0
+    assert stats["default"]["conv_flops"] == stats["conv3s"]["conv_flops"]
+    if B == 16:
+        assert stats["default"]["conv4_launches"] == 32  # the 31 3 x 3 convolutions and the 512 -> 256 shortcut; the attention projections and the 256 -> 128 shortcut (four stages: not whole trips) stay on conv3s
+    assert int(out["default"].max()) - int(out["default"].min()) > 60
+    assert torch.equal(out["default"], out["conv3s"])
+
+
 def test_hip_flux_vae_geometry_matches_pytorch():
     """FLUX VAE: 16 latent channels, no post_quant_conv, z = latents / scaling + shift."""
     from ecad_amd.pipelines.vae_decoder import HipVaeDecoder

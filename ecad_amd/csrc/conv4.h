@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
     });
   });
   __syncthreads();
+  f32x2 ss[4], sq[4];   // GroupNorm partial sums of this lane's eight channels over its NPASS rows (p.gn_part), channel pairs on the packed fp32 pipe
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ss[e] = sq[e] = (f32x2){0.f, 0.f};
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     const int ml = pass * RPP + crow0;
@@ -113,8 +116,58 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
       v = pack8<T>(a);
     }
     gstore16(out + off0 + pass * pstep, v);
+    if (p.gn_part) {   // of the values as stored (rounded): what gn_stats_kernel would read back
+      float f[8];
+      unpack8<T>(v, f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 f2 = (f32x2){f[2 * e], f[2 * e + 1]};
+        ss[e] += f2;
+        sq[e] += f2 * f2;
+      }
+    }
+  }
+  if (p.gn_part) {
+    // fixed-order fold (gn_stats_kernel's scheme): every thread leaves (low half, high half) x (sum, sum of squares) of its chunk in LDS behind the C tile, thread
+    // t < groups-of-the-tile adds its group's partials in row order (all reads first: a chain of dependent LDS round trips per tile is time a one-wave-per-SIMD
+    // kernel cannot hide); one row of partials per 256-pixel tile, added in tile order by gn_finalize_kernel
+    f32x4* part = reinterpret_cast<f32x4*>(smem + 256 * CS * sizeof(T));
+    const f32x2 lo_s = ss[0] + ss[1], lo_q = sq[0] + sq[1], hi_s = ss[2] + ss[3], hi_q = sq[2] + sq[3];
+    part[tid] = (f32x4){lo_s[0] + lo_s[1], lo_q[0] + lo_q[1], hi_s[0] + hi_s[1], hi_q[0] + hi_q[1]};
+    __syncthreads();
+    const int cg = p.Cout >> 5;   // channels per group (32 groups): 4, 8 or 16
+    if (tid < BN / cg) {
+      const int gl = tid;
+      const int cc = cg == 4 ? gl >> 1 : gl * cg / 8;      // first (or only) chunk of the group
+      const bool two = cg == 16, upper = cg == 4 && (gl & 1);
+      f32x4 a[RPP], b[RPP];
+#pragma unroll
+      for (int r = 0; r < RPP; ++r) {
+        a[r] = part[r * CPR + cc];
+        b[r] = part[r * CPR + cc + (two ? 1 : 0)];
+      }
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPP; ++r) {
+        if (cg == 4) {
+          ts += upper ? a[r][2] : a[r][0];
+          tq += upper ? a[r][3] : a[r][1];
+        } else {
+          ts += a[r][0] + a[r][2];
+          tq += a[r][1] + a[r][3];
+          if (two) {
+            ts += b[r][0] + b[r][2];
+            tq += b[r][1] + b[r][3];
+          }
+        }
+      }
+      // tile tm = image b, tile (m0 % HW) / 256 of it: [b][tile][group][2] when HW % 256 == 0
+      *reinterpret_cast<f32x2*>(p.gn_part + ((size_t)tm * 32 + n0 / cg + gl) * 2) = (f32x2){ts, tq};
+    }
   }
 }
+constexpr int CONV4_PART_BYTES = 256 * 16;   // LDS behind the C tile for the GroupNorm fold
+template <int BN> constexpr int conv4_lds_bytes() { return (g4_lds_bytes<BN>() > 256 * (BN + 8) * 2 + CONV4_PART_BYTES) ? g4_lds_bytes<BN>() : 256 * (BN + 8) * 2 + CONV4_PART_BYTES; }
 
 // GroupNorm apply (+ SiLU) from plain [B H W][C] into the zero-bordered layout [B][H + 2][W + 2][C] a conv4_kernel reads; the border chunks are written as zeros here,
 // every time, so that the buffer carries no state from the geometry it held before

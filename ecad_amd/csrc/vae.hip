@@ -81,6 +81,9 @@ template <typename T> struct VaeT : VaeBase {
   bool async_failed = false;  // an asynchronous call inside a void helper failed: decode() turns it into ECAD_E_HIP
   int gn_blocks_cap = 0;  // per-block partial sums the GroupNorm statistics may write: sized by ensure_acts for the largest stage of the geometry it was given
   bool conv_tile128 = false;  // env ECAD_VAE_CONV=tile128: every convolution on the 128 x 128 kernel (A/B against conv3s_kernel)
+  bool gn_separate = false;   // env ECAD_VAE_GN=separate: GroupNorm statistics always by gn_stats_kernel (A/B and the byte-identity test against the conv3s path)
+  const void* stats_of = nullptr;  // the tensor whose per-tile GroupNorm partial sums a conv4_kernel epilogue left in gn_sums (conv4.h), or null
+  int stats_nblk = 0;
   bool conv_gather = false;   // env ECAD_VAE_CONV=conv3s: no conv4_kernel launches (the round-3 path: per-tap gathered A on eight waves; A/B and the byte-identity test)
   int num_cus = 256;
 
@@ -141,10 +144,11 @@ template <typename T> struct VaeT : VaeBase {
     REG("decoder.conv_out.weight", CONVOUT, 3, 128) REG("decoder.conv_out.bias", F32, 3, 0)
     VHIPCHK(hipFuncSetAttribute((const void*)conv_gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     VHIPCHK(hipFuncSetAttribute((const void*)conv3s_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES));
-    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<256>()));
-    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<128>()));
-    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<256>()));
-    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g4_lds_bytes<128>()));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<256>()));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<128>()));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<256>()));
+    VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<128>()));
+    if (const char* e = getenv("ECAD_VAE_GN")) gn_separate = strcmp(e, "separate") == 0;
     if (const char* e = getenv("ECAD_VAE_CONV")) { conv_tile128 = strcmp(e, "tile128") == 0; conv_gather = strcmp(e, "conv3s") == 0; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount;
@@ -207,7 +211,7 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipMalloc((void**)&bufD, bufD_elems * sizeof(T)));
     VHIPCHK(hipMalloc((void**)&bufP, (size_t)B * (8 * h + 2) * (8 * w + 2) * 256 * sizeof(T)));
     // per-block partial (sum, sum of squares) of the 32 groups: the largest stage has 64 h w pixels at 512 per block (group_norm_stats), the small ones at most 64 blocks
-    const size_t blocks_max = (64 * tokens + 511) / 512;
+    const size_t blocks_max = (64 * tokens + 255) / 256;   // gn_stats_kernel: 512 pixels per block at the largest stage; conv4_kernel's fused partials: one row per 256-pixel tile
     gn_blocks_cap = (int)(blocks_max > 64 ? blocks_max : 64);
     VHIPCHK(hipMalloc((void**)&gn_sums, (size_t)B * gn_blocks_cap * 64 * sizeof(float)));
     VHIPCHK(hipMalloc((void**)&gn_scale, (size_t)B * 512 * sizeof(float)));
@@ -235,12 +239,19 @@ template <typename T> struct VaeT : VaeBase {
     const int M = B * H * W;
     conv_flops += 2.0 * M * (double)cout * taps * cin;
     ++conv_launches;
+    if (stats_of == out) stats_of = nullptr;
     if (const int bn = (up || (taps == 9) != bordered) ? 0 : conv4_bn(M, cin, cout, taps)) {
       const dim3 grid((M / 256) * (cout / bn));
-      if (bn == 256 && resid) hipLaunchKernelGGL((conv4_kernel<T, 256, true>), grid, dim3(256), g4_lds_bytes<256>(), s, a);
-      else if (bn == 256) hipLaunchKernelGGL((conv4_kernel<T, 256, false>), grid, dim3(256), g4_lds_bytes<256>(), s, a);
-      else if (resid) hipLaunchKernelGGL((conv4_kernel<T, 128, true>), grid, dim3(256), g4_lds_bytes<128>(), s, a);
-      else hipLaunchKernelGGL((conv4_kernel<T, 128, false>), grid, dim3(256), g4_lds_bytes<128>(), s, a);
+      // every 3 x 3 convolution's output goes through a GroupNorm next: its statistics come out of this epilogue (per-tile partial sums in tile order)
+      if (taps == 9 && !gn_separate && (H * W) % 256 == 0 && (H * W) / 256 <= gn_blocks_cap && cout % 128 == 0) {
+        a.gn_part = gn_sums;
+        stats_of = out;
+        stats_nblk = (H * W) / 256;
+      }
+      if (bn == 256 && resid) hipLaunchKernelGGL((conv4_kernel<T, 256, true>), grid, dim3(256), conv4_lds_bytes<256>(), s, a);
+      else if (bn == 256) hipLaunchKernelGGL((conv4_kernel<T, 256, false>), grid, dim3(256), conv4_lds_bytes<256>(), s, a);
+      else if (resid) hipLaunchKernelGGL((conv4_kernel<T, 128, true>), grid, dim3(256), conv4_lds_bytes<128>(), s, a);
+      else hipLaunchKernelGGL((conv4_kernel<T, 128, false>), grid, dim3(256), conv4_lds_bytes<128>(), s, a);
       ++conv4_launches;
       return ECAD_OK;
     }
@@ -268,11 +279,16 @@ template <typename T> struct VaeT : VaeBase {
   }
   // statistics -> per-(image, channel) scale/shift in gn_scale / gn_shift
   void group_norm_stats(const T* x, const std::string& name, int B, int HW, int C, hipStream_t s) {
+    if (stats_of == x) {   // the convolution that wrote x left the partial sums (conv4.h): only the finalize pass is left
+      stats_of = nullptr;
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, gn_sums, stats_nblk, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
+      return;
+    }
     const int ppb = HW >= 16384 ? 512 : HW >= 4096 ? 256 : 64;
     const int nblk = (HW + ppb - 1) / ppb;
     if (nblk > gn_blocks_cap) { async_failed = true; return; }  // cannot happen for a geometry ensure_acts has sized the buffers for; decode() reports it
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nblk, B), dim3(256), 0, s, x, gn_sums, HW, C, 32, ppb);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, gn_sums, nblk, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, gn_sums, nblk, W_<float>(name + ".weight"), W_<float>(name + ".bias"), gn_scale, gn_shift, C, HW, 32, 1e-6f);
   }
   // GroupNorm + SiLU into the zero-bordered layout (conv4.h)
   void group_norm_bordered(const T* x, T* y, const std::string& name, int B, int H, int W, int C, hipStream_t s) {
@@ -283,6 +299,7 @@ template <typename T> struct VaeT : VaeBase {
   }
   void group_norm(const T* x, T* y, const std::string& name, int B, int HW, int C, bool act, hipStream_t s) {
     group_norm_stats(x, name, B, HW, C, s);
+    if (stats_of == y) stats_of = nullptr;
     const size_t chunks = (size_t)B * HW * (C / 8);
     const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
     if (act) hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(grid), dim3(256), 0, s, x, y, gn_scale, gn_shift, chunks, HW, C);
@@ -312,6 +329,7 @@ template <typename T> struct VaeT : VaeBase {
     int rc = ensure_acts(B, h, w);
     if (rc) return rc;
     conv_flops = 0; conv_launches = conv3s_launches = conv4_launches = 0;
+    stats_of = nullptr;
     T *x = bufA, *y = bufB, *t = bufC;
     int H = h, Wd = w;
     {

@@ -70,16 +70,27 @@ def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B
 
     lat = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(11)) * 0.36
     out, stats = {}, {}
-    for mode in ("conv3s", "default"):
-        if mode == "default":
-            monkeypatch.delenv("ECAD_VAE_CONV", raising=False)
-        else:
+    # the statistics of the GroupNorm behind a conv4 launch come out of its epilogue as per-tile partial sums -- another (fixed) order of the same fp32 additions than
+    # gn_stats_kernel's, so THAT is compared at one grey level below; byte identity is of the convolutions, with the statistics kernel kept (ECAD_VAE_GN=separate)
+    monkeypatch.setenv("ECAD_VAE_GN", "separate")
+    for mode in ("conv3s", "default", "fused", "fused-again"):
+        if mode == "fused":
+            monkeypatch.delenv("ECAD_VAE_GN", raising=False)
+        if mode == "conv3s":
             monkeypatch.setenv("ECAD_VAE_CONV", mode)
+        else:
+            monkeypatch.delenv("ECAD_VAE_CONV", raising=False)
         vae = HipVaeDecoder.random_init(3, device=0)
         out[mode] = vae.decode_to_uint8(lat.cuda()).cpu()
         stats[mode] = vae.decode_stats()
         del vae
     print(stats)
+    d = (out["fused"].int() - out["default"].int()).abs()
+    print(f"fused GroupNorm statistics vs gn_stats_kernel: {100 * float((d > 0).float().mean()):.4f} % of the bytes differ, max {int(d.max())} level")
+    assert torch.equal(out["fused"], out["fused-again"])
+    # measured: 7.5 % of the bytes move by one level, a handful by two (each order is within one level of the fp32 oracle) -- what ANY change of summation order does to
+    # this random-weight decoder (round 3 saw the same 7 % between two runs of its atomics)
+    assert int(d.max()) <= 2 and float(d.float().mean()) < 0.12
     assert stats["conv3s"]["conv4_launches"] == 0 and stats["default"]["conv4_launches"] > 0
     assert stats["default"]["conv_flops"] == stats["conv3s"]["conv_flops"]
     if B == 16:

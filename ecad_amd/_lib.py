@@ -163,7 +163,7 @@ SIGNATURES = {
     "ecad_vae_create_ex": (_I, [_I, _I, _I, _I, C.POINTER(_P)]),
     "ecad_vae_decode_ex": (_I, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P]),
     "ecad_vae_decode_stats": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I), C.POINTER(_I)]),
-    "ecad_vae_decode_stats_ex": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "ecad_vae_decode_stats_ex": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(C.c_double)]),
     # include/ecad_flux.h
     "ecad_flux_create": (_I, [C.POINTER(EcadFluxCfg), _I, C.POINTER(_P)]),
     "ecad_flux_destroy": (None, [_P]),

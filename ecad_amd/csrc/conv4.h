@@ -7,6 +7,11 @@
 // The M index still runs over the B H W real pixels (whole 256-row tiles, the same tile counts as conv3s), so a lane's eight DMA pieces have gathered byte offsets
 // (operands %[ao0..7] of the GEMM4_ASM_*G statements); outputs, residuals and 1 x 1 inputs stay plain [B H W][C].  K order per accumulator (row of taps, tap, channel,
 // fp32) and the epilogue arithmetic (bias in fp32, round, C tile through LDS, residual added to the rounded value, round) are conv3s_kernel's: the outputs are its bytes.
+//
+// Upsampler convolutions (p.up == 2, grid.y = 4 phases): conv3x3(nearest2x(x)) at output pixel (2 y + a, 2 x + b) reads only the 2 x 2 input pixels (y - 1 + a .. y + a,
+// x - 1 + b .. x + b), each through the SUM of the kernel taps that land on it -- four 2 x 2 convolutions over the low-resolution image with pre-summed weights
+// (vae_phase_weights_kernel: fp32 sums of the fp16 taps, rounded once), 4/9 of the multiplications and no upsampled image in memory.  Same function, another rounding
+// (weights summed before instead of products after): held to the oracle's tolerance, not to conv3s's bytes (ECAD_VAE_UP=nine keeps the nine-tap form).
 #pragma once
 #include "common.h"
 #include "gemm4.h"
@@ -34,7 +39,9 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = p.B * p.H * p.W;
+  const int phase = p.up == 2 ? blockIdx.y : 0, pa = phase >> 1, pb = phase & 1;
+  const int Hs = p.up == 2 ? p.H >> 1 : p.H, Ws = p.up == 2 ? p.W >> 1 : p.W;   // the image the M index runs over (low resolution for the phase form)
+  const int M = p.B * Hs * Ws;
   int tm, tn;
   {  // workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles: neighbours share their halo rows (and, along n, all their A rows) in that XCD's L2
     const int tiles_n = p.Cout / BN, nwg = (M / 256) * tiles_n;
@@ -45,10 +52,10 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
     tn = bid - tm * tiles_n;
   }
   const int m0 = tm * 256, n0 = tn * BN;
-  const int K = p.taps * p.Cin;
+  const int K = (p.up == 2 ? 4 : p.taps) * p.Cin;
   unsigned ao[8];
   {
-    const int HW = p.H * p.W, Wp = p.W + 2;
+    const int HW = Hs * Ws, Wp = Ws + 2;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int r = 8 * (8 * wave + q) + (lane >> 3);
@@ -57,16 +64,18 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
       unsigned pix = (unsigned)m;
       if (p.taps == 9) {
         const int b = m / HW, rem = m - b * HW;
-        const int y = rem / p.W, x = rem - y * p.W;
-        pix = (unsigned)((b * (p.H + 2) + y) * Wp + x);   // the pixel above-left of (y, x) in the bordered image: first tap of the first kernel row
+        const int y = rem / Ws, x = rem - y * Ws;
+        // the pixel above-left of (y, x) in the bordered image: first tap of the first kernel row (phase form: (y - 1 + a, x - 1 + b) of the low-resolution image)
+        pix = (unsigned)((b * (Hs + 2) + y + pa) * Wp + x + pb);
       }
       ao[q] = pix * (unsigned)(p.Cin * 2) + (unsigned)(c * 16);
     }
   }
-  const unsigned seg = p.taps == 9 ? (unsigned)(3 * p.Cin / 64) : 0x7fffffffu;
-  const unsigned jump = p.taps == 9 ? (unsigned)((p.W + 2 - 3) * p.Cin * 2 + 128) : 128u;
+  const int kw = p.up == 2 ? 2 : 3;   // pixels per kernel row
+  const unsigned seg = p.taps == 9 ? (unsigned)(kw * p.Cin / 64) : 0x7fffffffu;
+  const unsigned jump = p.taps == 9 ? (unsigned)((Ws + 2 - kw) * p.Cin * 2 + 128) : 128u;
   constexpr int period = G4Period<T, BN>::value;
-  conv4_statement<T, BN>(reinterpret_cast<const char*>(p.in), reinterpret_cast<const char*>(p.w) + (size_t)n0 * K * sizeof(T), (unsigned)(K * sizeof(T)),
+  conv4_statement<T, BN>(reinterpret_cast<const char*>(p.in), reinterpret_cast<const char*>(p.w) + ((size_t)phase * p.Cout + n0) * K * sizeof(T), (unsigned)(K * sizeof(T)),
                          (unsigned)(K / 64 / period - 1), __builtin_amdgcn_readfirstlane(lds_offset(smem)), (unsigned)wave, seg, jump, ao);
 
   // epilogue of conv3s_kernel on this wave geometry (2 x 2 waves of 128 x BN/2): the statement ends behind a barrier, the ring is free
@@ -78,6 +87,14 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
   const T* res = reinterpret_cast<const T*>(p.resid);
   const size_t off0 = (size_t)(m0 + crow0) * p.Cout + n0 + cchunk * 8;
   const size_t pstep = (size_t)RPP * p.Cout;
+  int ub = 0, uy = 0, ux = 0;   // phase form: low-resolution pixel of this thread's row of the current pass
+  if (p.up == 2) {
+    const int m = m0 + crow0, HW = Hs * Ws;
+    ub = m / HW;
+    const int rem = m - ub * HW;
+    uy = rem / Ws;
+    ux = rem - uy * Ws;
+  }
   Pack8 rv[RES ? NPASS : 1];
   if constexpr (RES) {
 #pragma unroll
@@ -115,7 +132,14 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
       for (int e = 0; e < 8; ++e) a[e] += b[e];
       v = pack8<T>(a);
     }
-    gstore16(out + off0 + pass * pstep, v);
+    if (p.up == 2) {
+      gstore16(out + ((size_t)(ub * p.H + 2 * uy + pa) * p.W + 2 * ux + pb) * p.Cout + n0 + cchunk * 8, v);
+      ux += RPP;
+      while (ux >= Ws) { ux -= Ws; ++uy; }
+      if (uy >= Hs) { uy -= Hs; ++ub; }
+    } else {
+      gstore16(out + off0 + pass * pstep, v);
+    }
     if (p.gn_part) {   // of the values as stored (rounded): what gn_stats_kernel would read back
       float f[8];
       unpack8<T>(v, f);
@@ -161,8 +185,13 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
           }
         }
       }
-      // tile tm = image b, tile (m0 % HW) / 256 of it: [b][tile][group][2] when HW % 256 == 0
-      *reinterpret_cast<f32x2*>(p.gn_part + ((size_t)tm * 32 + n0 / cg + gl) * 2) = (f32x2){ts, tq};
+      // tile tm = image b, tile (m0 % HW) / 256 of it: [b][tile][group][2] when HW % 256 == 0; phase form: [b][phase][tile of the low-resolution image]
+      size_t row = (size_t)tm;
+      if (p.up == 2) {
+        const int tpi = (Hs * Ws) >> 8, b = tm / tpi;
+        row = ((size_t)b * 4 + phase) * tpi + (tm - b * tpi);
+      }
+      *reinterpret_cast<f32x2*>(p.gn_part + (row * 32 + n0 / cg + gl) * 2) = (f32x2){ts, tq};
     }
   }
 }
@@ -203,10 +232,11 @@ __global__ __launch_bounds__(256) void gn_apply_pad_kernel(const T* __restrict__
   }
 }
 
-// nearest-2x upsample of plain [B][H/2][W/2][C] into the zero-bordered [B][H + 2][W + 2][C] (H, W: the upsampled size) in front of an upsampler's conv4_kernel
+// plain [B][H >> sh][W >> sh][C] into the zero-bordered [B][H + 2][W + 2][C]: sh = 1, the nearest-2x upsampled image in front of an upsampler's nine-tap conv4_kernel;
+// sh = 0, a bordered copy in front of its phase form
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_pad_kernel(const T* __restrict__ x, T* __restrict__ y, size_t total_chunks, int H, int W, int C) {
-  const int cpr = C >> 3, Wp = W + 2, HWp = (H + 2) * Wp, Hin = H >> 1, Win = W >> 1;
+__global__ __launch_bounds__(256) void upsample_pad_kernel(const T* __restrict__ x, T* __restrict__ y, size_t total_chunks, int H, int W, int C, int sh) {
+  const int cpr = C >> 3, Wp = W + 2, HWp = (H + 2) * Wp, Hin = H >> sh, Win = W >> sh;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_chunks; idx += (size_t)gridDim.x * 256) {
     const size_t pp = idx / cpr;
     const int c = (int)(idx - pp * cpr) * 8;
@@ -215,8 +245,26 @@ __global__ __launch_bounds__(256) void upsample_pad_kernel(const T* __restrict__
     const int yy = rem / Wp, xx = rem - yy * Wp;
     Pack8 o;
     o.u = (u32x4){0u, 0u, 0u, 0u};
-    if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) o = gload16(x + (((size_t)b * Hin + ((yy - 1) >> 1)) * Win + ((xx - 1) >> 1)) * C + c);
+    if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) o = gload16(x + (((size_t)b * Hin + ((yy - 1) >> sh)) * Win + ((xx - 1) >> sh)) * C + c);
     gstore16(y + idx * 8, o);
+  }
+}
+
+// w9: [Cout][3][3][Cin] -> w4: [phase = 2 a + b][Cout][2][2][Cin]: tap row r of phase a sums kernel rows {0} / {1, 2} (a = 0) or {0, 1} / {2} (a = 1), columns likewise
+template <typename T>
+__global__ void vae_phase_weights_kernel(const T* __restrict__ w9, T* __restrict__ w4, int Cout, int Cin) {
+  const size_t n = (size_t)4 * Cout * 4 * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int t = (int)((i / Cin) % 4), r = t >> 1, c = t & 1;
+    const int co = (int)((i / ((size_t)4 * Cin)) % Cout);
+    const int ph = (int)(i / ((size_t)4 * Cin * Cout)), a = ph >> 1, b = ph & 1;
+    const int ky0 = a == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), ky1 = a == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+    const int kx0 = b == 0 ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2), kx1 = b == 0 ? (c == 0 ? 0 : 2) : (c == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) acc += (float)w9[((size_t)co * 9 + ky * 3 + kx) * Cin + ci];
+    w4[i] = (T)acc;
   }
 }
 

@@ -62,6 +62,7 @@ struct VaeBase {
   virtual int decode(const float* lat, int B, int h, int w, float scaling, float shift, uint8_t* out, hipStream_t s) = 0;
   // roofline accounting of the last decode: flops of its convolution GEMMs (2 M Cout taps Cin each) and how many of them ran on the 256 x 128 / 3-stage kernel
   double conv_flops = 0;
+  double conv_flops_exec = 0;  // what the launches multiplied: below conv_flops when the upsampler convolutions ran in their four-phase 2 x 2 form (conv4.h)
   int conv_launches = 0, conv3s_launches = 0, conv4_launches = 0;
 };
 
@@ -69,6 +70,7 @@ template <typename T> struct VaeT : VaeBase {
   enum Kind { F32, CONV3, LIN, CONVOUT };
   struct W { void* ptr; Kind kind; int cout, cin; size_t numel; bool loaded; };
   std::map<std::string, W> wt;
+  std::map<std::string, void*> phase_w;  // upsampler convolutions: pre-summed 2 x 2 weights of the four output phases (conv4.h)
   std::vector<void*> allocs;
   void* zero_page = nullptr;
   // activation buffers
@@ -81,6 +83,7 @@ template <typename T> struct VaeT : VaeBase {
   bool async_failed = false;  // an asynchronous call inside a void helper failed: decode() turns it into ECAD_E_HIP
   int gn_blocks_cap = 0;  // per-block partial sums the GroupNorm statistics may write: sized by ensure_acts for the largest stage of the geometry it was given
   bool conv_tile128 = false;  // env ECAD_VAE_CONV=tile128: every convolution on the 128 x 128 kernel (A/B against conv3s_kernel)
+  bool up_nine = false;       // env ECAD_VAE_UP=nine: upsampler convolutions as nine taps over the materialised upsampled image (A/B against the phase form)
   bool gn_separate = false;   // env ECAD_VAE_GN=separate: GroupNorm statistics always by gn_stats_kernel (A/B and the byte-identity test against the conv3s path)
   const void* stats_of = nullptr;  // the tensor whose per-tile GroupNorm partial sums a conv4_kernel epilogue left in gn_sums (conv4.h), or null
   int stats_nblk = 0;
@@ -137,7 +140,14 @@ template <typename T> struct VaeT : VaeBase {
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 3; ++j)
         if ((rc = reg_resnet("decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", j == 0 ? prev : chans[i], chans[i]))) return rc;
-      if (i < 3) { REG("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.weight", CONV3, chans[i], chans[i]) REG("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.bias", F32, chans[i], 0) }
+      if (i < 3) {
+        const std::string un = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
+        REG(un + "weight", CONV3, chans[i], chans[i]) REG(un + "bias", F32, chans[i], 0)
+        void* ph = nullptr;   // [4 phases][Cout][2][2][Cin]: filled by load() from the relaid-out nine-tap weight
+        VHIPCHK(hipMalloc(&ph, (size_t)16 * chans[i] * chans[i] * sizeof(T)));
+        allocs.push_back(ph);
+        phase_w[un + "weight"] = ph;
+      }
       prev = chans[i];
     }
     REG("decoder.conv_norm_out.weight", F32, 128, 0) REG("decoder.conv_norm_out.bias", F32, 128, 0)
@@ -148,6 +158,7 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<128>()));
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<256>()));
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<128>()));
+    if (const char* e = getenv("ECAD_VAE_UP")) up_nine = strcmp(e, "nine") == 0;
     if (const char* e = getenv("ECAD_VAE_GN")) gn_separate = strcmp(e, "separate") == 0;
     if (const char* e = getenv("ECAD_VAE_CONV")) { conv_tile128 = strcmp(e, "tile128") == 0; conv_gather = strcmp(e, "conv3s") == 0; }
     hipDeviceProp_t prop;
@@ -177,7 +188,11 @@ template <typename T> struct VaeT : VaeBase {
   if (dtype == ECAD_DTYPE_F16) hipLaunchKernelGGL((KERNEL<f16_t, DST>), dim3(grid), dim3(256), 0, 0, (const f16_t*)stage, (DST*)w.ptr, __VA_ARGS__);   \
   else if (dtype == ECAD_DTYPE_BF16) hipLaunchKernelGGL((KERNEL<bf16_t, DST>), dim3(grid), dim3(256), 0, 0, (const bf16_t*)stage, (DST*)w.ptr, __VA_ARGS__); \
   else hipLaunchKernelGGL((KERNEL<float, DST>), dim3(grid), dim3(256), 0, 0, (const float*)stage, (DST*)w.ptr, __VA_ARGS__);
-    if (w.kind == CONV3) { DISPATCH(vae_relayout_kernel, T, w.cout, w.cin, 9) }
+    if (w.kind == CONV3) {
+      DISPATCH(vae_relayout_kernel, T, w.cout, w.cin, 9)
+      auto ph = phase_w.find(name);
+      if (ph != phase_w.end()) hipLaunchKernelGGL((vae_phase_weights_kernel<T>), dim3(4096), dim3(256), 0, 0, (const T*)w.ptr, (T*)ph->second, w.cout, w.cin);
+    }
     else if (w.kind == CONVOUT) { DISPATCH(vae_relayout_kernel, T, w.cout, w.cin, 9) }
     else if (w.kind == LIN) { DISPATCH(vae_convert_kernel, T, (size_t)numel) }
     else { DISPATCH(vae_convert_kernel, float, (size_t)numel) }
@@ -238,6 +253,7 @@ template <typename T> struct VaeT : VaeBase {
     a.resid = resid; a.out = out; a.zero_page = zero_page; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = taps; a.up = up;
     const int M = B * H * W;
     conv_flops += 2.0 * M * (double)cout * taps * cin;
+    conv_flops_exec += 2.0 * M * (double)cout * taps * cin;
     ++conv_launches;
     if (stats_of == out) stats_of = nullptr;
     if (const int bn = (up || (taps == 9) != bordered) ? 0 : conv4_bn(M, cin, cout, taps)) {
@@ -273,6 +289,7 @@ template <typename T> struct VaeT : VaeBase {
     a.in = in; a.w = w; a.out = out; a.zero_page = zero_page; a.B = 1; a.H = M; a.W = 1; a.Cin = K; a.Cout = N; a.taps = 1;
     a.bs_in = bs_in; a.bs_w = bs_w; a.bs_out = bs_out;
     conv_flops += 2.0 * nb * M * (double)N * K;
+    conv_flops_exec += 2.0 * nb * M * (double)N * K;
     ++conv_launches;
     hipLaunchKernelGGL((conv_gemm_kernel<T>), dim3(((M + 127) / 128) * (N / 128), nb), dim3(256), 65536, s, a);
     return ECAD_OK;
@@ -328,7 +345,7 @@ template <typename T> struct VaeT : VaeBase {
     if (B < 1 || h < 4 || w < 4 || (h * w) % 128 || (w & 1)) return fail(ECAD_E_INVALID, "latent %dx%dx%d unsupported (h*w must be a multiple of 128, w even)", B, h, w);
     int rc = ensure_acts(B, h, w);
     if (rc) return rc;
-    conv_flops = 0; conv_launches = conv3s_launches = conv4_launches = 0;
+    conv_flops = conv_flops_exec = 0; conv_launches = conv3s_launches = conv4_launches = 0;
     stats_of = nullptr;
     T *x = bufA, *y = bufB, *t = bufC;
     int H = h, Wd = w;
@@ -384,10 +401,26 @@ template <typename T> struct VaeT : VaeBase {
       if (i < 3) {
         H *= 2; Wd *= 2;
         const std::string un = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
-        if (conv4_bn(B * H * Wd, chans[i], chans[i], 9)) {  // the upsampled image is written out (bordered) and the convolution runs on conv4_kernel
+        const int Ml = B * (H / 2) * (Wd / 2), c = chans[i];
+        if (!up_nine && !conv_tile128 && !conv_gather && Ml % 256 == 0 && c % 256 == 0 && (4 * c / 64) % G4Period<T, 256>::value == 0 && (Ml / 256) * (c / 256) * 4 >= num_cus) {
+          // four 2 x 2 convolutions over the bordered low-resolution image, one per output phase (conv4.h): 4/9 of the nine-tap form's multiplications
+          const size_t chunks = (size_t)B * (H / 2 + 2) * (Wd / 2 + 2) * (c / 8);
+          const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+          hipLaunchKernelGGL((upsample_pad_kernel<T>), dim3(grid), dim3(256), 0, s, cur, bufP, chunks, H / 2, Wd / 2, c, 0);
+          ConvArgs a{};
+          a.in = bufP; a.w = phase_w.at(un + ".weight"); a.bias = W_<float>(un + ".bias"); a.out = oth; a.zero_page = zero_page;
+          a.B = B; a.H = H; a.W = Wd; a.Cin = c; a.Cout = c; a.taps = 9; a.up = 2;
+          if (stats_of == oth) stats_of = nullptr;
+          const int HWl = (H / 2) * (Wd / 2);
+          if (!gn_separate && HWl % 256 == 0 && 4 * (HWl / 256) <= gn_blocks_cap) { a.gn_part = gn_sums; stats_of = oth; stats_nblk = 4 * (HWl / 256); }
+          conv_flops += 2.0 * B * H * Wd * (double)c * 9 * c;
+          conv_flops_exec += 2.0 * B * H * Wd * (double)c * 4 * c;
+          ++conv_launches; ++conv4_launches;
+          hipLaunchKernelGGL((conv4_kernel<T, 256, false>), dim3((Ml / 256) * (c / 256), 4), dim3(256), conv4_lds_bytes<256>(), s, a);
+        } else if (conv4_bn(B * H * Wd, chans[i], chans[i], 9)) {  // the upsampled image is written out (bordered) and the convolution runs on conv4_kernel
           const size_t chunks = (size_t)B * (H + 2) * (Wd + 2) * (chans[i] / 8);
           const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
-          hipLaunchKernelGGL((upsample_pad_kernel<T>), dim3(grid), dim3(256), 0, s, cur, bufP, chunks, H, Wd, chans[i]);
+          hipLaunchKernelGGL((upsample_pad_kernel<T>), dim3(grid), dim3(256), 0, s, cur, bufP, chunks, H, Wd, chans[i], 1);
           if ((rc = conv(bufP, un, oth, nullptr, B, H, Wd, chans[i], chans[i], 9, 0, s, nullptr, nullptr, false, true))) return rc;
         } else if ((rc = conv(cur, un, oth, nullptr, B, H, Wd, chans[i], chans[i], 9, 1, s))) return rc;
         std::swap(cur, oth);
@@ -446,9 +479,10 @@ int ecad_vae_decode_stats(const EcadVae* v, double* conv_flops, int* conv_launch
   if (conv3s_launches) *conv3s_launches = v->impl->conv3s_launches;
   return ECAD_OK;
 }
-int ecad_vae_decode_stats_ex(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches, int* conv4_launches) {
+int ecad_vae_decode_stats_ex(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches, int* conv4_launches, double* conv_flops_executed) {
   if (!v) return ECAD_E_INVALID;
   if (conv4_launches) *conv4_launches = v->impl->conv4_launches;
+  if (conv_flops_executed) *conv_flops_executed = v->impl->conv_flops_exec;
   return ecad_vae_decode_stats(v, conv_flops, conv_launches, conv3s_launches);
 }
 int ecad_vae_decode_ex(EcadVae* v, const float* latents_dev, int B, int h, int w, float scaling_factor, float shift_factor, uint8_t* out_u8_dev, void* stream) {

@@ -122,9 +122,10 @@ class HipVaeDecoder:
         """Roofline accounting of the last decode: flops of its convolution GEMMs, their launch count, how many ran on the 256 x 128 / 3-stage kernel
         (`conv3s_kernel`) and how many on the generated four-wave K loop over the zero-bordered layout (`conv4_kernel`)."""
         C = self._C
-        fl, n, n3, n4 = C.c_double(0), C.c_int(0), C.c_int(0), C.c_int(0)
-        self._chk(self.lib.ecad_vae_decode_stats_ex(self._h, C.byref(fl), C.byref(n), C.byref(n3), C.byref(n4)))
-        return {"conv_flops": fl.value, "conv_launches": n.value, "conv3s_launches": n3.value, "conv4_launches": n4.value}
+        fl, n, n3, n4, fx = C.c_double(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_double(0)
+        self._chk(self.lib.ecad_vae_decode_stats_ex(self._h, C.byref(fl), C.byref(n), C.byref(n3), C.byref(n4), C.byref(fx)))
+        # conv_flops: the reference's arithmetic (nine taps per 3 x 3 convolution); conv_flops_executed: what the launches multiplied (upsamplers in their phase form)
+        return {"conv_flops": fl.value, "conv_launches": n.value, "conv3s_launches": n3.value, "conv4_launches": n4.value, "conv_flops_executed": fx.value}
 
     def decode_to_uint8(self, latents: torch.Tensor, stream=None) -> torch.Tensor:
         """latents: [B, latent_channels, h, w] (un-scaled pipeline latents) -> uint8 [B, 8h, 8w, 3] on the device."""

@@ -296,8 +296,10 @@ int ecad_vae_decode_ex(EcadVae* v, const float* latents_dev, int B, int h, int w
 /* Roofline accounting of the last ecad_vae_decode*: flops of its convolution GEMMs (2 M Cout taps Cin per launch: the implicit-GEMM view of the 3x3 / 1x1
  * convolutions behind vae.decode, pass_through.py:382-396), their launch count, and how many ran on the 256 x 128 / 3-stage kernel (any pointer may be NULL). */
 int ecad_vae_decode_stats(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches);
-/* ABI 7: the same, plus how many of the launches ran on the one-wave-per-SIMD generated K loop over the zero-bordered layout (conv4_kernel, csrc/conv4.h). */
-int ecad_vae_decode_stats_ex(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches, int* conv4_launches);
+/* ABI 7: the same, plus how many of the launches ran on the one-wave-per-SIMD generated K loop over the zero-bordered layout (conv4_kernel, csrc/conv4.h), and
+ * the flops the launches actually multiplied: conv_flops stays the reference's arithmetic (nine taps per 3x3 convolution); the upsampler convolutions run as four
+ * 2 x 2 convolutions with pre-summed weights (4/9 of their nine-tap multiplications), so conv_flops_executed <= conv_flops. */
+int ecad_vae_decode_stats_ex(const EcadVae* v, double* conv_flops, int* conv_launches, int* conv3s_launches, int* conv4_launches, double* conv_flops_executed);
 
 #ifdef __cplusplus
 }

@@ -22,4 +22,4 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 st = vae.decode_stats()
-print(f"B {B}: {ms:.3f} ms per decode, {st['conv_flops'] / ms / 1e9:.0f} TFLOP/s over the whole decode; {st}")
+print(f"B {B}: {ms:.3f} ms per decode, {st['conv_flops'] / ms / 1e9:.0f} TFLOP/s of the reference's arithmetic ({st['conv_flops_executed'] / ms / 1e9:.0f} executed) over the whole decode; {st}")

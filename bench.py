@@ -799,10 +799,14 @@ def main():
             torch.cuda.synchronize()
             dec_ms = ev0.elapsed_time(ev1) / 5
             vs = vae.decode_stats()
+            # "achieved" prices the multiplications the launches EXECUTED (the upsampler convolutions run as four 2 x 2 phase convolutions with pre-summed weights: 4/9 of
+            # their nine-tap work); the reference's own arithmetic (nine taps everywhere) over the same time is reported beside it, not as the roofline fraction
             res["decode_tail"] = {
-                "device_ms_per_batch": dec_ms, "conv_launches": vs["conv_launches"], "conv3s_launches": vs["conv3s_launches"], "conv4_launches": vs["conv4_launches"], "conv_flops_per_batch": vs["conv_flops"],
-                "roofline": {"bound": "mfma", "kernel": "conv3s_kernel + conv_gemm_kernel (implicit-GEMM convolutions of the AutoencoderKL decoder; GroupNorm / SiLU / upsample time included in the denominator)",
-                             "achieved": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
+                "device_ms_per_batch": dec_ms, "conv_launches": vs["conv_launches"], "conv3s_launches": vs["conv3s_launches"], "conv4_launches": vs["conv4_launches"],
+                "conv_flops_per_batch": vs["conv_flops"], "conv_flops_executed_per_batch": vs["conv_flops_executed"],
+                "reference_arithmetic_tflops": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12,
+                "roofline": {"bound": "mfma", "kernel": "conv4_kernel (+ conv3s_kernel / conv_gemm_kernel for the small launches): implicit-GEMM convolutions of the AutoencoderKL decoder; GroupNorm / SiLU / border-copy time included in the denominator",
+                             "achieved": vs["conv_flops_executed"] / (dec_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": vs["conv_flops_executed"] / (dec_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
             }
             res["config"]["decode_tail_ms_per_batch"] = 1000.0 * (dt - dt_lat)  # against one batch at a time on the same context
             res["config"]["decode_tail"] = "HIP AutoencoderKL decoder (ecad_vae_decode, random-init SD-VAE geometry) -> uint8 NHWC -> host -> PIL; the reference's 84.09 ms/image (A6000) includes this tail"

@@ -19,9 +19,21 @@
 
 namespace ecad {
 
+// the statement takes its pointers in SGPRs: pin what the compiler may have computed per lane (tile coordinates are workgroup-uniform, hipcc does not always see it)
+ECAD_DEV const char* conv4_uniform(const char* ptr) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
 template <typename T, int BN> ECAD_DEV void conv4_statement(const char* ap, const char* wp, unsigned rsw, unsigned trips, unsigned lds, unsigned wave, unsigned seg,
                                                             unsigned jump, const unsigned (&ao)[8]) {
   const unsigned zero = 1u;
+  ap = conv4_uniform(ap);
+  wp = conv4_uniform(wp);
+  rsw = __builtin_amdgcn_readfirstlane(rsw);
+  trips = __builtin_amdgcn_readfirstlane(trips);
+  seg = __builtin_amdgcn_readfirstlane(seg);
+  jump = __builtin_amdgcn_readfirstlane(jump);
   if constexpr (std::is_same<T, bf16_t>::value && BN == 256) { GEMM4_ASM_BF16_256G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
   else if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_128G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
   else if constexpr (BN == 256) { GEMM4_ASM_F16_256G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
@@ -52,32 +64,59 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
     tn = bid - tm * tiles_n;
   }
   const int m0 = tm * 256, n0 = tn * BN;
+  // p.tile2d: the 256 rows of a tile are a 16 x 16 patch of one image (row r = pixel (ty0 + r / 16, tx0 + r % 16)) instead of 256 consecutive pixels: 18 x 18 input
+  // pixels under the nine taps instead of 3 (or 4, 6) whole image rows -- 2.4x fewer distinct A bytes per tile at W = 256 for the L2 to keep
+  int tb = 0, ty0 = 0, tx0 = 0;
+  if (p.tile2d) {
+    const int tiles_x = Ws >> 4, tpi = (Hs >> 4) * tiles_x;
+    tb = tm / tpi;
+    const int t = tm - tb * tpi, trow = t / tiles_x;
+    ty0 = trow << 4;
+    tx0 = (t - trow * tiles_x) << 4;
+  }
   const int K = (p.up == 2 ? 4 : p.taps) * p.Cin;
   unsigned ao[8];
   {
+    // rows 8 (8 wave + q) + (lane >> 3), q = 0..7: one division pair for q = 0, then eight rows further per piece (two integer divisions per piece were 1.5 us of
+    // a 22 us tile on the 18-stage convolutions)
     const int HW = Hs * Ws, Wp = Ws + 2;
+    const int r0 = 64 * wave + (lane >> 3);
+    int b = tb, y = 0, x = 0;
+    if (p.taps == 9 && !p.tile2d) {
+      const int m = m0 + r0;
+      b = m / HW;
+      const int rem = m - b * HW;
+      y = rem / Ws;
+      x = rem - y * Ws;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int r = 8 * (8 * wave + q) + (lane >> 3);
-      const int m = m0 + r;
+      const int r = r0 + 8 * q;
       const int c = (lane & 7) ^ ((r >> 1) & 7);
-      unsigned pix = (unsigned)m;
-      if (p.taps == 9) {
-        const int b = m / HW, rem = m - b * HW;
-        const int y = rem / Ws, x = rem - y * Ws;
-        // the pixel above-left of (y, x) in the bordered image: first tap of the first kernel row (phase form: (y - 1 + a, x - 1 + b) of the low-resolution image)
-        pix = (unsigned)((b * (Hs + 2) + y + pa) * Wp + x + pb);
-      }
+      if (p.tile2d) { y = ty0 + (r >> 4); x = tx0 + (r & 15); }
+      // 3 x 3: the pixel above-left of (y, x) in the bordered image, first tap of the first kernel row (phase form: (y - 1 + a, x - 1 + b) of the low-resolution image)
+      const unsigned pix = p.taps == 9 ? (unsigned)((b * (Hs + 2) + y + pa) * Wp + x + pb) : (unsigned)(m0 + r);
       ao[q] = pix * (unsigned)(p.Cin * 2) + (unsigned)(c * 16);
+      if (!p.tile2d) {
+        x += 8;
+        while (x >= Ws) { x -= Ws; ++y; }
+        if (y >= Hs) { y -= Hs; ++b; }
+      }
     }
   }
   const int kw = p.up == 2 ? 2 : 3;   // pixels per kernel row
   const unsigned seg = p.taps == 9 ? (unsigned)(kw * p.Cin / 64) : 0x7fffffffu;
   const unsigned jump = p.taps == 9 ? (unsigned)((Ws + 2 - kw) * p.Cin * 2 + 128) : 128u;
   constexpr int period = G4Period<T, BN>::value;
-  conv4_statement<T, BN>(reinterpret_cast<const char*>(p.in), reinterpret_cast<const char*>(p.w) + ((size_t)phase * p.Cout + n0) * K * sizeof(T), (unsigned)(K * sizeof(T)),
+#ifdef CONV4_PROBE_NO_LOOP
+  if (p.bias == reinterpret_cast<const float*>(8))
+#endif
+  conv4_statement<T, BN>(reinterpret_cast<const char*>(p.in), conv4_uniform(reinterpret_cast<const char*>(p.w) + ((size_t)phase * p.Cout + n0) * K * sizeof(T)), (unsigned)(K * sizeof(T)),
                          (unsigned)(K / 64 / period - 1), __builtin_amdgcn_readfirstlane(lds_offset(smem)), (unsigned)wave, seg, jump, ao);
 
+#ifdef CONV4_PROBE_NO_EPILOGUE   // scripts/probe_conv4.hip only (timing of the tile's phases; the product build never defines it)
+  if (p.bias != reinterpret_cast<const float*>(8)) return;
+#endif
   // epilogue of conv3s_kernel on this wave geometry (2 x 2 waves of 128 x BN/2): the statement ends behind a barrier, the ring is free
   const int wm = wave & 1, wn = wave >> 1;
   const int l15 = lane & 15, g = lane >> 4;
@@ -85,20 +124,37 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
   const int cchunk = tid % CPR, crow0 = tid / CPR;
   T* out = reinterpret_cast<T*>(p.out);
   const T* res = reinterpret_cast<const T*>(p.resid);
-  const size_t off0 = (size_t)(m0 + crow0) * p.Cout + n0 + cchunk * 8;
-  const size_t pstep = (size_t)RPP * p.Cout;
-  int ub = 0, uy = 0, ux = 0;   // phase form: low-resolution pixel of this thread's row of the current pass
-  if (p.up == 2) {
+  // element offset of this thread's chunk of tile row ml = pass * RPP + crow0 in the plain [B][H][W][Cout] output (and residual)
+  int ub = 0, uy = 0, ux = 0;   // phase form on consecutive pixels: low-resolution pixel of this thread's row of the current pass
+  if (p.up == 2 && !p.tile2d) {
     const int m = m0 + crow0, HW = Hs * Ws;
     ub = m / HW;
     const int rem = m - ub * HW;
     uy = rem / Ws;
     ux = rem - uy * Ws;
   }
+  size_t ooff[NPASS];
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int ml = pass * RPP + crow0;
+    size_t pix;
+    if (p.tile2d) {
+      const int y = ty0 + (ml >> 4), x = tx0 + (ml & 15);
+      pix = p.up == 2 ? (size_t)(tb * p.H + 2 * y + pa) * p.W + 2 * x + pb : (size_t)(tb * Hs + y) * Ws + x;
+    } else if (p.up == 2) {
+      pix = (size_t)(ub * p.H + 2 * uy + pa) * p.W + 2 * ux + pb;
+      ux += RPP;
+      while (ux >= Ws) { ux -= Ws; ++uy; }
+      if (uy >= Hs) { uy -= Hs; ++ub; }
+    } else {
+      pix = (size_t)(m0 + ml);
+    }
+    ooff[pass] = pix * p.Cout + n0 + cchunk * 8;
+  }
   Pack8 rv[RES ? NPASS : 1];
   if constexpr (RES) {
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) rv[pass] = gload16(res + off0 + pass * pstep);
+    for (int pass = 0; pass < NPASS; ++pass) rv[pass] = gload16(res + ooff[pass]);
   }
   T* ctile = reinterpret_cast<T*>(smem);
   static_for<FN>([&](auto jc) {
@@ -132,14 +188,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
       for (int e = 0; e < 8; ++e) a[e] += b[e];
       v = pack8<T>(a);
     }
-    if (p.up == 2) {
-      gstore16(out + ((size_t)(ub * p.H + 2 * uy + pa) * p.W + 2 * ux + pb) * p.Cout + n0 + cchunk * 8, v);
-      ux += RPP;
-      while (ux >= Ws) { ux -= Ws; ++uy; }
-      if (uy >= Hs) { uy -= Hs; ++ub; }
-    } else {
-      gstore16(out + off0 + pass * pstep, v);
-    }
+    gstore16(out + ooff[pass], v);
     if (p.gn_part) {   // of the values as stored (rounded): what gn_stats_kernel would read back
       float f[8];
       unpack8<T>(v, f);

@@ -83,6 +83,7 @@ template <typename T> struct VaeT : VaeBase {
   bool async_failed = false;  // an asynchronous call inside a void helper failed: decode() turns it into ECAD_E_HIP
   int gn_blocks_cap = 0;  // per-block partial sums the GroupNorm statistics may write: sized by ensure_acts for the largest stage of the geometry it was given
   bool conv_tile128 = false;  // env ECAD_VAE_CONV=tile128: every convolution on the 128 x 128 kernel (A/B against conv3s_kernel)
+  bool tile_linear = false;   // env ECAD_VAE_TILE=linear: conv4_kernel's M tiles as 256 consecutive pixels instead of 16 x 16 patches (A/B)
   bool up_nine = false;       // env ECAD_VAE_UP=nine: upsampler convolutions as nine taps over the materialised upsampled image (A/B against the phase form)
   bool gn_separate = false;   // env ECAD_VAE_GN=separate: GroupNorm statistics always by gn_stats_kernel (A/B and the byte-identity test against the conv3s path)
   const void* stats_of = nullptr;  // the tensor whose per-tile GroupNorm partial sums a conv4_kernel epilogue left in gn_sums (conv4.h), or null
@@ -158,6 +159,7 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<128>()));
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<256>()));
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<128>()));
+    if (const char* e = getenv("ECAD_VAE_TILE")) tile_linear = strcmp(e, "linear") == 0;
     if (const char* e = getenv("ECAD_VAE_UP")) up_nine = strcmp(e, "nine") == 0;
     if (const char* e = getenv("ECAD_VAE_GN")) gn_separate = strcmp(e, "separate") == 0;
     if (const char* e = getenv("ECAD_VAE_CONV")) { conv_tile128 = strcmp(e, "tile128") == 0; conv_gather = strcmp(e, "conv3s") == 0; }
@@ -258,6 +260,7 @@ template <typename T> struct VaeT : VaeBase {
     if (stats_of == out) stats_of = nullptr;
     if (const int bn = (up || (taps == 9) != bordered) ? 0 : conv4_bn(M, cin, cout, taps)) {
       const dim3 grid((M / 256) * (cout / bn));
+      a.tile2d = taps == 9 && !tile_linear && H % 16 == 0 && W % 16 == 0;
       // every 3 x 3 convolution's output goes through a GroupNorm next: its statistics come out of this epilogue (per-tile partial sums in tile order)
       if (taps == 9 && !gn_separate && (H * W) % 256 == 0 && (H * W) / 256 <= gn_blocks_cap && cout % 128 == 0) {
         a.gn_part = gn_sums;
@@ -410,6 +413,7 @@ template <typename T> struct VaeT : VaeBase {
           ConvArgs a{};
           a.in = bufP; a.w = phase_w.at(un + ".weight"); a.bias = W_<float>(un + ".bias"); a.out = oth; a.zero_page = zero_page;
           a.B = B; a.H = H; a.W = Wd; a.Cin = c; a.Cout = c; a.taps = 9; a.up = 2;
+          a.tile2d = !tile_linear && (H / 2) % 16 == 0 && (Wd / 2) % 16 == 0;
           if (stats_of == oth) stats_of = nullptr;
           const int HWl = (H / 2) * (Wd / 2);
           if (!gn_separate && HWl % 256 == 0 && 4 * (HWl / 256) <= gn_blocks_cap) { a.gn_part = gn_sums; stats_of = oth; stats_nblk = 4 * (HWl / 256); }

@@ -8,7 +8,7 @@
 // (operands %[ao0..7] of the GEMM4_ASM_*G statements); outputs, residuals and 1 x 1 inputs stay plain [B H W][C].  K order per accumulator (row of taps, tap, channel,
 // fp32) and the epilogue arithmetic (bias in fp32, round, C tile through LDS, residual added to the rounded value, round) are conv3s_kernel's: the outputs are its bytes.
 //
-// Upsampler convolutions (p.up == 2, grid.y = 4 phases): conv3x3(nearest2x(x)) at output pixel (2 y + a, 2 x + b) reads only the 2 x 2 input pixels (y - 1 + a .. y + a,
+// Upsampler convolutions (p.up == 2, four workgroups per tile: the phases): conv3x3(nearest2x(x)) at output pixel (2 y + a, 2 x + b) reads only the 2 x 2 input pixels (y - 1 + a .. y + a,
 // x - 1 + b .. x + b), each through the SUM of the kernel taps that land on it -- four 2 x 2 convolutions over the low-resolution image with pre-summed weights
 // (vae_phase_weights_kernel: fp32 sums of the fp16 taps, rounded once), 4/9 of the multiplications and no upsampled image in memory.  Same function, another rounding
 // (weights summed before instead of products after): held to the oracle's tolerance, not to conv3s's bytes (ECAD_VAE_UP=nine keeps the nine-tap form).
@@ -51,18 +51,22 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int phase = p.up == 2 ? blockIdx.y : 0, pa = phase >> 1, pb = phase & 1;
   const int Hs = p.up == 2 ? p.H >> 1 : p.H, Ws = p.up == 2 ? p.W >> 1 : p.W;   // the image the M index runs over (low resolution for the phase form)
   const int M = p.B * Hs * Ws;
-  int tm, tn;
+  int tm, tn, phase = 0;
   {  // workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles: neighbours share their halo rows (and, along n, all their A rows) in that XCD's L2
-    const int tiles_n = p.Cout / BN, nwg = (M / 256) * tiles_n;
+    const int tiles_n = p.Cout / BN, nph = p.up == 2 ? 4 : 1, nwg = (M / 256) * tiles_n * nph;
     int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.up == 2) {   // the four phases of a tile are neighbours in the run: they read the same 3 x 3 neighbourhoods and write the four pixels of the same 2 x 2 blocks
+      phase = bid & 3;
+      bid >>= 2;
+    }
     tm = bid / tiles_n;
     tn = bid - tm * tiles_n;
   }
+  const int pa = phase >> 1, pb = phase & 1;
   const int m0 = tm * 256, n0 = tn * BN;
   // p.tile2d: the 256 rows of a tile are a 16 x 16 patch of one image (row r = pixel (ty0 + r / 16, tx0 + r % 16)) instead of 256 consecutive pixels: 18 x 18 input
   // pixels under the nine taps instead of 3 (or 4, 6) whole image rows -- 2.4x fewer distinct A bytes per tile at W = 256 for the L2 to keep

@@ -420,7 +420,7 @@ template <typename T> struct VaeT : VaeBase {
           conv_flops += 2.0 * B * H * Wd * (double)c * 9 * c;
           conv_flops_exec += 2.0 * B * H * Wd * (double)c * 4 * c;
           ++conv_launches; ++conv4_launches;
-          hipLaunchKernelGGL((conv4_kernel<T, 256, false>), dim3((Ml / 256) * (c / 256), 4), dim3(256), conv4_lds_bytes<256>(), s, a);
+          hipLaunchKernelGGL((conv4_kernel<T, 256, false>), dim3((Ml / 256) * (c / 256) * 4), dim3(256), conv4_lds_bytes<256>(), s, a);
         } else if (conv4_bn(B * H * Wd, chans[i], chans[i], 9)) {  // the upsampled image is written out (bordered) and the convolution runs on conv4_kernel
           const size_t chunks = (size_t)B * (H + 2) * (Wd + 2) * (chans[i] / 8);
           const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);

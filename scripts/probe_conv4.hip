@@ -25,7 +25,7 @@ template <int BN, bool RES> static void run(const char* name, int B, int H, int 
   a.tile2d = g_tile2d;
   CK(hipFuncSetAttribute((const void*)conv4_kernel<f16_t, BN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<BN>()));
   const int M = B * Hs * Ws;
-  const dim3 grid((M / 256) * (cout / BN), up == 2 ? 4 : 1);
+  const dim3 grid((M / 256) * (cout / BN) * (up == 2 ? 4 : 1));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv4_kernel<f16_t, BN, RES>), grid, dim3(256), conv4_lds_bytes<BN>(), 0, a);
   CK(hipEventRecord(e0));

@@ -242,6 +242,7 @@ template <typename T> struct VaeT : VaeBase {
   // tiles for the chip.  A 3 x 3 convolution on conv4_kernel reads the zero-bordered layout: its producer (GroupNorm apply or the upsample pass) asks here first.
   int conv4_bn(int M, int cin, int cout, int taps) const {
     if (conv_tile128 || conv_gather || M % 256 || cin % 64) return 0;
+    if ((double)M * 1.13 * cin * sizeof(T) >= 4294967296.0) return 0;   // the statement's gathered A offsets are 32-bit (bordered input: at most 1.13 x the plain one at 32 x 32)
     const int stages = taps * cin / 64, tiles_m = M / 256;
     if (cout % 256 == 0 && stages % G4Period<T, 256>::value == 0 && tiles_m * (cout / 256) >= num_cus) return 256;
     if (cout % 128 == 0 && stages % G4Period<T, 128>::value == 0 && tiles_m * (cout / 128) >= num_cus) return 128;

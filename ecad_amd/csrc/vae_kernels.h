@@ -591,19 +591,33 @@ __global__ __launch_bounds__(256) void vae_conv_out_kernel(const T* __restrict__
       sc[e] = scale[(size_t)b * CO_C + ch * 8 + e];
       sh[e] = shift[(size_t)b * CO_C + ch * 8 + e];
     }
-    for (int hp = tid >> 4; hp < CO_HALO_H * CO_HALO_W; hp += 16) {
+    // all of the thread's halo chunks are requested before the first is normalised (round 6: the loop asked for one at a time -- load, SiLU, LDS write, next --
+    // and the kernel ran at a sixth of the HBM rate)
+    constexpr int NIT = (CO_HALO_H * CO_HALO_W + 15) / 16;   // 12
+    Pack8 raw[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int hp = (tid >> 4) + 16 * it;
       const int hy = hp / CO_HALO_W, hx = hp - hy * CO_HALO_W;
       const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      ok[it] = hp < CO_HALO_H * CO_HALO_W && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      raw[it].u = (u32x4){0u, 0u, 0u, 0u};
+      if (ok[it]) raw[it] = gload16(x + (((size_t)b * H + yy) * W + xx) * CO_C + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int hp = (tid >> 4) + 16 * it;
       Pack8 v;
       v.u = (u32x4){0u, 0u, 0u, 0u};
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      if (ok[it]) {
         float f[8];
-        unpack8<T>(gload16(x + (((size_t)b * H + yy) * W + xx) * CO_C + ch * 8), f);
+        unpack8<T>(raw[it], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = silu(f[e] * sc[e] + sh[e]);
         v = pack8<T>(f);
       }
-      *reinterpret_cast<u32x4*>(halo + hp * CO_PIX_BYTES + ch * 16) = v.u;
+      if (hp < CO_HALO_H * CO_HALO_W) *reinterpret_cast<u32x4*>(halo + hp * CO_PIX_BYTES + ch * 16) = v.u;
     }
   }
   __syncthreads();

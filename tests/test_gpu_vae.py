@@ -67,14 +67,15 @@ def test_conv3s_tiles_give_the_bytes_of_the_128_tile_kernel_and_decodes_repeat(m
         assert torch.equal(out["tile128"], out["conv3s"])
 
 
-@pytest.mark.parametrize("B", [16, 4, 3])
-def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B):
+@pytest.mark.parametrize("B,h,w", [(16, 32, 32), (4, 32, 32), (3, 32, 32), (1, 128, 128), (2, 64, 32)])
+def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B, h, w):
     """conv4.h (round 6): the convolutions whose tiles fill the chip run the generated one-wave-per-SIMD K loop over a zero-bordered copy of their input (written by the
     GroupNorm apply / upsample pass), K order and epilogue arithmetic of conv3s_kernel -- the decoded image must be conv3s's byte for byte.  B 16 is the bench geometry
-    (every 3 x 3 convolution and the 512 -> 256 shortcut on conv4); B 4 / B 3 mix conv4 stages with conv3s / conv_gemm ones."""
+    (every 3 x 3 convolution and the 512 -> 256 shortcut on conv4); B 4 / B 3 mix conv4 stages with conv3s / conv_gemm ones; (1, 128, 128) is one image of the
+    Sigma-1024 / FLUX-1024 decode (1024 x 1024 pixels: the largest offsets the 32-bit gathered addressing sees per image), (2, 64, 32) a non-square one."""
     from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
 
-    lat = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(11)) * 0.36
+    lat = torch.randn(B, 4, h, w, generator=torch.Generator().manual_seed(11)) * 0.36
     out, stats = {}, {}
     # the statistics of the GroupNorm behind a conv4 launch come out of its epilogue as per-tile partial sums -- another (fixed) order of the same fp32 additions than
     # gn_stats_kernel's, so THAT is compared at one grey level below; byte identity is of the convolutions, with the statistics kernel kept (ECAD_VAE_GN=separate)

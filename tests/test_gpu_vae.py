@@ -67,8 +67,9 @@ def test_conv3s_tiles_give_the_bytes_of_the_128_tile_kernel_and_decodes_repeat(m
         assert torch.equal(out["tile128"], out["conv3s"])
 
 
-@pytest.mark.parametrize("B,h,w", [(16, 32, 32), (4, 32, 32), (3, 32, 32), (1, 128, 128), (2, 64, 32)])
-def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B, h, w):
+@pytest.mark.parametrize("B,h,w,dtype", [(16, 32, 32, torch.float16), (4, 32, 32, torch.float16), (3, 32, 32, torch.float16), (1, 128, 128, torch.float16),
+                                         (2, 64, 32, torch.float16), (16, 32, 32, torch.bfloat16)])
+def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B, h, w, dtype):
     """conv4.h (round 6): the convolutions whose tiles fill the chip run the generated one-wave-per-SIMD K loop over a zero-bordered copy of their input (written by the
     GroupNorm apply / upsample pass), K order and epilogue arithmetic of conv3s_kernel -- the decoded image must be conv3s's byte for byte.  B 16 is the bench geometry
     (every 3 x 3 convolution and the 512 -> 256 shortcut on conv4); B 4 / B 3 mix conv4 stages with conv3s / conv_gemm ones; (1, 128, 128) is one image of the
@@ -90,7 +91,7 @@ def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B
             monkeypatch.setenv("ECAD_VAE_CONV", mode)
         else:
             monkeypatch.delenv("ECAD_VAE_CONV", raising=False)
-        vae = HipVaeDecoder.random_init(3, device=0)
+        vae = HipVaeDecoder.random_init(3, device=0, dtype=dtype)
         out[mode] = vae.decode_to_uint8(lat.cuda()).cpu()
         stats[mode] = vae.decode_stats()
         del vae
@@ -102,7 +103,10 @@ def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B
     assert torch.equal(out["fused"], out["fused-again"])
     # measured: 7.5 % of the bytes move by one level, a handful by two (each order is within one level of the fp32 oracle) -- what ANY change of summation order does to
     # this random-weight decoder (round 3 saw the same 7 % between two runs of its atomics)
-    assert int(d.max()) <= 2 and float(d.float().mean()) < 0.12
+    if dtype == torch.bfloat16:   # eight mantissa bits: a reordered sum moves more roundings (and each by more); the bf16 loops (GEMM4_ASM_BF16_*G) are held to conv3s's bytes below
+        assert float(d.float().mean()) < 1.0
+    else:
+        assert int(d.max()) <= 2 and float(d.float().mean()) < 0.12
     assert stats["conv3s"]["conv4_launches"] == 0 and stats["default"]["conv4_launches"] > 0
     assert stats["default"]["conv_flops"] == stats["conv3s"]["conv_flops"]
     if B == 16:

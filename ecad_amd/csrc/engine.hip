@@ -37,6 +37,7 @@
 #include "gemm2w.h"
 #include "gemm2w4.h"
 #include "gemm3s4.h"
+#include "attention_w472.h"
 #include "gemm3s.h"
 #include "gemm3s8.h"
 
@@ -350,6 +351,7 @@ template <typename T> class EngineT : public EngineBase {
     gemm_impl_cls[KC_GEMM_FF2] = gemm_impl_cls[KC_GEMM_CAPTION] = gemm_impl_cls[KC_GEMM_SMALL] = 0;
     gemm_impl_cls[KC_GEMM_FF1] = gemm_impl_cls[KC_GEMM_TEXTKV] = gemm_impl_cls[KC_GEMM_KV1] = 2;
     if (const char* l = getenv("ECAD_FUSE_ATTN")) fuse_attn = atoi(l) != 0;
+    if (const char* l = getenv("ECAD_ATTN_W472")) attn_w472_on = atoi(l) != 0;
     if (const char* l = getenv("ECAD_PLAN_CACHE")) plan_lru_cap = (size_t)(atoi(l) > 0 ? atoi(l) : 0);
     custom_mask.assign((size_t)cfg.num_layers * 3, 0);
     valid_rt.assign((size_t)cfg.num_layers * 3, 0);
@@ -1596,7 +1598,18 @@ template <typename T> class EngineT : public EngineBase {
   int attn_shared = 1;  // attention128.h (d_h 72: both query fragments of a wave share each K / V fragment read); 0 (ecad_op_attention_ex only): the generic attention.h, which serves every other head size
   bool attn_shared_attr[2] = {};
   bool attn_dma_attr = false;
-  int launch_attn(const AttnArgs& a, bool masked, hipStream_t s, bool wide = false) {
+  bool attn_w472_on = true;   // env ECAD_ATTN_W472=0: long-sequence self-attention stays on attn_dma_kernel<T, 72, 4> (eight waves, compiler-scheduled)
+  bool attn_w472_attr = false;
+  int launch_attn(const AttnArgs& a, bool masked, hipStream_t s, bool wide = false, bool four_fragment = false) {
+    if (wide && !four_fragment && attn_w472_on && attn_w472_ok(a, masked)) {  // one wave per SIMD, generated instruction stream (attention_w472.h): 256 query rows per work item
+      if (!attn_w472_attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)attn_w472_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+        attn_w472_attr = true;
+      }
+      const int items = a.B * a.H * (a.Nq / 256);
+      hipLaunchKernelGGL((attn_w472_kernel<T>), dim3(items < num_cus ? items : num_cus), dim3(256), W4_LDS_BYTES, s, a);
+      return ECAD_OK;
+    }
     if (wide && a.dh == 72 && !masked && a.Nk % 128 == 0 && a.seg_t == 0 && a.Nq % 512 == 0) {  // four query fragments per wave: 512 query rows per work item (attention_dma.h)
       if (!attn_dma_attr) {
         HIPCHK(hipFuncSetAttribute((const void*)attn_dma_kernel<T, 72, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_dma_lds_bytes<72>()));
@@ -2131,15 +2144,29 @@ template <typename T> class EngineT : public EngineBase {
   }
   int op_attention_ex(int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H, int Nq, int Nk,
                       int dh, const float* bias, hipStream_t s) override {
-    if (kernel < 0 || kernel > 3) return fail(ECAD_E_INVALID, "attention kernel %d unknown", kernel);
+    if (kernel < 0 || kernel > 4) return fail(ECAD_E_INVALID, "attention kernel %d unknown", kernel);
     if (kernel >= 2 && dh != 72) return fail(ECAD_E_UNSUPPORTED, "attention128.h / attention_dma.h are instantiated for head_dim 72 on this path, got %d", dh);
-    if (kernel == 3) {  // attention_dma.h with four query fragments per wave: what the plans launch for self-attention over >= 1024 tokens
+    if (kernel == 4) {  // attention_w472.h: what the plans launch for self-attention over >= 1024 tokens (round 6)
+      if (bias || Nk % 256 || Nq % 256) return fail(ECAD_E_UNSUPPORTED, "attention_w472 needs Nq %% 256 == 0, Nk %% 256 == 0 and no key bias");
+      HIPCHK(hipSetDevice(dev));
+      AttnArgs a{};
+      a.q = q; a.k = k; a.v = v; a.out = out; a.bias = nullptr; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh;
+      a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)dh));
+      const bool keep_on = attn_w472_on;
+      attn_w472_on = true;
+      const int rc = launch_attn(a, false, s, true);
+      attn_w472_on = keep_on;
+      if (rc) return rc;
+      HIPCHK(hipGetLastError());
+      return ECAD_OK;
+    }
+    if (kernel == 3) {  // attention_dma.h with four query fragments per wave: the plans' kernel for self-attention over >= 1024 tokens until round 6 (ECAD_ATTN_W472=0)
       if (bias || Nk % 128 || Nq % 512) return fail(ECAD_E_UNSUPPORTED, "the four-fragment kernel needs Nq %% 512 == 0, Nk %% 128 == 0 and no key bias");
       HIPCHK(hipSetDevice(dev));
       AttnArgs a{};
       a.q = q; a.k = k; a.v = v; a.out = out; a.bias = nullptr; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh;
       a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)dh));
-      const int rc = launch_attn(a, false, s, true);
+      const int rc = launch_attn(a, false, s, true, true);
       if (rc) return rc;
       HIPCHK(hipGetLastError());
       return ECAD_OK;

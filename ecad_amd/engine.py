@@ -389,10 +389,10 @@ class EcadEngine:
         return out
 
     def op_attention(self, q, k, v, B, H, Nq, Nk, dh, bias=None, kernel: str = "auto"):
-        """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer).  kernel: auto | generic (attention.h) | shared (attention128.h) | wide4 (attention_dma.h, four query fragments per wave)."""
+        """q: [B*Nq, ldq] view, k/v: [B*Nk, ld] views (may be column slices of a fused buffer).  kernel: auto | generic (attention.h) | shared (attention128.h) | wide4 (attention_dma.h, four query fragments per wave) | w472 (attention_w472.h: one wave per SIMD, generated stream)."""
         out = torch.empty((B * Nq, H * dh), device=self.device, dtype=self.dtype)
         if kernel != "auto":
-            self._chk(self.lib.ecad_op_attention_ex(self._h, {"generic": 1, "shared": 2, "wide4": 3}[kernel], q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+            self._chk(self.lib.ecad_op_attention_ex(self._h, {"generic": 1, "shared": 2, "wide4": 3, "w472": 4}[kernel], q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                                     out.data_ptr(), out.stride(0), B, H, Nq, Nk, dh, _ptr(bias), _stream_ptr()))
             return out
         self._chk(self.lib.ecad_op_attention(self._h, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0),

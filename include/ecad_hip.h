@@ -263,7 +263,9 @@ int ecad_op_attention(EcadEngine* e, const void* q, int64_t ldq, const void* k, 
                       int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream);
 
 /* ecad_op_attention with the kernel named: 0 = what the engine would pick, 1 = attention.h (any head_dim <= 72, % 8 == 0), 2 =
- * attention128.h (head_dim 72 only; ECAD_E_UNSUPPORTED otherwise). */
+ * attention128.h (head_dim 72 only; ECAD_E_UNSUPPORTED otherwise), 3 = attention_dma.h with four query fragments per wave (head_dim 72, Nq % 512 == 0, Nk % 128 == 0, no bias),
+ * 4 = attention_w472.h (head_dim 72, Nq % 256 == 0, Nk % 256 == 0, no bias): one wave per SIMD, generated instruction stream -- what the plans launch for
+ * self-attention over >= 1024 tokens (PixArt-Sigma at 1024 x 1024). */
 int ecad_op_attention_ex(EcadEngine* e, int kernel, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo,
                          int B, int H, int Nq, int Nk, int dh, const float* bias, void* stream);
 

@@ -20,7 +20,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffast-math -fno-finite-math-only -DECAD_PRODUCT_BUILD -S --cuda-device-only".split()  # BASEFLAGS of the Makefile
-KERNELS = ("fgemm4", "fgemm48", "attn_w4a", "gemm2w4", "gemm3s4", "conv4")
+KERNELS = ("fgemm4", "fgemm48", "attn_w4a", "attn_w472", "gemm2w4", "gemm3s4", "conv4")
 
 
 def audit(asm: str, unit: str) -> int:

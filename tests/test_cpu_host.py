@@ -238,14 +238,14 @@ def test_inference_cli_guidance_scale_follows_the_reference(tmp_path):
 
 
 def test_generated_instruction_streams_are_what_their_generators_write():
-    """`ecad_amd/csrc/gemm4_asm.h` and `attention_w4_asm.h` are generated (scripts/gen_gemm4.py, scripts/gen_attn_w4.py) and committed: a hand edit of either header, or a
+    """`ecad_amd/csrc/gemm4_asm.h`, `attention_w4_asm.h` and `attention_w472_asm.h` are generated (scripts/gen_gemm4.py, gen_attn_w4.py, gen_attn_w4_72.py) and committed: a hand edit of either header, or a
     generator change without regenerating, would leave the tree describing one instruction stream and building another.  `--check` regenerates in memory and compares."""
     import subprocess
     import sys
     from pathlib import Path
 
     root = Path(__file__).resolve().parents[1]
-    for gen in ("gen_gemm4.py", "gen_attn_w4.py"):
+    for gen in ("gen_gemm4.py", "gen_attn_w4.py", "gen_attn_w4_72.py"):
         r = subprocess.run([sys.executable, str(root / "scripts" / gen), "--check"], capture_output=True, text=True)
         assert r.returncode == 0, f"{gen}: {r.stderr[-400:]}"
 

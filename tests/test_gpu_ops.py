@@ -542,6 +542,35 @@ def test_self_attention_four_fragment_kernel_is_the_same_arithmetic(dtype_name, 
     assert within(rel_l2(got, _attn_ref(qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :], B, H, N, N, dh, None)), ATT_TOL[dtype_name])
 
 
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("N", [256, 1024, 4096])
+def test_self_attention_on_one_wave_per_simd_for_heads_of_72(dtype_name, N):
+    """attention_w472.h (round 6): d_h 72 on the one-wave-per-SIMD structure of the FLUX kernel -- a generated instruction stream (scripts/gen_attn_w4_72.py), five
+    k-steps of S = K Q~^T with the last half zero, the row sums as row 72 of O^T (a ones column preset in the V ring that the masked DMA never overwrites), deferred
+    rescale with threshold 2^8.  What the plans launch for self-attention over >= 1024 tokens (Sigma-1024: N = 4096; 634 against 813 us for attention_dma.h's
+    four-fragment kernel).  Another MFMA shape and summation order than attention128.h: not bit-identical, held to the fp32 reference at the attention tolerance --
+    with a late dominant key tile (the recentre / rescale paths), large scores, and launch-to-launch reproducibility (a race between the DMA ring and the fragment
+    reads shows up there first)."""
+    dt = getattr(torch, dtype_name)
+    B, H, dh = (2 if N == 4096 else 3), 16, 72
+    D = H * dh
+    eng = small_engine(dtype_name)
+    for case in ("plain", "late dominant keys", "large scores"):
+        qkv = _r((B * N, 3 * D), dt, 1.0, 7)
+        if case == "late dominant keys":
+            qkv[N - 40 : N - 32, D : 2 * D] *= 5.0
+        if case == "large scores":
+            qkv[:, : 2 * D] *= 1.7
+        q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
+        got = eng.op_attention(q, k, v, B, H, N, N, dh, kernel="w472")
+        again = eng.op_attention(q, k, v, B, H, N, N, dh, kernel="w472")
+        assert torch.equal(got, again)
+        assert torch.isfinite(got.float()).all()
+        assert within(rel_l2(got, _attn_ref(q, k, v, B, H, N, N, dh, None)), ATT_TOL[dtype_name]), case
+    with pytest.raises(Exception):
+        eng.op_attention(qkv[: B * 128, :D], qkv[: B * 128, D : 2 * D], qkv[: B * 128, 2 * D :], B, H, 128, 128, dh, kernel="w472")   # Nq % 256 != 0: refused, not mis-run
+
+
 def test_attention_large_scores_online_softmax():
     """Force the running-max rescale branch: one key tile dominates late (guide rule 26)."""
     eng = small_engine("float16")

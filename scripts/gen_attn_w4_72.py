@@ -15,7 +15,7 @@ Q prescale, pipeline fill, the tile loop, the rare recentre / rescale paths, the
 C++ around it (attention_w4.h) only walks the work items and computes addresses.  Structure and budget: cdna_hip_programming.md "Fused attention prefill",
 MI355X_MICROARCH.md "Per-instruction cycle constants" (<= 24 issue cycles of fillers per 32-cycle MFMA gap, at most one 8-cycle v_exp among them).
 
-Register map (per lane; VGPR v0..v243 and AGPR a0..a255 belong to the statement, v244.. stay with the compiler for the operands):
+Register map (per lane; VGPR v0..v244 and AGPR a0..a255 belong to the statement, v245.. stay with the compiler for the operands):
   v[0:31]    S, key block 0          [rq][16]      scores minus the running maximum, log2 domain (the -m comes in as the C operand of the first MFMA of a tile)
   v[32:63]   S, key block 1, bank X  [rq][16]      (tiles t even)
   v[64:95]   S, key block 1, bank Y                (tiles t odd)
@@ -23,10 +23,10 @@ Register map (per lane; VGPR v0..v243 and AGPR a0..a255 belong to the statement,
   v[128:143] P k-steps 0,1, bank PX  [rq][kst][4]  (tiles t even)
   v[144:159] P k-steps 0,1, bank PY                (tiles t odd)
   v[160:175] P k-steps 2,3           [rq][kst-2][4]
-  v[176:191] K fragment window (4 x 4)     v[192:211] V fragment window (5 x 4)
-  v[212:216] K read addresses [ks]         v[220:222] V read addresses [db] (+ 64 KiB: the V ring)
-  v[224:227] DMA lane offsets K [piece]    v228 DMA lane offset V (piece 0; pieces 1..3 by scalar base)
-  v[231:232] pending alpha[rq]   v[233:234] lane maxima   v[235:242] temporaries
+  v[176:195] K fragment window (5 x 4)     v[196:219] V fragment window (6 x 4)
+  v[220:224] K read addresses [ks]         v[225:227] V read addresses [db] (+ 64 KiB: the V ring)
+  v[228:231] DMA lane offsets K [piece]    v232 DMA lane offset V (piece 0; pieces 1..3 by scalar base)
+  v[233:234] pending alpha[rq]   v[235:236] lane maxima   v[237:244] temporaries
   a[0:95]    O^T accumulators [rq][db][16] (db 2: rows 64..71 of the head, row 72 = the row sums)         a[96:135] Q~ fragments [rq][ks][4]
 """
 from __future__ import annotations
@@ -41,12 +41,13 @@ ABLATE = set(filter(None, os.environ.get("W472_ABLATE", "").split(",")))   # tim
 
 S0, SX, SY, CI = 0, 32, 64, 96
 PX, PY, PZ = 128, 144, 160
-KW, VW = 176, 192
-KA, VA = 212, 220
-KOFF, VOFF = 224, 228          # K: one lane offset per piece (the row XOR differs per piece); V: piece 0, pieces 1..3 by scalar base
-LRUN, PEND, MXP = 229, 231, 233
-TMP = 235                      # 8 temporaries: v235..v242
-NV = 244                       # v0..v243 belong to the statement
+KW, VW = 176, 196              # fragment windows: K 5 x 4 registers, V 6 x 4 (one deeper than the d_h 128 stream: its 8 K + 4 V address registers are 5 + 3 here)
+KA, VA = 220, 225
+KOFF, VOFF = 228, 232          # K: one lane offset per piece (the row XOR differs per piece); V: piece 0, pieces 1..3 by scalar base
+PEND, MXP = 233, 235
+LRUN = MXP                     # output stage only: the row sums read back from O^T (the lane maxima are dead by then)
+TMP = 237                      # 8 temporaries: v237..v244
+NV = 245                       # v0..v244 belong to the statement
 OACC, QF = 0, 96
 NKS, NDB = 5, 3               # k-steps of 16 over the head dim (80 >= 72), 32-row blocks of O^T (96 >= 73)
 N1, N2 = 4 * NKS, 8 * NDB     # MFMAs per phase with RQ = 2: S(t+1) = K Q~^T, O^T += V^T P^T
@@ -54,8 +55,8 @@ N1, N2 = 4 * NKS, 8 * NDB     # MFMAs per phase with RQ = 2: S(t+1) = K Q~^T, O^
 # only source pieces 0..8 (144 bytes) exist
 KMASK = [sum(1 << (16 * g + pos) for g in range(4) for pos in range(16) if (pos ^ ((4 * j + g) & 15)) < 9) for j in range(4)]
 VMASK = sum(1 << (16 * g + pos) for g in range(4) for pos in range(16) if (pos ^ (g << 2)) < 9)
-K_AHEAD, K_WIN = 3, 4
-V_AHEAD, V_WIN = 4, 5
+K_AHEAD, K_WIN = 4, 5
+V_AHEAD, V_WIN = 5, 6
 THR = 8.0
 SLOT = 16384
 VRING = 65536

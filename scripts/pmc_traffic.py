@@ -70,7 +70,7 @@ def classify(name: str) -> str | None:
         return "cache_hit_step" if tag and tag.group(1) == "1" else "cache_replay"
     if "ln_modulate" in name:
         return "ln_modulate"
-    if "attn_dma_kernel" in name:  # attention_dma.h: unmasked self-attention only
+    if "attn_dma_kernel" in name or "attn_w472_kernel" in name:  # attention_dma.h / attention_w472.h: unmasked self-attention only
         return "attn_self"
     if "attn128_kernel" in name or "attn_kernel" in name:
         masked = re.search(r"Lb([01])E", name) or re.search(r"(true|false)", name)

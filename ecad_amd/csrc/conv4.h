@@ -17,6 +17,10 @@
 #include "gemm4.h"
 #include "vae_kernels.h"
 
+#if defined(ECAD_PRODUCT_BUILD) && (defined(CONV4_PROBE_NO_EPILOGUE) || defined(CONV4_PROBE_NO_LOOP))
+#error "CONV4_PROBE_* cut phases out of conv4_kernel for scripts/probe_conv4.hip: never in the product library"
+#endif
+
 namespace ecad {
 
 // the statement takes its pointers in SGPRs: pin what the compiler may have computed per lane (tile coordinates are workgroup-uniform, hipcc does not always see it)

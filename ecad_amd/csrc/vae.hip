@@ -406,7 +406,8 @@ template <typename T> struct VaeT : VaeBase {
         H *= 2; Wd *= 2;
         const std::string un = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
         const int Ml = B * (H / 2) * (Wd / 2), c = chans[i];
-        if (!up_nine && !conv_tile128 && !conv_gather && Ml % 256 == 0 && c % 256 == 0 && (4 * c / 64) % G4Period<T, 256>::value == 0 && (Ml / 256) * (c / 256) * 4 >= num_cus) {
+        if (!up_nine && !conv_tile128 && !conv_gather && Ml % 256 == 0 && c % 256 == 0 && (4 * c / 64) % G4Period<T, 256>::value == 0 && (Ml / 256) * (c / 256) * 4 >= num_cus &&
+            (double)Ml * 1.13 * c * sizeof(T) < 4294967296.0) {   // 32-bit gathered offsets, as conv4_bn
           // four 2 x 2 convolutions over the bordered low-resolution image, one per output phase (conv4.h): 4/9 of the nine-tap form's multiplications
           const size_t chunks = (size_t)B * (H / 2 + 2) * (Wd / 2 + 2) * (c / 8);
           const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);

@@ -67,20 +67,44 @@ def engine_score_fn(engine, enc, mask, latents, timesteps, coefs, guidance: floa
     return score
 
 
-def engine_score_fn_batches(engine, batches, timesteps, coefs, guidance: float = 4.5, contexts: int = 3):
+def _pad_batch(enc, mask, latents, full: int):
+    """A partial last prompt batch (config 4: 100 prompts = 6 x 16 + 4) filled up to the full batch size by repeating its last prompt / latent: the candidate then needs
+    ONE plan set and ONE graph capture per schedule instead of two, at the price of 12 discarded images.  Measured on config 4 (round 6, same box, same scores to the
+    last bit): 9.83 s per generation against 9.46 without -- lowering + capture of a second batch size costs 10-25 ms (scripts/ga_time_probe.py), twelve more images of
+    these lightly cached seed schedules 70-100 ms -- so it is OFF by default (``pad_partial=True`` for callers whose schedules change every batch).  The rows of the real
+    images are what they are in a batch of their own: a row's arithmetic does not depend on its neighbours from batch 4 up (engine tests)."""
+    import torch
+
+    n = latents.shape[0]
+    if n == full:
+        return enc, mask, latents, n
+    r = full - n
+    enc = torch.cat([enc[:n], enc[n - 1 : n].expand(r, *enc.shape[1:]), enc[n:], enc[2 * n - 1 : 2 * n].expand(r, *enc.shape[1:])], 0)   # [negative | prompt] halves
+    mask = torch.cat([mask[:n], mask[n - 1 : n].expand(r, *mask.shape[1:]), mask[n:], mask[2 * n - 1 : 2 * n].expand(r, *mask.shape[1:])], 0)
+    latents = torch.cat([latents, latents[n - 1 : n].expand(r, *latents.shape[1:])], 0)
+    return enc.contiguous(), mask.contiguous(), latents.contiguous(), n
+
+
+def engine_score_fn_batches(engine, batches, timesteps, coefs, guidance: float = 4.5, contexts: int = 3, pad_partial: bool = False):
     """score_fn over SEVERAL fixed prompt batches (config 4: 100 prompts per candidate = 6 batches of 16 + one of 4), the batches of a candidate kept in flight on
     ``contexts`` execution contexts over this rank's weights (``EngineContexts``: batch i + 1 .. i + contexts - 1 run while batch i is being scored; every batch's
-    latents are bit-identical to running it alone).  Score = mean over the batches of the stand-in fidelity to the uncached run of the same batch.  ``score.restore()``
-    as in ``engine_score_fn``; ``score.close()`` releases the extra contexts."""
+    latents are bit-identical to running it alone).  Score = mean over the batches of the stand-in fidelity to the uncached run of the same batch (real images only:
+    ``pad_partial`` fills a smaller batch up to the largest one, see ``_pad_batch``).  ``score.restore()`` as in ``engine_score_fn``; ``score.close()`` releases the
+    extra contexts."""
     import torch
 
     from ecad_amd.engine import EngineContexts
 
+    full = max(l.shape[0] for _, _, l in batches)
+    real = [l.shape[0] for _, _, l in batches]
+    if pad_partial and 2 * full <= engine.cfg.max_batch:
+        padded = [_pad_batch(e, m, l, full) for e, m, l in batches]
+        batches = [(e, m, l) for e, m, l, _ in padded]
     steps = len(timesteps)
     fold_before = getattr(engine, "ln_fold", True)
     engine.set_ln_fold(False)
     engine.set_schedule(np.ones((steps, engine.cfg.num_layers, 3), dtype=np.uint8))
-    refs = [engine.run_schedule(e, m, l, timesteps, coefs, guidance).clone() for e, m, l in batches]
+    refs = [engine.run_schedule(e, m, l, timesteps, coefs, guidance)[:n].clone() for (e, m, l), n in zip(batches, real)]
     pool = EngineContexts(engine, max(1, int(contexts))) if contexts > 1 else None
     if pool is not None:
         for ctx in pool.engines[1:]:
@@ -89,14 +113,14 @@ def engine_score_fn_batches(engine, batches, timesteps, coefs, guidance: float =
     def score(_idx: int, bits: np.ndarray) -> float:
         if pool is None:
             engine.set_schedule(bits)
-            return float(np.mean([latent_fidelity_score(engine.run_schedule(e, m, l, timesteps, coefs, guidance), r) for (e, m, l), r in zip(batches, refs)]))
+            return float(np.mean([latent_fidelity_score(engine.run_schedule(e, m, l, timesteps, coefs, guidance)[: r.shape[0]], r) for (e, m, l), r in zip(batches, refs)]))
         pool.set_schedule(bits)
         pending, scores = [], []
 
         def finish():
             i, out, st = pending.pop(0)
             torch.cuda.current_stream(engine.device).wait_stream(st)
-            scores.append(latent_fidelity_score(out, refs[i]))  # .norm() -> float: waits for that batch only
+            scores.append(latent_fidelity_score(out[: refs[i].shape[0]], refs[i]))  # .norm() -> float: waits for that batch only
 
         for i, (e, m, l) in enumerate(batches):
             out, st = pool.submit(e, m, l, timesteps, coefs, guidance)

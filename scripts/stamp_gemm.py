@@ -13,7 +13,9 @@ eng = EcadEngine(num_layers=1, max_batch=2, dtype=torch.float16)
 import os
 CASES = [("wide288", "ff1", 1, 8192, 4608, 1152), ("wide288", "attn1_kv", 0, 8192, 2304, 1152), ("tile144", "qkv", 0, 8192, 1152, 1152),
          ("tile144", "attn1_out", 3, 8192, 1152, 1152), ("tile144", "ff2", 3, 8192, 1152, 4608)]
-if os.environ.get("STAMP_SMALL"):  # few workgroups: is the epilogue bound by the chip (HBM / fabric) or by the CU's own store path?
+if os.environ.get("STAMP_LATENCY"):  # the 64-row latency tiles of a batch of 1 (M = 512): how long is a K-step when a workgroup has nobody to hide its DMA latency behind?
+    CASES = [("latency64", "qkv", 0, 512, 1152, 1152), ("latency64", "attn1_kv", 0, 512, 2304, 1152), ("latency64", "ff1", 1, 512, 4608, 1152), ("latency64", "attn1_out", 3, 512, 1152, 1152)]
+elif os.environ.get("STAMP_SMALL"):  # few workgroups: is the epilogue bound by the chip (HBM / fabric) or by the CU's own store path?
     CASES = [("tile144", "qkv", 0, 256 * m, 1152, 1152) for m in (1, 4, 8, 16, 32)] + [("wide288", "attn1_kv", 0, 256 * m, 2304, 1152) for m in (1, 4, 16, 32)]
 for kernel, site, epi, M, N, K in CASES:
     a = torch.randn(M, K, device="cuda").half()

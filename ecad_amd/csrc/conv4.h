@@ -4,6 +4,8 @@
 // GroupNorm apply pass or the upsample pass that produces it anyway -- so that
 //   * the three taps of one kernel row are 3 C contiguous channels starting at pixel (y + dy, x - 1): a K segment of 3 C elements, no padding test;
 //   * from one kernel row to the next every lane's source moves by the same (W + 2) C elements: a uniform jump of the A pointer every 3 C / 64 stages.
+// (That is conv3s_kernel's K order -- kernel row, tap, channel -- kept as p.korder 1; the default since the PMC counters showed every input byte fetched three times is
+// chunk of 64 channels, kernel row, tap: the same statement, another walk of its A pointer and a matching weight layout, see conv4_kernel.)
 // The M index still runs over the B H W real pixels (whole 256-row tiles, the same tile counts as conv3s), so a lane's eight DMA pieces have gathered byte offsets
 // (operands %[ao0..7] of the GEMM4_ASM_*G statements); outputs, residuals and 1 x 1 inputs stay plain [B H W][C].  K order per accumulator (row of taps, tap, channel,
 // fp32) and the epilogue arithmetic (bias in fp32, round, C tile through LDS, residual added to the rounded value, round) are conv3s_kernel's: the outputs are its bytes.
@@ -29,19 +31,22 @@ ECAD_DEV const char* conv4_uniform(const char* ptr) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
-template <typename T, int BN> ECAD_DEV void conv4_statement(const char* ap, const char* wp, unsigned rsw, unsigned trips, unsigned lds, unsigned wave, unsigned seg,
-                                                            unsigned jump, const unsigned (&ao)[8]) {
+// the A pointer's walk (gen_gemm4.py, gathered A): da bytes per stage, db into stages kw and 2 kw of a cycle, the 64-bit dc into stage kt (= stage 0 of the next cycle)
+struct Conv4Walk { unsigned da, db, dc, dch, kw, kw2, kt; };
+template <typename T, int BN> ECAD_DEV void conv4_statement(const char* ap, const char* wp, unsigned rsw, unsigned trips, unsigned lds, unsigned wave, const Conv4Walk& wk,
+                                                            const unsigned (&ao)[8]) {
   const unsigned zero = 1u;
   ap = conv4_uniform(ap);
   wp = conv4_uniform(wp);
   rsw = __builtin_amdgcn_readfirstlane(rsw);
   trips = __builtin_amdgcn_readfirstlane(trips);
-  seg = __builtin_amdgcn_readfirstlane(seg);
-  jump = __builtin_amdgcn_readfirstlane(jump);
-  if constexpr (std::is_same<T, bf16_t>::value && BN == 256) { GEMM4_ASM_BF16_256G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
-  else if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_128G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
-  else if constexpr (BN == 256) { GEMM4_ASM_F16_256G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
-  else { GEMM4_ASM_F16_128G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao); }
+  const unsigned da = __builtin_amdgcn_readfirstlane(wk.da), db = __builtin_amdgcn_readfirstlane(wk.db), dc = __builtin_amdgcn_readfirstlane(wk.dc),
+                 dch = __builtin_amdgcn_readfirstlane(wk.dch), kw = __builtin_amdgcn_readfirstlane(wk.kw), kw2 = __builtin_amdgcn_readfirstlane(wk.kw2),
+                 kt = __builtin_amdgcn_readfirstlane(wk.kt);
+  if constexpr (std::is_same<T, bf16_t>::value && BN == 256) { GEMM4_ASM_BF16_256G(ap, wp, rsw, trips, lds, wave, zero, da, db, dc, dch, kw, kw2, kt, ao); }
+  else if constexpr (std::is_same<T, bf16_t>::value) { GEMM4_ASM_BF16_128G(ap, wp, rsw, trips, lds, wave, zero, da, db, dc, dch, kw, kw2, kt, ao); }
+  else if constexpr (BN == 256) { GEMM4_ASM_F16_256G(ap, wp, rsw, trips, lds, wave, zero, da, db, dc, dch, kw, kw2, kt, ao); }
+  else { GEMM4_ASM_F16_128G(ap, wp, rsw, trips, lds, wave, zero, da, db, dc, dch, kw, kw2, kt, ao); }
 }
 
 // p.in: [B][H + 2][W + 2][Cin] with a zero border when p.taps == 9, plain [B H W][Cin] when p.taps == 1; B H W % 256 == 0, Cout % BN == 0, taps Cin / 64 a whole
@@ -112,15 +117,30 @@ __global__ __launch_bounds__(256) void conv4_kernel(const ConvArgs p) {
       }
     }
   }
-  const int kw = p.up == 2 ? 2 : 3;   // pixels per kernel row
-  const unsigned seg = p.taps == 9 ? (unsigned)(kw * p.Cin / 64) : 0x7fffffffu;
-  const unsigned jump = p.taps == 9 ? (unsigned)((Ws + 2 - kw) * p.Cin * 2 + 128) : 128u;
+  // K order (p.korder 0, the default): 64-channel chunk, kernel row, tap -- the nine (four) visits of a tile to the same chunk of its pixels are consecutive stages, so the
+  // chunk comes from HBM once (tap-major, p.korder 1 = conv3s_kernel's order kernel row, tap, channel: every input byte was fetched about three times, PMC: 16.5 GB of reads
+  // per decode for 5.2 GB of inputs).  The weights are laid out to match (vae.hip).
+  Conv4Walk wk;
+  {
+    const int kwid = p.up == 2 ? 2 : 3, khei = kwid;   // taps per kernel row, kernel rows
+    const long long pix = (long long)p.Cin * 2, row = (long long)(Ws + 2) * pix;
+    if (p.taps != 9) {                 // 1 x 1: plain rows, 128 bytes per stage
+      wk = Conv4Walk{128u, 128u, 128u, 0u, 1u, 2u, 1u};
+    } else if (p.korder == 1) {        // kernel row, tap, channel: kwid * Cin / 64 contiguous stages, then to the next image row; the cycle is the whole K loop
+      const unsigned seg = (unsigned)(kwid * p.Cin / 64);
+      wk = Conv4Walk{128u, (unsigned)(row - (kwid - 1) * pix - (pix - 128)), 128u, 0u, seg, 2 * seg, (unsigned)khei * seg};
+    } else {                           // chunk, kernel row, tap
+      const long long back = 128 - ((khei - 1) * row + (kwid - 1) * pix);
+      wk = Conv4Walk{(unsigned)pix, (unsigned)(row - (kwid - 1) * pix), (unsigned)(unsigned long long)back, (unsigned)((unsigned long long)back >> 32), (unsigned)kwid, (unsigned)(2 * kwid),
+                     (unsigned)(kwid * khei)};
+    }
+  }
   constexpr int period = G4Period<T, BN>::value;
 #ifdef CONV4_PROBE_NO_LOOP
   if (p.bias == reinterpret_cast<const float*>(8))
 #endif
   conv4_statement<T, BN>(reinterpret_cast<const char*>(p.in), conv4_uniform(reinterpret_cast<const char*>(p.w) + ((size_t)phase * p.Cout + n0) * K * sizeof(T)), (unsigned)(K * sizeof(T)),
-                         (unsigned)(K / 64 / period - 1), __builtin_amdgcn_readfirstlane(lds_offset(smem)), (unsigned)wave, seg, jump, ao);
+                         (unsigned)(K / 64 / period - 1), __builtin_amdgcn_readfirstlane(lds_offset(smem)), (unsigned)wave, wk, ao);
 
 #ifdef CONV4_PROBE_NO_EPILOGUE   // scripts/probe_conv4.hip only (timing of the tile's phases; the product build never defines it)
   if (p.bias != reinterpret_cast<const float*>(8)) return;
@@ -322,6 +342,19 @@ __global__ void vae_phase_weights_kernel(const T* __restrict__ w9, T* __restrict
     for (int ky = ky0; ky <= ky1; ++ky)
       for (int kx = kx0; kx <= kx1; ++kx) acc += (float)w9[((size_t)co * 9 + ky * 3 + kx) * Cin + ci];
     w4[i] = (T)acc;
+  }
+}
+
+// src [rows][taps][Cin] -> dst [rows][Cin / 64][taps][64]: the weight layout of conv4_kernel's default K order (chunk of 64 channels, kernel row, tap)
+template <typename T>
+__global__ void vae_chunk_major_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t rows, int taps, int Cin) {
+  const size_t n = rows * taps * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 64);
+    const int tap = (int)((i / 64) % taps);
+    const int chunk = (int)((i / ((size_t)64 * taps)) % (Cin / 64));
+    const size_t row = i / ((size_t)taps * Cin);
+    dst[i] = src[(row * taps + tap) * Cin + chunk * 64 + c];
   }
 }
 

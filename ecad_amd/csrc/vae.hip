@@ -71,6 +71,8 @@ template <typename T> struct VaeT : VaeBase {
   struct W { void* ptr; Kind kind; int cout, cin; size_t numel; bool loaded; };
   std::map<std::string, W> wt;
   std::map<std::string, void*> phase_w;  // upsampler convolutions: pre-summed 2 x 2 weights of the four output phases (conv4.h)
+  std::map<std::string, void*> chunk_w, phase_chunk_w;  // the 3 x 3 / phase weights again in conv4_kernel's default K order: [Cout][Cin / 64][taps][64]
+  bool korder_tap = false;    // env ECAD_VAE_KORDER=tap: conv4_kernel multiplies in conv3s_kernel's K order (kernel row, tap, channel) -- its bytes; the default fetches each input once
   std::vector<void*> allocs;
   void* zero_page = nullptr;
   // activation buffers
@@ -111,6 +113,12 @@ template <typename T> struct VaeT : VaeBase {
     if (kind == CONVOUT) VHIPCHK(hipMemset(p, 0, bytes));
     allocs.push_back(p);
     wt[name] = W{p, kind, cout, cin, n, false};
+    if (kind == CONV3 && cin % 64 == 0) {
+      void* c = nullptr;
+      VHIPCHK(hipMalloc(&c, bytes));
+      allocs.push_back(c);
+      chunk_w[name] = c;
+    }
     return ECAD_OK;
   }
 #define REG(...) { int rc_ = reg(__VA_ARGS__); if (rc_) return rc_; }
@@ -144,10 +152,13 @@ template <typename T> struct VaeT : VaeBase {
       if (i < 3) {
         const std::string un = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
         REG(un + "weight", CONV3, chans[i], chans[i]) REG(un + "bias", F32, chans[i], 0)
-        void* ph = nullptr;   // [4 phases][Cout][2][2][Cin]: filled by load() from the relaid-out nine-tap weight
+        void *ph = nullptr, *phc = nullptr;   // [4 phases][Cout][2][2][Cin]: filled by load() from the relaid-out nine-tap weight; and chunk-major
         VHIPCHK(hipMalloc(&ph, (size_t)16 * chans[i] * chans[i] * sizeof(T)));
+        VHIPCHK(hipMalloc(&phc, (size_t)16 * chans[i] * chans[i] * sizeof(T)));
         allocs.push_back(ph);
+        allocs.push_back(phc);
         phase_w[un + "weight"] = ph;
+        phase_chunk_w[un + "weight"] = phc;
       }
       prev = chans[i];
     }
@@ -160,6 +171,7 @@ template <typename T> struct VaeT : VaeBase {
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<256>()));
     VHIPCHK(hipFuncSetAttribute((const void*)conv4_kernel<T, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<128>()));
     if (const char* e = getenv("ECAD_VAE_TILE")) tile_linear = strcmp(e, "linear") == 0;
+    if (const char* e = getenv("ECAD_VAE_KORDER")) korder_tap = strcmp(e, "tap") == 0;
     if (const char* e = getenv("ECAD_VAE_UP")) up_nine = strcmp(e, "nine") == 0;
     if (const char* e = getenv("ECAD_VAE_GN")) gn_separate = strcmp(e, "separate") == 0;
     if (const char* e = getenv("ECAD_VAE_CONV")) { conv_tile128 = strcmp(e, "tile128") == 0; conv_gather = strcmp(e, "conv3s") == 0; }
@@ -193,7 +205,12 @@ template <typename T> struct VaeT : VaeBase {
     if (w.kind == CONV3) {
       DISPATCH(vae_relayout_kernel, T, w.cout, w.cin, 9)
       auto ph = phase_w.find(name);
-      if (ph != phase_w.end()) hipLaunchKernelGGL((vae_phase_weights_kernel<T>), dim3(4096), dim3(256), 0, 0, (const T*)w.ptr, (T*)ph->second, w.cout, w.cin);
+      if (ph != phase_w.end()) {
+        hipLaunchKernelGGL((vae_phase_weights_kernel<T>), dim3(4096), dim3(256), 0, 0, (const T*)w.ptr, (T*)ph->second, w.cout, w.cin);
+        hipLaunchKernelGGL((vae_chunk_major_kernel<T>), dim3(4096), dim3(256), 0, 0, (const T*)ph->second, (T*)phase_chunk_w.at(name), (size_t)4 * w.cout, 4, w.cin);
+      }
+      auto cw = chunk_w.find(name);
+      if (cw != chunk_w.end()) hipLaunchKernelGGL((vae_chunk_major_kernel<T>), dim3(4096), dim3(256), 0, 0, (const T*)w.ptr, (T*)cw->second, (size_t)w.cout, 9, w.cin);
     }
     else if (w.kind == CONVOUT) { DISPATCH(vae_relayout_kernel, T, w.cout, w.cin, 9) }
     else if (w.kind == LIN) { DISPATCH(vae_convert_kernel, T, (size_t)numel) }
@@ -262,6 +279,8 @@ template <typename T> struct VaeT : VaeBase {
     if (const int bn = (up || (taps == 9) != bordered) ? 0 : conv4_bn(M, cin, cout, taps)) {
       const dim3 grid((M / 256) * (cout / bn));
       a.tile2d = taps == 9 && !tile_linear && H % 16 == 0 && W % 16 == 0;
+      a.korder = korder_tap ? 1 : 0;
+      if (taps == 9 && !korder_tap && !w_override) a.w = chunk_w.at(name + ".weight");
       // every 3 x 3 convolution's output goes through a GroupNorm next: its statistics come out of this epilogue (per-tile partial sums in tile order)
       if (taps == 9 && !gn_separate && (H * W) % 256 == 0 && (H * W) / 256 <= gn_blocks_cap && cout % 128 == 0) {
         a.gn_part = gn_sums;
@@ -413,7 +432,7 @@ template <typename T> struct VaeT : VaeBase {
           const unsigned grid = (unsigned)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
           hipLaunchKernelGGL((upsample_pad_kernel<T>), dim3(grid), dim3(256), 0, s, cur, bufP, chunks, H / 2, Wd / 2, c, 0);
           ConvArgs a{};
-          a.in = bufP; a.w = phase_w.at(un + ".weight"); a.bias = W_<float>(un + ".bias"); a.out = oth; a.zero_page = zero_page;
+          a.in = bufP; a.w = korder_tap ? phase_w.at(un + ".weight") : phase_chunk_w.at(un + ".weight"); a.korder = korder_tap ? 1 : 0; a.bias = W_<float>(un + ".bias"); a.out = oth; a.zero_page = zero_page;
           a.B = B; a.H = H; a.W = Wd; a.Cin = c; a.Cout = c; a.taps = 9; a.up = 2;
           a.tile2d = !tile_linear && (H / 2) % 16 == 0 && (Wd / 2) % 16 == 0;
           if (stats_of == oth) stats_of = nullptr;

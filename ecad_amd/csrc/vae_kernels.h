@@ -20,6 +20,7 @@ struct ConvArgs {
   int B, H, W;        // OUTPUT spatial size
   int Cin, Cout, taps;  // taps = 9 (3x3, pad 1) or 1 (1x1 / linear)
   int up;             // 1: input is [B, H/2, W/2, Cin], nearest-upsampled on the fly
+  int korder;         // conv4_kernel only: 0 = K runs chunk of 64 channels, kernel row, tap (p.w laid out [Cout][Cin / 64][taps][64]); 1 = kernel row, tap, channel (p.w [Cout][taps][Cin])
   int tile2d;         // conv4_kernel only: 16 x 16 pixel patches as M tiles (needs the M image's H % 16 == W % 16 == 0), see conv4.h
   float* gn_part;     // conv4_kernel only: per-tile GroupNorm partial sums of the OUTPUT, [B H W / 256][32 groups][2] (null: none); needs H W % 256 == 0
   size_t bs_in, bs_w, bs_out;  // conv_gemm_kernel only: element strides of in / w / out per blockIdx.y (batched GEMMs of the mid-block attention; 0 elsewhere)

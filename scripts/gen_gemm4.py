@@ -52,9 +52,11 @@ class Gen:
 
     def __init__(self, dtype, bn, stage=False, gather=False):
         self.dt, self.BN = dtype, bn
-        # gathered A (conv4_kernel of vae_kernels.h: a 3 x 3 convolution over zero-bordered NHWC activations as an implicit GEMM): the byte offsets of the lane's eight A
-        # pieces come in as operands %[ao0] .. %[ao7] instead of row * stride, and the A pointer jumps by %[jump] instead of 128 bytes after every %[seg] stages (from the
-        # three pixels of one image row to the three of the next: the K order is row of taps, tap, channel)
+        # gathered A (conv4_kernel of conv4.h: a 3 x 3 convolution over zero-bordered NHWC activations as an implicit GEMM): the byte offsets of the lane's eight A
+        # pieces come in as operands %[ao0] .. %[ao7] instead of row * stride, and the A pointer walks a cycle of %[kt] steps: %[da] bytes per step, %[db] into the
+        # %[kw]-th and the 2 %[kw]-th, the 64-bit %[dc] : %[dch] (usually negative) into the %[kt]-th, which starts the cycle again.  Two K orders use it: 64-channel
+        # chunk, kernel row, tap (da = one pixel, db = to the next image row, dc = back to the first tap and 128 bytes on: a tile's nine visits to a pixel's chunk are
+        # nine consecutive stages, so it comes from HBM once) and kernel row, tap, channel (da = 128, db = the row jump, kt = all stages: conv3s_kernel's order)
         self.gather = gather
         self.stage = stage                       # BN 288 / 144: after the K loop the statement itself rounds acc + bias into the row-major C tile in LDS (see stage_c)
         self.fp8 = dtype == "fp8"
@@ -146,9 +148,11 @@ class Gen:
 
     def advance(self):
         if self.gather:
-            return [f"s_sub_u32 {s('segc')}, {s('segc')}, 1", f"s_cmp_eq_u32 {s('segc')}, 0", f"s_cselect_b32 {s('tmp0')}, %[jump], 128",
-                    f"s_cselect_b32 {s('segc')}, %[seg], {s('segc')}", f"s_add_u32 {s('ap')}, {s('ap')}, {s('tmp0')}", f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, 0",
-                    f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"]
+            t = s('segc')
+            return [f"s_add_u32 {t}, {t}, 1", f"s_cmp_eq_u32 {t}, %[kw]", f"s_cselect_b32 {s('tmp0')}, %[db], %[da]", f"s_cmp_eq_u32 {t}, %[kw2]",
+                    f"s_cselect_b32 {s('tmp0')}, %[db], {s('tmp0')}", f"s_cmp_eq_u32 {t}, %[kt]", f"s_cselect_b32 {s('tmp0')}, %[dc], {s('tmp0')}",
+                    f"s_cselect_b32 {s('tmp1')}, %[dch], 0", f"s_cselect_b32 {t}, 0, {t}", f"s_add_u32 {s('ap')}, {s('ap')}, {s('tmp0')}",
+                    f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, {s('tmp1')}", f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"]
         return [f"s_add_u32 {s('ap')}, {s('ap')}, 128", f"s_addc_u32 {s('ap_hi')}, {s('ap_hi')}, 0", f"s_add_u32 {s('wp')}, {s('wp')}, 128", f"s_addc_u32 {s('wp_hi')}, {s('wp_hi')}, 0"]
 
     def dma_stage(self, slot):
@@ -337,7 +341,7 @@ class Gen:
         I(f"s_mov_b64 {s2('ap')}, %[ap]")
         I(f"s_mov_b64 {s2('wp')}, %[wp]")
         if self.gather:
-            I(f"s_mov_b32 {s('segc')}, %[seg]")
+            I(f"s_mov_b32 {s('segc')}, 0")
         b2 = len(self.lines)
         if self.fp8:
             I(f"v_mov_b32_e32 {v(self.SC)}, 0x7f7f7f7f")
@@ -541,7 +545,7 @@ OPERANDS = """\
 """
 OPERANDS_G = ("""\
       : /* accumulators stay in AGPRs */
-      : [ap] "s"(ap), [wp] "s"(wp), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero), [seg] "s"(seg), [jump] "s"(jump), """
+      : [ap] "s"(ap), [wp] "s"(wp), [rsw] "s"(rsw), [trips] "s"(trips), [lds] "s"(lds), [wave] "s"(wave), [zero] "s"(zero), [da] "s"(da), [db] "s"(db), [dc] "s"(dc), [dch] "s"(dch), [kw] "s"(kw), [kw2] "s"(kw2), [kt] "s"(kt), """
               + ", ".join(f'[ao{i}] "v"(ao[{i}])' for i in range(8)) + "\n")
 OPERANDS_288 = """\
       : [c8_0] "+v"(c8[0]), [c8_1] "+v"(c8[1]), [c8_2] "+v"(c8[2]), [c8_3] "+v"(c8[3]), [c8_4] "+v"(c8[4]), [c8_5] "+v"(c8[5]), [c8_6] "+v"(c8[6]), [c8_7] "+v"(c8[7])
@@ -602,7 +606,7 @@ def main():
             lines = g.build()
             print(f"{dt} BN {bn}, gathered A: {len(lines)} lines, {sum('v_mfma' in x for x in lines)} MFMAs, {g.NV} VGPRs", file=sys.stderr)
             body = "\n".join('    "' + ln + '\\n"' for ln in lines)
-            parts.append(f"#define GEMM4_ASM_{dt.upper()}_{bn}G(ap, wp, rsw, trips, lds, wave, zero, seg, jump, ao) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
+            parts.append(f"#define GEMM4_ASM_{dt.upper()}_{bn}G(ap, wp, rsw, trips, lds, wave, zero, da, db, dc, dch, kw, kw2, kt, ao) \\\n  asm volatile( \\\n" + "\n".join(x + " \\" for x in body.split("\n")) + "\n"
                          + "\n".join(x + " \\" for x in OPERANDS_G.rstrip("\n").split("\n")) + "\n      : " + clobbers(g.NV, 71) + ")\n")
     text = "\n".join(parts)
     if "--check" in sys.argv:   # the committed header is what this generator writes (tests/test_cpu_host.py)

@@ -9,7 +9,7 @@
 using namespace ecad;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-static int g_tile2d = 0;
+static int g_tile2d = 0, g_korder = 0;
 template <int BN, bool RES> static void run(const char* name, int B, int H, int W, int cin, int cout, int taps, int up, bool stats) {
   const int Hs = up == 2 ? H / 2 : H, Ws = up == 2 ? W / 2 : W;
   const size_t in_elems = taps == 9 ? (size_t)B * (Hs + 2) * (Ws + 2) * cin : (size_t)B * H * W * cin;
@@ -23,6 +23,7 @@ template <int BN, bool RES> static void run(const char* name, int B, int H, int 
   a.in = in; a.w = w; a.bias = bias; a.resid = RES ? res : nullptr; a.out = out; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.taps = taps; a.up = up;
   a.gn_part = stats ? part : nullptr;
   a.tile2d = g_tile2d;
+  a.korder = g_korder;
   CK(hipFuncSetAttribute((const void*)conv4_kernel<f16_t, BN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, conv4_lds_bytes<BN>()));
   const int M = B * Hs * Ws;
   const dim3 grid((M / 256) * (cout / BN) * (up == 2 ? 4 : 1));
@@ -40,7 +41,8 @@ template <int BN, bool RES> static void run(const char* name, int B, int H, int 
 
 int main(int argc, char** argv) {
   g_tile2d = argc > 1 ? atoi(argv[1]) : 0;
-  printf("tile2d %d\n", g_tile2d);
+  g_korder = argc > 2 ? atoi(argv[2]) : 0;
+  printf("tile2d %d, K order %s\n", g_tile2d, g_korder ? "kernel row, tap, channel (conv3s)" : "chunk of 64 channels, kernel row, tap");
   run<128, false>("256^2 128->128 (BN 128)", 16, 256, 256, 128, 128, 9, 0, true);
   run<128, true>("256^2 128->128 + residual", 16, 256, 256, 128, 128, 9, 0, true);
   run<128, false>("256^2 256->128", 16, 256, 256, 256, 128, 9, 0, true);

@@ -81,12 +81,15 @@ def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B
     # the statistics of the GroupNorm behind a conv4 launch come out of its epilogue as per-tile partial sums -- another (fixed) order of the same fp32 additions than
     # gn_stats_kernel's, so THAT is compared at one grey level below; byte identity is of the convolutions, with the statistics kernel kept (ECAD_VAE_GN=separate)
     # (and of the nine-tap form of the upsampler convolutions, ECAD_VAE_UP=nine: their four-phase form sums weights before the products)
+    # and of conv3s's K order (kernel row, tap, channel: ECAD_VAE_KORDER=tap; the default walks chunk of 64 channels, kernel row, tap so that every input byte comes from HBM once)
     monkeypatch.setenv("ECAD_VAE_GN", "separate")
     monkeypatch.setenv("ECAD_VAE_UP", "nine")
+    monkeypatch.setenv("ECAD_VAE_KORDER", "tap")
     for mode in ("conv3s", "default", "fused", "fused-again"):
         if mode == "fused":
             monkeypatch.delenv("ECAD_VAE_GN", raising=False)
             monkeypatch.delenv("ECAD_VAE_UP", raising=False)
+            monkeypatch.delenv("ECAD_VAE_KORDER", raising=False)
         if mode == "conv3s":
             monkeypatch.setenv("ECAD_VAE_CONV", mode)
         else:
@@ -99,7 +102,7 @@ def test_conv4_kernel_over_the_bordered_layout_gives_conv3s_bytes(monkeypatch, B
     d = (out["fused"].int() - out["default"].int()).abs()
     if B == 16:
         assert stats["fused"]["conv_flops_executed"] < stats["fused"]["conv_flops"] == stats["default"]["conv_flops_executed"]
-    print(f"fused GroupNorm statistics + phase-form upsamplers vs gn_stats_kernel + nine taps: {100 * float((d > 0).float().mean()):.4f} % of the bytes differ, max {int(d.max())} level")
+    print(f"product path (chunk-major K order, fused GroupNorm statistics, phase-form upsamplers) vs conv3s order + gn_stats_kernel + nine taps: {100 * float((d > 0).float().mean()):.4f} % of the bytes differ, max {int(d.max())} level")
     assert torch.equal(out["fused"], out["fused-again"])
     # measured: 7.5 % of the bytes move by one level, a handful by two (each order is within one level of the fp32 oracle) -- what ANY change of summation order does to
     # this random-weight decoder (round 3 saw the same 7 % between two runs of its atomics)

@@ -155,6 +155,19 @@ def stamped_traffic(workload: str, dtype: str) -> tuple[dict, str | None, str]:
     return {}, None, stamp
 
 
+def stamped_vae_traffic() -> tuple[float | None, str | None]:
+    """HBM bytes of one decode of a batch of 16 (scripts/pmc_vae.py) from the newest committed profile measured on exactly these kernel sources; otherwise nothing."""
+    stamp = kernel_source_stamp()
+    for f in sorted((ROOT / "profiles").glob("r*_vae_pmc_traffic.json"), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if (d.get("_stamp") or {}).get("kernel_sources") == stamp:
+            return d.get("_total_hbm_bytes_per_decode"), f.name
+    return None, None
+
+
 def stamped_sq(workload: str, dtype: str) -> tuple[dict, str | None]:
     """Counter-based MFMA utilisation per kernel class (scripts/pmc_sq.py: SQ_VALU_MFMA_BUSY_CYCLES over the launch's busy cycles, wave-state fractions, effective
     clock from GRBM_GUI_ACTIVE) from the newest committed profile measured on exactly these kernel sources; otherwise nothing."""
@@ -799,6 +812,7 @@ def main():
             torch.cuda.synchronize()
             dec_ms = ev0.elapsed_time(ev1) / 5
             vs = vae.decode_stats()
+            vae_traffic, vae_traffic_file = stamped_vae_traffic()   # HBM bytes per decode of a batch of 16 by the PMC counters (whole decode, all kernels), stamped like roofline.traffic
             # "achieved" prices the multiplications the launches EXECUTED (the upsampler convolutions run as four 2 x 2 phase convolutions with pre-summed weights: 4/9 of
             # their nine-tap work); the reference's own arithmetic (nine taps everywhere) over the same time is reported beside it, not as the roofline fraction
             res["decode_tail"] = {
@@ -806,7 +820,8 @@ def main():
                 "conv_flops_per_batch": vs["conv_flops"], "conv_flops_executed_per_batch": vs["conv_flops_executed"],
                 "reference_arithmetic_tflops": vs["conv_flops"] / (dec_ms * 1e-3) / 1e12,
                 "roofline": {"bound": "mfma", "kernel": "conv4_kernel (+ conv3s_kernel / conv_gemm_kernel for the small launches): implicit-GEMM convolutions of the AutoencoderKL decoder; GroupNorm / SiLU / border-copy time included in the denominator",
-                             "achieved": vs["conv_flops_executed"] / (dec_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": vs["conv_flops_executed"] / (dec_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS},
+                             "achieved": vs["conv_flops_executed"] / (dec_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": vs["conv_flops_executed"] / (dec_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                             "traffic": vae_traffic if batch == 16 else None, "traffic_source": vae_traffic_file if batch == 16 else None},
             }
             res["config"]["decode_tail_ms_per_batch"] = 1000.0 * (dt - dt_lat)  # against one batch at a time on the same context
             res["config"]["decode_tail"] = "HIP AutoencoderKL decoder (ecad_vae_decode, random-init SD-VAE geometry) -> uint8 NHWC -> host -> PIL; the reference's 84.09 ms/image (A6000) includes this tail"

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+BF16_MEAN_TOL, BF16_BAD_TOL = 1.2, 0.039  # bf16 decoder vs the fp32 oracle: <= 2 x the measured 0.628 level mean / 1.95 % of the bytes above 2 levels
 
 
 def _ref_uint8(vae, latents):
@@ -65,6 +66,32 @@ def test_conv3s_tiles_give_the_bytes_of_the_128_tile_kernel_and_decodes_repeat(m
         assert int(out["conv3s"].max()) - int(out["conv3s"].min()) > 60
         assert torch.equal(out["conv3s"], out["conv3s-again"])
         assert torch.equal(out["tile128"], out["conv3s"])
+
+
+def test_hip_vae_decoder_in_bf16_tracks_the_oracle():
+    """The bf16 instantiation of every decoder path of round 6 (GEMM4_ASM_BF16_*G loops in the chunk-major K order, phase-form upsamplers, fused GroupNorm statistics) at the
+    geometry where all of them run (B 8), against the fp32 oracle.  bf16 keeps eight mantissa bits through ~30 layers: the tolerance is its own (measured mean 0.63 level,
+    1.95 % of the bytes above 2 levels, max 10), about eight times the fp16 figures above."""
+    from ecad_amd.pipelines.vae_decoder import HipVaeDecoder
+    from oracle.vae_ref import AutoencoderKLDecoderOnly  # checker only
+
+    torch.manual_seed(0)
+    ref = AutoencoderKLDecoderOnly().float().eval()
+    with torch.no_grad():
+        for n, p_ in ref.named_parameters():
+            if "norm" in n and n.endswith("weight"):
+                p_.copy_(1.0 + 0.2 * torch.randn_like(p_))
+            if "norm" in n and n.endswith("bias"):
+                p_.copy_(0.1 * torch.randn_like(p_))
+    hip = HipVaeDecoder.from_torch(ref, dtype=torch.bfloat16)
+    lat = torch.randn(8, 4, 32, 32, generator=torch.Generator().manual_seed(1)) * 0.18215 * 2.0
+    exp = _ref_uint8(ref, lat)
+    got = hip.decode_to_uint8(lat.cuda()).cpu()
+    st = hip.decode_stats()
+    assert st["conv4_launches"] > 0 and st["conv_flops_executed"] < st["conv_flops"]
+    d = (got.int() - exp.int()).abs()
+    print(f"bf16 VAE uint8: mean |diff| {float(d.float().mean()):.3f}, max {int(d.max())}, >2 levels: {100 * float((d > 2).float().mean()):.3f} %")
+    assert float(d.float().mean()) < BF16_MEAN_TOL and float((d > 2).float().mean()) < BF16_BAD_TOL
 
 
 @pytest.mark.parametrize("B,h,w,dtype", [(16, 32, 32, torch.float16), (4, 32, 32, torch.float16), (3, 32, 32, torch.float16), (1, 128, 128, torch.float16),
